@@ -1,0 +1,86 @@
+"""Pin the oracle: every stage of oracle/ref_cpu.py against vectors captured from the reference
+itself (tools/gen_golden.py).  The oracle runs the same ATen CPU ops as the reference, so the
+match is exact (torch.equal) wherever the op sequence is the same; a tolerance appears only where
+the restatement orders fp32 ops differently."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from tinyvc_amd import synth
+from helpers import convert_inputs, load_golden, state_dicts
+
+CASES = ["convert_T28", "convert_B2_T50"]
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_stages_match_reference(case):
+    g = load_golden(case)
+    wf, tgt, shift, angle = convert_inputs(g)
+    enc, dec = state_dicts(int(g["weight_seed"]))
+    dm = int(g["decim"])
+    with torch.inference_mode():
+        wfp = R.autopad_waveform(wf)
+        assert wfp.shape[1] % 480 == 0
+        spec = R.spectrogram(wfp)
+        assert torch.equal(spec, _t(g["spec"]))
+        energy = R.estimate_energy(wfp)
+        assert torch.equal(energy, _t(g["energy"]))
+        ssl = R.ssl_features(enc, spec)
+        assert torch.equal(ssl, _t(g["ssl"]))
+        logits = R.pitch_logits(enc, spec)
+        assert torch.equal(logits, _t(g["logits"]))
+        f0 = R.pitch_decode(logits)
+        assert torch.equal(f0, _t(g["f0"]))
+        matched, idx, _ = R.match_features(ssl, tgt, return_indices=True)
+        assert torch.equal(idx, _t(g["knn_idx"]))
+        assert torch.equal(matched, _t(g["matched"]))
+        f0s = R.shift_frequency(f0, shift)
+        assert torch.equal(f0s, _t(g["f0s"]))
+        amps, kern = R.source_net(dec, matched, f0s, energy)
+        assert torch.equal(amps, _t(g["amps"]))
+        assert torch.equal(kern, _t(g["kernel"]))
+        harm = R.oscillate_harmonics(f0s)
+        assert torch.equal(harm[:, :, ::dm], _t(g["harmonics_d"]))
+        src = R.dsp(f0s, amps, kern, angle)
+        assert torch.equal(src[:, 15], _t(g["noise"]))
+        assert torch.equal(src[:, :, ::dm], _t(g["source_d"]))
+        out, skips = R.filter_net(dec, matched, f0s, energy, src, return_skips=True)
+        for i, s in enumerate(skips):
+            assert torch.equal(s[:, :, ::(dm if i < 2 else 1)], _t(g[f"skip{i}_d"])), f"skip{i}"
+        assert torch.equal(out.squeeze(1), _t(g["wave"]))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_convert_end_to_end(case):
+    g = load_golden(case)
+    wf, tgt, shift, angle = convert_inputs(g)
+    enc, dec = state_dicts(int(g["weight_seed"]))
+    wave = R.convert(enc, dec, wf, tgt, shift, angle)
+    assert torch.equal(wave, _t(g["wave"]))
+
+
+@pytest.mark.parametrize("case,pv", [("stream_6blocks", False), ("stream_pv_3blocks", True)])
+def test_oracle_streaming(case, pv):
+    g = load_golden(case)
+    enc, dec = state_dicts(0)
+    tgt = synth.synth_index(int(g["index_size"]), seed=int(g["index_seed"]))
+    blocks = synth.synth_wave(1, 6 * 1920, seed=int(g["wave_seed"]))[0].view(6, 1920)
+    st = R.StreamState(block_size=1920, extra_size=3840)
+    assert st.input_size == int(g["input_size"]) == 13440
+    for i in range(int(g["n_blocks"])):
+        angle = synth.synth_angle(1, st.input_size // 480, int(g["noise_seed"]) + i)
+        out, shift = R.stream_callback(st, enc, dec, tgt, 0.0, blocks[i], angle, use_phase_vocoder=pv)
+        assert shift == int(g["shift"][i])
+        assert torch.equal(out, _t(g["out"][i]))
+
+
+def test_knn_fixture_gaps_are_decidable():
+    """Index equality is only meaningful when the fp64 top-5 gaps dwarf fp32 dot-product noise
+    (~2e-7 for unit vectors of dim 768)."""
+    for case in CASES:
+        assert float(load_golden(case)["knn_min_gap64"]) > 5e-6
