@@ -1,0 +1,149 @@
+/* tinyvc_hip.h — C ABI of libtinyvc_hip.so: the MI355X (gfx950) implementation of the tinyvc
+ * voice-conversion inference path (encoder -> kNN match -> source-filter decoder -> SOLA).
+ *
+ * The reference (uthree/tinyvc) has no FFI: its boundary is the Python module surface.  Each entry
+ * point below names the reference function it stands in for; the Python host package
+ * (`tinyvc_amd.module.*`) re-exposes those functions with the reference's names and binds them to
+ * these symbols through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every `const float*` / `float*` tensor argument is a DEVICE pointer owned by the caller
+ *     (a torch tensor's data_ptr), fp32, contiguous, channels-first [B, C, T] like the reference;
+ *     16-byte aligned;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all
+ *     work is enqueued asynchronously on it; nothing here synchronises the device;
+ *   - `ws` is a caller-allocated device scratch buffer of at least tvc_workspace_bytes() bytes;
+ *     the library never allocates device memory after tvc_finalize_weights();
+ *   - return value: 0 = ok, negative = tvc_status; tvc_last_error() has the message;
+ *   - one ctx per device, one host thread per ctx at a time.
+ */
+#ifndef TINYVC_HIP_H
+#define TINYVC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tvc_ctx tvc_ctx;
+
+enum tvc_status {
+    TVC_OK = 0,
+    TVC_ERR_ARG = -1,        /* bad shape / null pointer / unsupported size */
+    TVC_ERR_HIP = -2,        /* a HIP runtime call failed (message has the hipError string) */
+    TVC_ERR_STATE = -3,      /* weights missing / not finalised */
+    TVC_ERR_WORKSPACE = -4   /* workspace too small */
+};
+
+#define TVC_ABI_VERSION 1
+int tvc_version(void);
+
+/* lifecycle ------------------------------------------------------------------------------- */
+int tvc_ctx_create(int hip_device, tvc_ctx** out);
+void tvc_ctx_destroy(tvc_ctx* ctx);
+const char* tvc_last_error(const tvc_ctx* ctx);
+
+/* Checkpoint loading: one call per state_dict entry of encoder.pt / decoder.pt
+ * (reference infer.py:34-37 `load_state_dict`; key names and shapes: SURVEY.md §2.4).
+ * `host_data` is a HOST pointer to contiguous fp32; the library copies it.  After the last tensor,
+ * tvc_finalize_weights() packs everything into the kernels' layouts and uploads once. */
+int tvc_load_tensor(tvc_ctx* ctx, const char* state_dict_key, const float* host_data,
+                    const int64_t* shape, int ndim);
+/* 512-entry class->Hz table of PitchEstimator.id2freq (reference encoder.py:48-54), host fp32. */
+int tvc_set_pitch_table(tvc_ctx* ctx, const float* host_freqs, int n);
+int tvc_finalize_weights(tvc_ctx* ctx);
+
+/* Scratch needed by any entry point below for a batch of B utterances of L samples (L % 480 == 0)
+ * matched against an index of N vectors. */
+int tvc_workspace_bytes(tvc_ctx* ctx, int B, int64_t L, int64_t N, size_t* out_bytes);
+
+/* front end ------------------------------------------------------------------------------- */
+/* module.utils.spectrogram (reference module/utils/spectrogram.py:8-15):
+ * wav [B, L] -> spec [B, 961, T], T = L/480. */
+int tvc_stft_mag_f32(tvc_ctx* ctx, void* stream, const float* wav, float* spec, int B, int64_t L,
+                     void* ws, size_t ws_bytes);
+/* module.utils.estimate_energy (reference module/utils/energy_estimation.py:9-14):
+ * wav [B, L] -> energy [B, 1, L]. */
+int tvc_energy_f32(tvc_ctx* ctx, void* stream, const float* wav, float* energy, int B, int64_t L,
+                   void* ws, size_t ws_bytes);
+
+/* encoder --------------------------------------------------------------------------------- */
+/* Encoder.infer (reference module/tinyvc/encoder.py:113-116): spec [B,961,T] ->
+ * ssl [B,768,T], f0 [B,1,T]; `logits` [B,512,T] is optional (NULL to skip): Encoder.forward's
+ * second output (encoder.py:108-111). */
+int tvc_encoder_f32(tvc_ctx* ctx, void* stream, const float* spec, float* ssl, float* f0,
+                    float* logits, int B, int T, void* ws, size_t ws_bytes);
+
+/* kNN match ------------------------------------------------------------------------------- */
+/* Prepare an index for matching, once per index: index [768, N] (the [1,768,N] tensor of index.pt,
+ * reference extract_index.py:58 / infer.py:49, or Generator.encode's output) -> `prepared`, a blob of
+ * tvc_knn_prepared_elems(N) floats holding the columns scaled by 1/(||r||+1e-6)
+ * (feature_retrieval.py:25 recomputes that on every call) and the raw vectors row-major for the
+ * final gather. */
+int64_t tvc_knn_prepared_elems(int64_t N);
+int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, float* prepared,
+                              int64_t N);
+/* match_features(source, reference, k=4, alpha=0, metrics='cos')
+ * (reference module/tinyvc/feature_retrieval.py:15-33): src [B,768,T] against one shared prepared
+ * index -> out [B,768,T]; idx_out [B,T,4] int64 (nullable) = topk indices, ties -> lowest index. */
+int tvc_knn_match_f32(tvc_ctx* ctx, void* stream, const float* src, const float* prepared, int64_t N,
+                      float* out, int64_t* idx_out, int B, int T, void* ws, size_t ws_bytes);
+
+/* pitch shift ----------------------------------------------------------------------------- */
+/* module.utils.shift_frequency (reference module/utils/pitch_shift.py:5-15), n elements. */
+int tvc_shift_frequency_f32(tvc_ctx* ctx, void* stream, const float* f0, float* out, int64_t n,
+                            float semitones);
+
+/* decoder --------------------------------------------------------------------------------- */
+/* Decoder.infer (reference module/tinyvc/decoder.py:253-257): content [B,768,T], f0 [B,1,T],
+ * energy [B,1,L], noise_angle [B,961,T] = the uniform phases of decoder.py:78 in [-pi,pi)
+ * (NULL -> drawn on device from `seed`; not bit-comparable with torch's CPU generator)
+ * -> wave [B, L]. */
+int tvc_decoder_f32(tvc_ctx* ctx, void* stream, const float* content, const float* f0,
+                    const float* energy, const float* noise_angle, uint64_t seed, float* wave,
+                    int B, int T, void* ws, size_t ws_bytes);
+/* Stage outputs of the decoder for parity tests (any pointer may be NULL):
+ * amps [B,15,T], kernel [B,961,T] (SourceNet.forward, decoder.py:126-134),
+ * source [B,16,L] (Decoder.dsp, decoder.py:259-266). Same arguments as tvc_decoder_f32. */
+int tvc_decoder_stages_f32(tvc_ctx* ctx, void* stream, const float* content, const float* f0,
+                           const float* energy, const float* noise_angle, uint64_t seed,
+                           float* wave, float* amps, float* kernel, float* source, int B, int T,
+                           void* ws, size_t ws_bytes);
+
+/* Decoder.dsp (reference module/tinyvc/decoder.py:259-266): f0 [B,1,T], amps [B,15,T],
+ * kernel [B,961,T], noise_angle as above -> source [B,16,L] (15 harmonics + filtered noise). */
+int tvc_dsp_f32(tvc_ctx* ctx, void* stream, const float* f0, const float* amps, const float* kernel,
+                const float* noise_angle, uint64_t seed, float* source, int B, int T, void* ws,
+                size_t ws_bytes);
+
+/* whole path ------------------------------------------------------------------------------ */
+/* Generator.convert (reference module/infer/generator.py:26-34): wav [B, L] (already padded to
+ * L % 480 == 0, autopad_waveform is a host-side zero pad) -> wave [B, L]. */
+int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* prepared_index,
+                    int64_t N, float pitch_shift, const float* noise_angle, uint64_t seed,
+                    float* wave, int B, int64_t L, void* ws, size_t ws_bytes);
+
+/* streaming tail -------------------------------------------------------------------------- */
+/* StreamInfer.audio_callback after convert (reference module/infer/stream.py:74-95), batched over
+ * S streams: y [S, Ly] converted buffers; sola_buf [S,1920] in/out; fade_in [1920] = the sin^2
+ * window init_buffer builds (stream.py:61; fade_out = 1 - fade_in); out [S, block];
+ * shift_out [S] int32 (nullable) = chosen SOLA lag.  block = 1920 in the reference;
+ * crossfade = search = 1920, delay = 3840 (stream.py:48-50).  use_phase_vocoder selects
+ * phase_vocoder() (stream.py:9-26) instead of the sin^2 cross-fade. */
+int tvc_sola_f32(tvc_ctx* ctx, void* stream, const float* y, float* sola_buf, const float* fade_in,
+                 float* out, int32_t* shift_out, int S, int64_t Ly, int block,
+                 int use_phase_vocoder);
+
+/* measurement ----------------------------------------------------------------------------- */
+/* When enabled, every stage (and every FilterNet block) is bracketed by a hipEvent pair on the
+ * launch stream.  tvc_profile_read() synchronises those events and writes
+ * "region=milliseconds;..." (summed per region name since the previous read) into buf. */
+int tvc_profile_enable(tvc_ctx* ctx, int on);
+int tvc_profile_read(tvc_ctx* ctx, char* buf, size_t buf_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYVC_HIP_H */

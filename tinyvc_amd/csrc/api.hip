@@ -1,0 +1,517 @@
+// libtinyvc_hip.so — context, checkpoint packing, workspace sizing and the extern "C" surface.
+#include <cmath>
+
+#include "tvc_common.h"
+
+using namespace tvc;
+
+namespace {
+
+struct ArenaBuilder {
+    std::vector<float> buf;
+    size_t put(const std::vector<float>& v) {
+        size_t off = (buf.size() + 63) & ~size_t(63);  // 256-byte aligned
+        buf.resize(off + v.size(), 0.f);
+        std::copy(v.begin(), v.end(), buf.begin() + off);
+        return off;
+    }
+};
+
+// Offsets are resolved to device pointers after the single upload.
+struct Fixup {
+    const float** slot;
+    size_t off;
+};
+
+int pad_m(int M) {
+    if (M <= 32) return 32;
+    if (M <= 64) return 64;
+    if (M <= 96) return 96;
+    if (M % 96 == 0 && M % 128 != 0) return M;
+    return (M + 127) / 128 * 128;
+}
+
+struct Packer {
+    tvc_ctx* ctx;
+    ArenaBuilder ab;
+    std::vector<Fixup> fix;
+    std::string missing;
+
+    const HostTensor* find(const std::string& key) {
+        auto it = ctx->host.find(key);
+        if (it == ctx->host.end()) {
+            if (missing.empty()) missing = key;
+            return nullptr;
+        }
+        return &it->second;
+    }
+    void raw(const std::string& key, const float** slot, size_t expect) {
+        const HostTensor* t = find(key);
+        if (!t) return;
+        if (t->data.size() != expect) {
+            if (missing.empty()) missing = key + " (wrong size)";
+            return;
+        }
+        fix.push_back({slot, ab.put(t->data)});
+    }
+    // Stack one or more conv weights [cout_i][cin][taps] along cout into At[k][m].
+    void conv(const std::vector<std::string>& names, PackedW* pw, int cin, int taps) {
+        int M = 0;
+        std::vector<const HostTensor*> ws, bs;
+        for (auto& n : names) {
+            const HostTensor* w = find(n + ".weight");
+            const HostTensor* b = find(n + ".bias");
+            if (!w || !b) return;
+            if (w->shape.size() != 3 || w->shape[1] != cin || w->shape[2] != taps ||
+                (int64_t)b->data.size() != w->shape[0]) {
+                if (missing.empty()) missing = n + " (unexpected shape)";
+                return;
+            }
+            ws.push_back(w);
+            bs.push_back(b);
+            M += (int)w->shape[0];
+        }
+        pw->M = M;
+        pw->K = cin * taps;
+        pw->cin = cin;
+        pw->taps = taps;
+        pw->Mpad = pad_m(M);
+        pw->Kpad = (pw->K + 15) / 16 * 16;
+        std::vector<float> At((size_t)pw->Kpad * pw->Mpad, 0.f), bias(pw->Mpad, 0.f);
+        int m0 = 0;
+        for (size_t i = 0; i < ws.size(); ++i) {
+            int cout = (int)ws[i]->shape[0];
+            for (int m = 0; m < cout; ++m) {
+                bias[m0 + m] = bs[i]->data[m];
+                for (int k = 0; k < pw->K; ++k) At[(size_t)k * pw->Mpad + m0 + m] = ws[i]->data[(size_t)m * pw->K + k];
+            }
+            m0 += cout;
+        }
+        fix.push_back({&pw->At, ab.put(At)});
+        fix.push_back({&pw->bias, ab.put(bias)});
+    }
+    void convnext(const std::string& p, ConvNeXtW* w, int C, int dil) {
+        w->C = C;
+        w->dilation = dil;
+        raw(p + ".c1.weight", &w->dw_w, (size_t)C * 7);
+        raw(p + ".c1.bias", &w->dw_b, C);
+        raw(p + ".norm.gamma", &w->ln_g, C);
+        raw(p + ".norm.beta", &w->ln_b, C);
+        conv({p + ".c2"}, &w->c2, C, 1);
+        raw(p + ".grn.gamma", &w->grn_g, 2 * C);
+        raw(p + ".grn.beta", &w->grn_b, 2 * C);
+        conv({p + ".c3"}, &w->c3, 2 * C, 1);
+    }
+};
+
+void build_dft_tables(Packer& pk, tvc_ctx* ctx) {
+    const int N = kNfft;
+    const double two_pi = 6.283185307179586476925286766559;
+    // forward: At[k = n][m], m = 2f -> cos * hann, 2f+1 -> -sin * hann   (torch.stft convention)
+    {
+        PackedW& pw = ctx->stft_dft;
+        pw.M = 2 * kBins;
+        pw.K = N;
+        pw.Mpad = pad_m(pw.M);
+        pw.Kpad = N;
+        pw.cin = N;
+        pw.taps = 1;
+        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f), bias(pw.Mpad, 0.f);
+        for (int n = 0; n < N; ++n) {
+            double hann = 0.5 - 0.5 * std::cos(two_pi * n / N);
+            for (int f = 0; f < kBins; ++f) {
+                double ang = two_pi * (double)(((long)f * n) % N) / N;
+                At[(size_t)n * pw.Mpad + 2 * f] = (float)(std::cos(ang) * hann);
+                At[(size_t)n * pw.Mpad + 2 * f + 1] = (float)(-std::sin(ang) * hann);
+            }
+        }
+        pk.fix.push_back({&pw.At, pk.ab.put(At)});
+        pk.fix.push_back({&pw.bias, pk.ab.put(bias)});
+    }
+    // inverse (c2r, 'backward' 1/N norm): At[k][m = n]; k < 961: Re X_k, k >= 961: Im X_{k-961}
+    {
+        PackedW& pw = ctx->istft_dft;
+        pw.M = N;
+        pw.K = 2 * kBins;
+        pw.Mpad = pad_m(pw.M);
+        pw.Kpad = (pw.K + 15) / 16 * 16;
+        pw.cin = pw.K;
+        pw.taps = 1;
+        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f), bias(pw.Mpad, 0.f);
+        for (int f = 0; f < kBins; ++f) {
+            double c = (f == 0 || f == N / 2) ? 1.0 : 2.0;
+            for (int n = 0; n < N; ++n) {
+                double ang = two_pi * (double)(((long)f * n) % N) / N;
+                At[(size_t)f * pw.Mpad + n] = (float)(c * std::cos(ang) / N);
+                if (f != 0 && f != N / 2) At[(size_t)(kBins + f) * pw.Mpad + n] = (float)(-c * std::sin(ang) / N);
+            }
+        }
+        pk.fix.push_back({&pw.At, pk.ab.put(At)});
+        pk.fix.push_back({&pw.bias, pk.ab.put(bias)});
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tvc_version(void) { return TVC_ABI_VERSION; }
+
+int tvc_ctx_create(int hip_device, tvc_ctx** out) {
+    if (!out) return TVC_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || hip_device < 0 || hip_device >= count) return TVC_ERR_HIP;
+    tvc_ctx* c = new tvc_ctx();
+    c->device = hip_device;
+    {   // constant tables (windowed forward DFT, inverse real DFT): independent of any checkpoint
+        Packer pk{c};
+        build_dft_tables(pk, c);
+        if (hipSetDevice(hip_device) != hipSuccess ||
+            hipMalloc((void**)&c->const_arena, pk.ab.buf.size() * sizeof(float)) != hipSuccess ||
+            hipMemcpy(c->const_arena, pk.ab.buf.data(), pk.ab.buf.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            if (c->const_arena) (void)hipFree(c->const_arena);
+            delete c;
+            return TVC_ERR_HIP;
+        }
+        for (auto& f : pk.fix) *f.slot = c->const_arena + f.off;
+    }
+    *out = c;
+    return TVC_OK;
+}
+
+void tvc_ctx_destroy(tvc_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->const_arena) (void)hipFree(ctx->const_arena);
+    delete ctx;
+}
+
+const char* tvc_last_error(const tvc_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
+
+int tvc_load_tensor(tvc_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim) {
+    if (!ctx || !key || !host_data || !shape || ndim < 1 || ndim > 4) return fail(ctx, TVC_ERR_ARG, "tvc_load_tensor: bad argument");
+    size_t n = 1;
+    HostTensor t;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_load_tensor(%s): bad shape", key);
+        n *= (size_t)shape[i];
+        t.shape.push_back(shape[i]);
+    }
+    t.data.assign(host_data, host_data + n);
+    ctx->host[key] = std::move(t);
+    ctx->enc_ready = ctx->dec_ready = false;
+    return TVC_OK;
+}
+
+int tvc_set_pitch_table(tvc_ctx* ctx, const float* host_freqs, int n) {
+    if (!ctx || !host_freqs || n != kPitchClasses) return fail(ctx, TVC_ERR_ARG, "pitch table must have %d entries", kPitchClasses);
+    ctx->pitch_table.assign(host_freqs, host_freqs + n);
+    ctx->enc_ready = ctx->dec_ready = false;
+    return TVC_OK;
+}
+
+int tvc_finalize_weights(tvc_ctx* ctx) {
+    if (!ctx) return TVC_ERR_ARG;
+    ctx->enc_ready = ctx->dec_ready = false;
+    Packer pk{ctx};
+    if (ctx->pitch_table.size() == (size_t)kPitchClasses)
+        pk.fix.push_back({&ctx->pitch_freq, pk.ab.put(ctx->pitch_table)});
+    else
+        pk.missing = "pitch table (tvc_set_pitch_table)";
+
+    // encoder (encoder.py:75-116): both estimators read the same spectrogram -> stacked input 1x1
+    pk.conv({"ssl_feature_estimator.input_layer", "pitch_estimator.input_layer"}, &ctx->enc_in, kBins, 1);
+    pk.raw("ssl_feature_estimator.norm.gamma", &ctx->ssl_ln_g, kSslCh);
+    pk.raw("ssl_feature_estimator.norm.beta", &ctx->ssl_ln_b, kSslCh);
+    pk.raw("pitch_estimator.norm.gamma", &ctx->pit_ln_g, kPitchCh);
+    pk.raw("pitch_estimator.norm.beta", &ctx->pit_ln_b, kPitchCh);
+    static const int ssl_dil[6] = {1, 3, 9, 1, 1, 1};
+    for (int i = 0; i < 6; ++i)
+        pk.convnext("ssl_feature_estimator.mid_layers." + std::to_string(i), &ctx->ssl_mid[i], kSslCh, ssl_dil[i]);
+    for (int i = 0; i < 4; ++i)
+        pk.convnext("pitch_estimator.mid_layers." + std::to_string(i), &ctx->pit_mid[i], kPitchCh, 1);
+    pk.conv({"ssl_feature_estimator.output_layer"}, &ctx->ssl_out, kSslCh, 1);
+    pk.conv({"pitch_estimator.output_layer"}, &ctx->pit_out, kPitchCh, 1);
+    const std::string missing_enc = pk.missing;
+    pk.missing.clear();
+
+    // source net (decoder.py:102-134)
+    pk.conv({"source_net.content_in"}, &ctx->src_content_in, kSslDim, 1);
+    pk.raw("source_net.energy_in.weight", &ctx->src_e_w, kSrcCh);
+    pk.raw("source_net.energy_in.bias", &ctx->src_e_b, kSrcCh);
+    pk.raw("source_net.f0_in.weight", &ctx->src_f_w, kSrcCh);
+    pk.raw("source_net.f0_in.bias", &ctx->src_f_b, kSrcCh);
+    for (int i = 0; i < 3; ++i)
+        pk.convnext("source_net.mid_layers." + std::to_string(i), &ctx->src_mid[i], kSrcCh, 1);
+    pk.conv({"source_net.to_amps"}, &ctx->src_to_amps, kSrcCh, 1);
+    pk.conv({"source_net.to_kernel"}, &ctx->src_to_kernel, kSrcCh, 1);
+
+    // filter net (decoder.py:193-233)
+    static const int ch[5] = {384, 192, 96, 48, 24};
+    static const int fac[5] = {2, 3, 4, 4, 5};
+    pk.conv({"filter_net.content_in"}, &ctx->flt_content_in, kSslDim, 1);
+    pk.raw("filter_net.f0_in.weight", &ctx->flt_f_w, ch[0]);
+    pk.raw("filter_net.f0_in.bias", &ctx->flt_f_b, ch[0]);
+    pk.conv({"filter_net.downs.0"}, &ctx->flt_down0, kHarm + 2, 3);
+    for (int i = 1; i <= 4; ++i) {
+        DownW& d = ctx->downs[i - 1];
+        d.cin = ch[5 - i];
+        d.cout = ch[4 - i];
+        d.factor = fac[5 - i];
+        std::string p = "filter_net.downs." + std::to_string(i);
+        pk.conv({p + ".down_res"}, &d.res, d.cin, 1);
+        pk.conv({p + ".c1"}, &d.c1, d.cin, 3);
+        pk.conv({p + ".c2"}, &d.c2, d.cin, 3);
+        pk.conv({p + ".c3"}, &d.c3, d.cin, 3);
+    }
+    for (int i = 0; i < 5; ++i) {
+        UpW& u = ctx->ups[i];
+        u.cin = ch[i];
+        u.cout = i < 4 ? ch[i + 1] : ch[4];
+        u.factor = fac[i];
+        std::string p = "filter_net.ups." + std::to_string(i);
+        pk.conv({p + ".c1"}, &u.c1, u.cin, 3);
+        pk.conv({p + ".c2"}, &u.c2, u.cin, 3);
+        pk.conv({p + ".c3"}, &u.c3, u.cin, 3);
+        pk.conv({p + ".c4"}, &u.c4, u.cin, 3);
+        pk.conv({p + ".c5"}, &u.c5, u.cin, 1);
+        pk.conv({p + ".film1.to_scale", p + ".film1.to_shift"}, &u.film1, u.cin, 1);
+        pk.conv({p + ".film2.to_scale", p + ".film2.to_shift"}, &u.film2, u.cin, 1);
+    }
+    pk.conv({"filter_net.output_layer"}, &ctx->flt_out, ch[4], 7);
+
+    const std::string missing_dec = pk.missing;
+    snprintf(ctx->enc_missing, sizeof(ctx->enc_missing), "%s", missing_enc.c_str());
+    snprintf(ctx->dec_missing, sizeof(ctx->dec_missing), "%s", missing_dec.c_str());
+    if (!missing_enc.empty() && !missing_dec.empty())
+        return fail(ctx, TVC_ERR_STATE, "no complete checkpoint: encoder lacks %s; decoder lacks %s", missing_enc.c_str(), missing_dec.c_str());
+
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->arena) {
+        TVC_HIP(ctx, hipFree(ctx->arena));
+        ctx->arena = nullptr;
+    }
+    ctx->arena_floats = pk.ab.buf.size();
+    TVC_HIP(ctx, hipMalloc((void**)&ctx->arena, ctx->arena_floats * sizeof(float)));
+    TVC_HIP(ctx, hipMemcpy(ctx->arena, pk.ab.buf.data(), ctx->arena_floats * sizeof(float), hipMemcpyHostToDevice));
+    for (auto& f : pk.fix) *f.slot = ctx->arena + f.off;
+    ctx->enc_ready = missing_enc.empty();
+    ctx->dec_ready = missing_dec.empty();
+    ctx->host.clear();   // staged copies are no longer needed
+    return TVC_OK;
+}
+
+enum { NEED_NONE = 0, NEED_ENC = 1, NEED_DEC = 2 };
+static int need_ready(tvc_ctx* ctx, int need) {
+    if (!ctx) return TVC_ERR_ARG;
+    if ((need & NEED_ENC) && !ctx->enc_ready)
+        return fail(ctx, TVC_ERR_STATE, "encoder weights not loaded (%s)", ctx->enc_missing[0] ? ctx->enc_missing : "tvc_finalize_weights not called");
+    if ((need & NEED_DEC) && !ctx->dec_ready)
+        return fail(ctx, TVC_ERR_STATE, "decoder weights not loaded (%s)", ctx->dec_missing[0] ? ctx->dec_missing : "tvc_finalize_weights not called");
+    return 0;
+}
+
+static int convert_impl(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, const float* prepared,
+                        int64_t N, float pitch_shift, const float* angle,
+                        uint64_t seed, float* wave, int B, int64_t L) {
+    const int T = (int)(L / kHop);
+    float* spec = ws.get<float>((size_t)B * kBins * T);
+    float* energy = ws.get<float>((size_t)B * L);
+    float* ssl = ws.get<float>((size_t)B * kSslDim * T);
+    float* matched = ws.get<float>((size_t)B * kSslDim * T);
+    float* f0 = ws.get<float>((size_t)B * T);
+    float* f0s = ws.get<float>((size_t)B * T);
+    size_t m = ws.mark();
+    {
+        ProfScope ps(ctx, s, dry, "stft");
+        TVC_CHECK(run_stft(ctx, s, ws, dry, wav, spec, B, L));
+    }
+    ws.release(m);
+    {
+        ProfScope ps(ctx, s, dry, "energy");
+        TVC_CHECK(run_energy(ctx, s, ws, dry, wav, energy, B, L));
+    }
+    ws.release(m);
+    {
+        ProfScope ps(ctx, s, dry, "encoder");
+        TVC_CHECK(run_encoder(ctx, s, ws, dry, spec, ssl, f0, nullptr, B, T));
+    }
+    ws.release(m);
+    {
+        ProfScope ps(ctx, s, dry, "knn");
+        TVC_CHECK(run_knn(ctx, s, ws, dry, ssl, prepared, N, matched, nullptr, B, T));
+    }
+    ws.release(m);
+    if (!dry) TVC_CHECK(run_shift(ctx, s, f0, f0s, (int64_t)B * T, pitch_shift));
+    TVC_CHECK(run_decoder(ctx, s, ws, dry, matched, f0s, energy, angle, seed, wave, nullptr, nullptr, nullptr, B, T));
+    ws.release(m);
+    return 0;
+}
+
+int tvc_workspace_bytes(tvc_ctx* ctx, int B, int64_t L, int64_t N, size_t* out_bytes) {
+    TVC_CHECK(need_ready(ctx, NEED_NONE));
+    if (!out_bytes || B <= 0 || L <= 0 || L % kHop != 0 || N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_workspace_bytes: need B>0, L%%480==0, N>=4");
+    Ws ws(nullptr, 0, true);
+    TVC_CHECK(convert_impl(ctx, nullptr, ws, true, nullptr, nullptr, N, 0.f, nullptr, 0, nullptr, B, L));
+    *out_bytes = ws.peak + 4096;
+    return TVC_OK;
+}
+
+// Workspace is validated *before* launching: every entry runs its driver once in dry mode.
+#define TVC_RUN(call_dry, call_real)                                                              \
+    {                                                                                             \
+        Ws dryws(nullptr, 0, true);                                                               \
+        {                                                                                         \
+            Ws& ws = dryws;                                                                       \
+            int rc0 = (call_dry);                                                                 \
+            if (rc0) return rc0;                                                                  \
+        }                                                                                         \
+        if (dryws.peak > ws_bytes)                                                                \
+            return fail(ctx, TVC_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", dryws.peak, ws_bytes); \
+        Ws ws(wsp, ws_bytes, false);                                                              \
+        return (call_real);                                                                       \
+    }
+
+int tvc_stft_mag_f32(tvc_ctx* ctx, void* stream, const float* wav, float* spec, int B, int64_t L, void* wsp, size_t ws_bytes) {
+    TVC_CHECK(need_ready(ctx, NEED_NONE));
+    if (!wav || !spec || B <= 0 || L <= 0 || L % kHop) return fail(ctx, TVC_ERR_ARG, "tvc_stft_mag_f32: bad argument (L must be a multiple of 480)");
+    if (L < kNfft / 2 + 1) return fail(ctx, TVC_ERR_ARG, "tvc_stft_mag_f32: L must exceed 960 (reflect padding)");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    TVC_RUN(run_stft(ctx, s, ws, true, wav, spec, B, L), run_stft(ctx, s, ws, false, wav, spec, B, L));
+}
+
+int tvc_energy_f32(tvc_ctx* ctx, void* stream, const float* wav, float* energy, int B, int64_t L, void* wsp, size_t ws_bytes) {
+    TVC_CHECK(need_ready(ctx, NEED_NONE));
+    if (!wav || !energy || B <= 0 || L < 128) return fail(ctx, TVC_ERR_ARG, "tvc_energy_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    TVC_RUN(run_energy(ctx, s, ws, true, wav, energy, B, L), run_energy(ctx, s, ws, false, wav, energy, B, L));
+}
+
+int tvc_encoder_f32(tvc_ctx* ctx, void* stream, const float* spec, float* ssl, float* f0, float* logits, int B, int T, void* wsp, size_t ws_bytes) {
+    TVC_CHECK(need_ready(ctx, NEED_ENC));
+    if (!spec || !ssl || !f0 || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_encoder_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    TVC_RUN(run_encoder(ctx, s, ws, true, spec, ssl, f0, logits, B, T), run_encoder(ctx, s, ws, false, spec, ssl, f0, logits, B, T));
+}
+
+int64_t tvc_knn_prepared_elems(int64_t N) {
+    if (N <= 0) return 0;
+    int64_t npad = (N + 127) / 128 * 128;
+    return (int64_t)kSslDim * npad + N * (int64_t)kSslDim;
+}
+
+int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, float* prepared, int64_t N) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!index || !prepared || N <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_prepare_index_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_prepare_index(ctx, (hipStream_t)stream, index, prepared, N);
+}
+
+int tvc_knn_match_f32(tvc_ctx* ctx, void* stream, const float* src, const float* prepared, int64_t N, float* out,
+                      int64_t* idx_out, int B, int T, void* wsp, size_t ws_bytes) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!src || !prepared || !out || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_match_f32: bad argument");
+    if (N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_knn_match_f32: index needs at least k=4 vectors (torch.topk raises too)");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    TVC_RUN(run_knn(ctx, s, ws, true, src, prepared, N, out, idx_out, B, T),
+            run_knn(ctx, s, ws, false, src, prepared, N, out, idx_out, B, T));
+}
+
+int tvc_shift_frequency_f32(tvc_ctx* ctx, void* stream, const float* f0, float* out, int64_t n, float semitones) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!f0 || !out || n <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_shift_frequency_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_shift(ctx, (hipStream_t)stream, f0, out, n, semitones);
+}
+
+int tvc_decoder_stages_f32(tvc_ctx* ctx, void* stream, const float* content, const float* f0, const float* energy,
+                           const float* noise_angle, uint64_t seed, float* wave, float* amps, float* kernel,
+                           float* source, int B, int T, void* wsp, size_t ws_bytes) {
+    TVC_CHECK(need_ready(ctx, NEED_DEC));
+    if (!content || !f0 || !energy || !wave || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_decoder_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    TVC_RUN(run_decoder(ctx, s, ws, true, content, f0, energy, noise_angle, seed, wave, amps, kernel, source, B, T),
+            run_decoder(ctx, s, ws, false, content, f0, energy, noise_angle, seed, wave, amps, kernel, source, B, T));
+}
+
+int tvc_dsp_f32(tvc_ctx* ctx, void* stream, const float* f0, const float* amps, const float* kernel, const float* noise_angle,
+                uint64_t seed, float* source, int B, int T, void* wsp, size_t ws_bytes) {
+    TVC_CHECK(need_ready(ctx, NEED_NONE));
+    if (!f0 || !amps || !kernel || !source || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_dsp_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    TVC_RUN(run_dsp(ctx, s, ws, true, f0, amps, kernel, noise_angle, seed, source, B, T),
+            run_dsp(ctx, s, ws, false, f0, amps, kernel, noise_angle, seed, source, B, T));
+}
+
+int tvc_decoder_f32(tvc_ctx* ctx, void* stream, const float* content, const float* f0, const float* energy,
+                    const float* noise_angle, uint64_t seed, float* wave, int B, int T, void* wsp, size_t ws_bytes) {
+    return tvc_decoder_stages_f32(ctx, stream, content, f0, energy, noise_angle, seed, wave, nullptr, nullptr, nullptr, B, T, wsp, ws_bytes);
+}
+
+int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* prepared, int64_t N,
+                    float pitch_shift, const float* noise_angle, uint64_t seed, float* wave, int B, int64_t L,
+                    void* wsp, size_t ws_bytes) {
+    TVC_CHECK(need_ready(ctx, NEED_ENC | NEED_DEC));
+    if (!wav || !prepared || !wave || B <= 0 || L <= 0 || L % kHop) return fail(ctx, TVC_ERR_ARG, "tvc_convert_f32: bad argument (L must be a positive multiple of 480)");
+    if (L < kNfft / 2 + 1) return fail(ctx, TVC_ERR_ARG, "tvc_convert_f32: L must exceed 960 samples (STFT reflect padding, as torch.stft requires)");
+    if (N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_convert_f32: index needs at least k=4 vectors");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    TVC_RUN(convert_impl(ctx, s, ws, true, wav, prepared, N, pitch_shift, noise_angle, seed, wave, B, L),
+            convert_impl(ctx, s, ws, false, wav, prepared, N, pitch_shift, noise_angle, seed, wave, B, L));
+}
+
+int tvc_profile_enable(tvc_ctx* ctx, int on) {
+    if (!ctx) return TVC_ERR_ARG;
+    ctx->profiling = on != 0;
+    return TVC_OK;
+}
+
+// Synchronises the recorded events and writes "name=ms;name=ms;..." (durations summed per region
+// name since the last read) into buf.
+int tvc_profile_read(tvc_ctx* ctx, char* buf, size_t buf_bytes) {
+    if (!ctx || !buf || buf_bytes < 2) return TVC_ERR_ARG;
+    std::vector<std::pair<std::string, double>> agg;
+    for (auto& r : ctx->regions) {
+        float ms = 0.f;
+        if (r.a && r.b && hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            bool found = false;
+            for (auto& a : agg)
+                if (a.first == r.name) {
+                    a.second += ms;
+                    found = true;
+                }
+            if (!found) agg.push_back({r.name, ms});
+        }
+        if (r.a) (void)hipEventDestroy(r.a);
+        if (r.b) (void)hipEventDestroy(r.b);
+    }
+    ctx->regions.clear();
+    std::string out;
+    for (auto& a : agg) {
+        char tmp[160];
+        snprintf(tmp, sizeof(tmp), "%s=%.6f;", a.first.c_str(), a.second);
+        out += tmp;
+    }
+    snprintf(buf, buf_bytes, "%s", out.c_str());
+    return TVC_OK;
+}
+
+int tvc_sola_f32(tvc_ctx* ctx, void* stream, const float* y, float* sola_buf, const float* fade_in, float* out,
+                 int32_t* shift_out, int S, int64_t Ly, int block, int use_phase_vocoder) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!y || !sola_buf || !fade_in || !out || S <= 0 || block <= 0 || Ly < block + kSolaCross + kSolaSearch + kSolaDelay)
+        return fail(ctx, TVC_ERR_ARG, "tvc_sola_f32: bad argument (Ly must cover block+1920+1920+3840)");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_sola(ctx, (hipStream_t)stream, y, sola_buf, fade_in, out, shift_out, S, Ly, block, use_phase_vocoder);
+}
+
+}  // extern "C"

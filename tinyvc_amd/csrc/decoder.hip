@@ -1,0 +1,358 @@
+// Source-filter decoder (decoder.py:24-266): SourceNet, additive harmonic oscillator, filtered-noise
+// iSTFT, and the FilterNet U-Net.
+#include "igemm.h"
+#include "small_kernels.h"
+#include "tvc_common.h"
+
+namespace tvc {
+
+// =================================================================================================
+// Harmonic oscillator (decoder.py:24-54).  The phase of harmonic m is the running sum over the whole
+// utterance of fl32(fl32(fs*m)/24000), accumulated in fp64 and rounded to fp32 per sample — what
+// ATen's CPU cumsum does for fp32 input.  Hierarchical scan: per-frame fp64 sums, an exclusive scan
+// of those per (utterance, harmonic), then an in-frame scan fused with sin / voiced gate / amplitude.
+// =================================================================================================
+
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+// grid (T, B): csum[b][m][t] = sum over the frame's 480 samples of inc_m
+static __global__ __launch_bounds__(256) void harm_frame_sum_kernel(const float* __restrict__ f0, double* __restrict__ csum,
+                                                                    int T, float scale) {
+    __shared__ double red[4][kHarm];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* f = f0 + (long)b * T;
+    double acc[kHarm];
+#pragma unroll
+    for (int m = 0; m < kHarm; ++m) acc[m] = 0.0;
+    for (int i = tid; i < kHop; i += 256) {
+        Lerp c = lerp_coord(t * kHop + i, scale, T);
+        float fs = lerp_eval(c, f[c.i0], f[c.i1]);
+#pragma unroll
+        for (int m = 0; m < kHarm; ++m) acc[m] += (double)__fdiv_rn(__fmul_rn(fs, (float)(m + 1)), 24000.f);
+    }
+#pragma unroll
+    for (int m = 0; m < kHarm; ++m) {
+        double v = acc[m];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][m] = v;
+    }
+    __syncthreads();
+    if (tid < kHarm) csum[((long)b * kHarm + tid) * T + t] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// grid (15, B), one wavefront: exclusive prefix over frames, in place
+static __global__ __launch_bounds__(64) void harm_frame_scan_kernel(double* __restrict__ csum, int T) {
+    double* p = csum + ((long)blockIdx.y * kHarm + blockIdx.x) * T;
+    const int lane = threadIdx.x;
+    double carry = 0.0;
+    for (int base = 0; base < T; base += 64) {
+        int i = base + lane;
+        double v = i < T ? p[i] : 0.0;
+        double inc = wave_incl_scan(v, lane);
+        if (i < T) p[i] = carry + (inc - v);
+        carry += __shfl(inc, 63);
+    }
+}
+
+// grid (T, B): thread i < 240 owns samples 2i, 2i+1 of the frame
+static __global__ __launch_bounds__(256) void harm_synth_kernel(const float* __restrict__ f0, const float* __restrict__ amps,
+                                                                const double* __restrict__ coff, float* __restrict__ source,
+                                                                int T, float scale_size, float scale_amp) {
+    __shared__ double wtot[4];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool act = tid < kHop / 2;
+    const long L = (long)T * kHop;
+    const float* f = f0 + (long)b * T;
+    const int p0 = t * kHop + 2 * tid;
+    float fs[2], uv[2];
+    Lerp ca[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        int p = act ? p0 + e : t * kHop;
+        Lerp c = lerp_coord(p, scale_size, T);
+        float a0 = f[c.i0], a1 = f[c.i1];
+        fs[e] = lerp_eval(c, a0, a1);
+        uv[e] = lerp_eval(c, a0 > 20.f ? 1.f : 0.f, a1 > 20.f ? 1.f : 0.f);
+        ca[e] = lerp_coord(p, scale_amp, T);
+    }
+    for (int m = 0; m < kHarm; ++m) {
+        double d0 = act ? (double)__fdiv_rn(__fmul_rn(fs[0], (float)(m + 1)), 24000.f) : 0.0;
+        double d1 = act ? (double)__fdiv_rn(__fmul_rn(fs[1], (float)(m + 1)), 24000.f) : 0.0;
+        double pair = d0 + d1;
+        double inc = wave_incl_scan(pair, lane);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        double base = coff[((long)b * kHarm + m) * T + t];
+        for (int w = 0; w < wave; ++w) base += wtot[w];
+        __syncthreads();
+        if (act) {
+            double e0 = base + (inc - pair) + d0;
+            double e1 = e0 + d1;
+            const float* am = amps + ((long)b * kHarm + m) * T;
+            float o[2];
+            double cyc[2] = {e0, e1};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float I = (float)cyc[e];                     // prefix rounded to fp32 (torch.cumsum output)
+                float frac = I - floorf(I);                  // I % 1
+                float theta = __fmul_rn(6.2831854820251465f, frac);
+                float hsin = __fmul_rn(sinf(theta), uv[e]);
+                float amp = lerp_eval(ca[e], am[ca[e].i0], am[ca[e].i1]);
+                o[e] = __fmul_rn(hsin, amp);
+            }
+            *reinterpret_cast<float2*>(source + ((long)b * 16 + m) * L + p0) = make_float2(o[0], o[1]);
+        }
+    }
+}
+
+// =================================================================================================
+// Filtered noise (decoder.py:63-85): Y = exp(i angle) * kernel, zero frame prepended, rectangular
+// window iSTFT (n_fft 1920, hop 480).  The per-frame c2r transform is a dense [1920 x 1922]
+// contraction; overlap-add divides by the frame-count envelope and trims 960 samples per side.
+// =================================================================================================
+static __global__ void noise_spec_kernel(const float* __restrict__ kern, const float* __restrict__ angle,
+                                         float* __restrict__ yri, long n_per_b, int B) {
+    // yri[b][0..960][t] = cos(angle)*kernel, yri[b][961..1921][t] = sin(angle)*kernel
+    long total = n_per_b * B;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long b = i / n_per_b, r = i - b * n_per_b;
+        float a = angle[i], k = kern[i], sn, cs;
+        sincosf(a, &sn, &cs);
+        yri[b * 2 * n_per_b + r] = __fmul_rn(cs, k);
+        yri[b * 2 * n_per_b + n_per_b + r] = __fmul_rn(sn, k);
+    }
+}
+
+// counter-based uniform phases when the caller gives no `noise_angle`
+static __global__ void angle_fill_kernel(float* __restrict__ angle, long n, uint64_t seed) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        float u = (float)(z >> 40) * (1.0f / 16777216.0f);  // [0, 1)
+        angle[i] = u * 6.2831854820251465f - 3.1415927410125732f;
+    }
+}
+
+static __global__ void noise_ola_kernel(const float* __restrict__ frames, float* __restrict__ source, int B, int T) {
+    const long L = (long)T * kHop;
+    long total = (long)B * L;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long b = i / L;
+        int p = (int)(i - b * L);
+        int q = p + kNfft / 2;  // position in the untrimmed signal; frame f (0..T) covers [480 f, 480 f + 1920)
+        int f_hi = q / kHop;
+        if (f_hi > T) f_hi = T;
+        int f_lo = (q - (kNfft - 1) + kHop - 1) / kHop;
+        if (q - (kNfft - 1) <= 0) f_lo = 0;
+        float s = 0.f;
+        for (int f = f_lo > 1 ? f_lo : 1; f <= f_hi; ++f)  // frame 0 is the zero pad (decoder.py:81)
+            s = __fadd_rn(s, frames[((long)b * T + (f - 1)) * kNfft + (q - f * kHop)]);
+        source[(b * 16 + 15) * L + p] = s / (float)(f_hi - f_lo + 1);
+    }
+}
+
+// =================================================================================================
+// SourceNet + dsp
+// =================================================================================================
+static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
+                          const float* energy, float* amps, float* kern, int B, int T) {
+    const int ncols = B * T;
+    float* ef = ws.get<float>((size_t)B * T);
+    float* x = ws.get<float>((size_t)B * kSrcCh * T);
+    if (!dry) {
+        hipLaunchKernelGGL(window_max_kernel, dim3(grid_for((long)ncols * 64)), dim3(256), 0, s, energy, ef, (long)B, T, kHop);
+        LoadPlain ld{content, kSslDim, T, (long)kSslDim * T};
+        EpiSumCond ep{x, ctx->src_content_in.bias, ef, f0, ctx->src_e_w, ctx->src_e_b, ctx->src_f_w, ctx->src_f_b, kSrcCh, T, ncols};
+        igemm_launch(s, ctx->src_content_in.At, ctx->src_content_in.Mpad, ctx->src_content_in.Kpad, ncols, T, ld, ep);
+    }
+    for (int i = 0; i < 3; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->src_mid[i], x, B, T));
+    if (dry) return 0;
+    LoadPlain ld{x, kSrcCh, T, (long)kSrcCh * T};
+    EpiBias<ACT_ELU1, false> ea{amps, ctx->src_to_amps.bias, nullptr, kHarm, T, ncols, (long)kHarm * T, 0};
+    igemm_launch(s, ctx->src_to_amps.At, ctx->src_to_amps.Mpad, ctx->src_to_amps.Kpad, ncols, T, ld, ea);
+    EpiBias<ACT_ELU1, false> ek{kern, ctx->src_to_kernel.bias, nullptr, kBins, T, ncols, (long)kBins * T, 0};
+    igemm_launch(s, ctx->src_to_kernel.At, ctx->src_to_kernel.Mpad, ctx->src_to_kernel.Kpad, ncols, T, ld, ek);
+    return launch_check(ctx, "source_net");
+}
+
+// Decoder.dsp (decoder.py:259-266): f0 [B,1,T], amps [B,15,T], kernel [B,961,T] -> source [B,16,L]
+int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, const float* amps, const float* kern,
+            const float* angle, uint64_t seed, float* source, int B, int T) {
+    const int ncols = B * T;
+    const long L = (long)T * kHop;
+    double* csum = ws.get<double>((size_t)B * kHarm * T);
+    float* yri = ws.get<float>((size_t)B * 2 * kBins * T);
+    float* frames = ws.get<float>((size_t)B * T * kNfft);
+    float* ang = angle ? nullptr : ws.get<float>((size_t)B * kBins * T);
+    if (dry) return 0;
+    // harmonics -> source[:, 0:15]
+    const float scale_size = (float)T / (float)L;         // F.interpolate(f0, Lw): size given
+    const float scale_amp = (float)(1.0 / (double)kHop);  // F.interpolate(amps, scale_factor=480)
+    hipLaunchKernelGGL(harm_frame_sum_kernel, dim3(T, B), dim3(256), 0, s, f0, csum, T, scale_size);
+    hipLaunchKernelGGL(harm_frame_scan_kernel, dim3(kHarm, B), dim3(64), 0, s, csum, T);
+    hipLaunchKernelGGL(harm_synth_kernel, dim3(T, B), dim3(256), 0, s, f0, amps, csum, source, T, scale_size, scale_amp);
+    // noise -> source[:, 15]
+    if (!angle) {
+        hipLaunchKernelGGL(angle_fill_kernel, dim3(grid_for((long)B * kBins * T)), dim3(256), 0, s, ang, (long)B * kBins * T, seed);
+        angle = ang;
+    }
+    hipLaunchKernelGGL(noise_spec_kernel, dim3(grid_for((long)B * kBins * T)), dim3(256), 0, s, kern, angle, yri, (long)kBins * T, B);
+    {
+        LoadPlain ld{yri, 2 * kBins, T, (long)2 * kBins * T};
+        EpiFrames ep{frames, ncols};
+        igemm_launch(s, ctx->istft_dft.At, ctx->istft_dft.Mpad, ctx->istft_dft.Kpad, ncols, T, ld, ep);
+    }
+    hipLaunchKernelGGL(noise_ola_kernel, dim3(grid_for((long)B * L)), dim3(256), 0, s, frames, source, B, T);
+    return launch_check(ctx, "dsp");
+}
+
+// =================================================================================================
+// FilterNet (decoder.py:193-233) — round-1 form: one implicit-GEMM launch per Conv1d, with
+// leaky_relu / replicate padding / FiLM / residuals fused into the loaders and epilogues, so HBM
+// traffic is the layer-boundary model of SURVEY.md §8d (each conv reads its input, writes its output).
+// =================================================================================================
+template <int TAPS, bool LRELU, class Epi>
+static void conv_launch(hipStream_t s, const PackedW& w, const float* x, int cin, int len, int dil, int B, const Epi& ep) {
+    LoadConv<TAPS, LRELU> ld{x, cin, len, dil, (long)cin * len};
+    igemm_launch(s, w.At, w.Mpad, w.Kpad, B * len, len, ld, ep);
+}
+
+static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
+                      const float* energy, const float* source, float* wave, int B, int T) {
+    const long L = (long)T * kHop;
+    static const int ch[5] = {384, 192, 96, 48, 24};
+    // level lengths: skip i lives at len_dn[i]
+    long len_dn[5] = {L, L / 5, L / 20, L / 80, L / 240};
+    float* skip[5];
+    for (int i = 0; i < 5; ++i) skip[i] = ws.get<float>((size_t)B * ch[4 - i] * len_dn[i]);
+    float* x = ws.get<float>((size_t)B * ch[0] * T);
+
+    if (!dry) {
+        ProfScope ps(ctx, s, dry, "filter.in+down0");
+        LoadPlain ld{content, kSslDim, T, (long)kSslDim * T};
+        EpiSumCond ep{x, ctx->flt_content_in.bias, nullptr, f0, nullptr, nullptr, ctx->flt_f_w, ctx->flt_f_b, ch[0], T, B * T};
+        igemm_launch(s, ctx->flt_content_in.At, ctx->flt_content_in.Mpad, ctx->flt_content_in.Kpad, B * T, T, ld, ep);
+        LoadConvCat17 l0{source, energy, (int)L};
+        EpiBias<ACT_NONE, false> e0{skip[0], ctx->flt_down0.bias, nullptr, 24, (int)L, (int)(B * L), 24 * L, 0};
+        igemm_launch(s, ctx->flt_down0.At, ctx->flt_down0.Mpad, ctx->flt_down0.Kpad, (int)(B * L), (int)L, l0, e0);
+    }
+    // down path
+    for (int i = 1; i <= 4; ++i) {
+        const DownW& d = ctx->downs[i - 1];
+        const int lin = (int)len_dn[i - 1], len = (int)len_dn[i];
+        size_t mk = ws.mark();
+        float* xi = ws.get<float>((size_t)B * d.cin * len);
+        float* res = ws.get<float>((size_t)B * d.cout * len);
+        float* h1 = ws.get<float>((size_t)B * d.cin * len);
+        float* h2 = ws.get<float>((size_t)B * d.cin * len);
+        if (!dry) {
+            static const char* names[4] = {"filter.down1", "filter.down2", "filter.down3", "filter.down4"};
+            ProfScope ps(ctx, s, dry, names[i - 1]);
+            // F.interpolate(scale_factor=1/f): ATen uses scale = 1/(1/f) = f
+            hipLaunchKernelGGL(lerp_resize_kernel, dim3(grid_for((long)B * d.cin * len)), dim3(256), 0, s, skip[i - 1], xi,
+                               (long)B * d.cin, lin, len, (float)d.factor);
+            const int nc = B * len;
+            {
+                LoadPlain ld{xi, d.cin, len, (long)d.cin * len};
+                EpiBias<ACT_NONE, false> ep{res, d.res.bias, nullptr, d.cout, len, nc, (long)d.cout * len, 0};
+                igemm_launch(s, d.res.At, d.res.Mpad, d.res.Kpad, nc, len, ld, ep);
+            }
+            conv_launch<3, true>(s, d.c1, xi, d.cin, len, 1, B, EpiBias<ACT_NONE, false>{h1, d.c1.bias, nullptr, d.cin, len, nc, (long)d.cin * len, 0});
+            conv_launch<3, true>(s, d.c2, h1, d.cin, len, 2, B, EpiBias<ACT_NONE, false>{h2, d.c2.bias, nullptr, d.cin, len, nc, (long)d.cin * len, 0});
+            conv_launch<3, true>(s, d.c3, h2, d.cin, len, 4, B, EpiBias<ACT_NONE, true>{skip[i], d.c3.bias, res, d.cout, len, nc, (long)d.cout * len, (long)d.cout * len});
+        }
+        ws.release(mk);
+    }
+    // up path: level outputs are persistent, block temporaries are released per level
+    float* xlev[5];
+    {
+        long l = T;
+        for (int i = 0; i < 5; ++i) {
+            l *= ctx->ups[i].factor;
+            xlev[i] = ws.get<float>((size_t)B * ctx->ups[i].cout * l);
+        }
+    }
+    long len = T;
+    for (int i = 0; i < 5; ++i) {
+        const UpW& u = ctx->ups[i];
+        const int lin = (int)len;
+        len *= u.factor;
+        const int lo = (int)len, C = u.cin, nc = B * lo;
+        const float* cond = skip[4 - i];
+        size_t mk = ws.mark();
+        float* xu = ws.get<float>((size_t)B * C * lo);
+        float* film = ws.get<float>((size_t)B * 2 * C * lo);
+        float* h = ws.get<float>((size_t)B * C * lo);
+        float* x1 = ws.get<float>((size_t)B * C * lo);
+        if (!dry) {
+            static const char* names[5] = {"filter.up0", "filter.up1", "filter.up2", "filter.up3", "filter.up4"};
+            ProfScope ps(ctx, s, dry, names[i]);
+            // F.interpolate(scale_factor=f): ATen uses scale = float(1/f)
+            hipLaunchKernelGGL(lerp_resize_kernel, dim3(grid_for((long)B * C * lo)), dim3(256), 0, s, x, xu, (long)B * C, lin, lo,
+                               (float)(1.0 / (double)u.factor));
+            for (int half = 0; half < 2; ++half) {
+                const PackedW& fw = half ? u.film2 : u.film1;
+                const PackedW& ca = half ? u.c3 : u.c1;
+                const PackedW& cb = half ? u.c4 : u.c2;
+                const int da = half ? 9 : 1, db = half ? 27 : 3;
+                const float* xin = half ? x1 : xu;
+                float* xout = half ? xu : x1;  // 2nd half writes over xu (its input and residual are x1)
+                {
+                    LoadPlain ld{cond, C, lo, (long)C * lo};
+                    EpiBias<ACT_NONE, false> ep{film, fw.bias, nullptr, 2 * C, lo, nc, (long)2 * C * lo, 0};
+                    igemm_launch(s, fw.At, fw.Mpad, fw.Kpad, nc, lo, ld, ep);
+                }
+                conv_launch<3, true>(s, ca, xin, C, lo, da, B, EpiBias<ACT_NONE, false>{h, ca.bias, nullptr, C, lo, nc, (long)C * lo, 0});
+                conv_launch<3, true>(s, cb, h, C, lo, db, B, EpiFilm{xout, cb.bias, film, xin, C, lo, nc});
+            }
+            LoadPlain ld{xu, C, lo, (long)C * lo};
+            EpiBias<ACT_NONE, false> ep{xlev[i], u.c5.bias, nullptr, u.cout, lo, nc, (long)u.cout * lo, 0};
+            igemm_launch(s, u.c5.At, u.c5.Mpad, u.c5.Kpad, nc, lo, ld, ep);
+        }
+        ws.release(mk);
+        x = xlev[i];
+    }
+    if (!dry) {
+        ProfScope ps(ctx, s, dry, "filter.out");
+        conv_launch<7, false>(s, ctx->flt_out, x, 24, (int)L, 1, B, EpiBias<ACT_NONE, false>{wave, ctx->flt_out.bias, nullptr, 1, (int)L, (int)(B * L), L, 0});
+    }
+    return dry ? 0 : launch_check(ctx, "filter_net");
+}
+
+int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
+                const float* energy, const float* angle, uint64_t seed, float* wave, float* amps_out,
+                float* kernel_out, float* source_out, int B, int T) {
+    const long L = (long)T * kHop;
+    float* amps = amps_out ? amps_out : ws.get<float>((size_t)B * kHarm * T);
+    float* kern = kernel_out ? kernel_out : ws.get<float>((size_t)B * kBins * T);
+    float* source = source_out ? source_out : ws.get<float>((size_t)B * 16 * L);
+    size_t mk = ws.mark();
+    {
+        ProfScope ps(ctx, s, dry, "source_net");
+        TVC_CHECK(run_source_net(ctx, s, ws, dry, content, f0, energy, amps, kern, B, T));
+    }
+    ws.release(mk);
+    {
+        ProfScope ps(ctx, s, dry, "dsp");
+        TVC_CHECK(run_dsp(ctx, s, ws, dry, f0, amps, kern, angle, seed, source, B, T));
+    }
+    ws.release(mk);
+    ProfScope ps(ctx, s, dry, "filter_net");
+    TVC_CHECK(run_filter(ctx, s, ws, dry, content, f0, energy, source, wave, B, T));
+    ws.release(mk);
+    return 0;
+}
+
+}  // namespace tvc

@@ -1,0 +1,206 @@
+// Encoder (encoder.py:75-116) and the ConvNeXt-v2 layer shared with SourceNet (convnext.py:7-58).
+#include "igemm.h"
+#include "small_kernels.h"
+#include "tvc_common.h"
+
+namespace tvc {
+
+// -------------------------------------------------------------------------------------------------
+// [depthwise k7 dilated replicate-padded conv] + LayerNorm over channels, per time column.
+// One workgroup = 64 consecutive time steps of one utterance; the 4 waves split the channels
+// (c = wave, wave+4, ...), lanes run along time (coalesced).  Two-pass moments (mean, then
+// centred variance) through a 4x64 LDS exchange; every thread re-reads only values it wrote.
+template <bool DW>
+static __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* x, float* y,
+                                                               const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+                                                               const float* __restrict__ g, const float* __restrict__ bta,
+                                                               int C, int T, int dil) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + lane;
+    const bool ok = t < T;
+    const int tc = ok ? t : T - 1;
+    const float* xb = x + (long)b * C * T;
+    float* yb = y + (long)b * C * T;
+
+    float sum = 0.f;
+    for (int c = wave; c < C; c += 4) {
+        float v;
+        if (DW) {
+            const float* xr = xb + (long)c * T;
+            v = dw_b[c];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                int tt = tc + (j - 3) * dil;
+                tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+                v = fmaf(dw_w[c * 7 + j], xr[tt], v);
+            }
+            if (ok) yb[(long)c * T + t] = v;
+        } else {
+            v = xb[(long)c * T + tc];
+        }
+        sum += v;
+    }
+    red[wave][lane] = sum;
+    __syncthreads();
+    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    __syncthreads();
+    float sq = 0.f;
+    for (int c = wave; c < C; c += 4) {
+        float v = (DW ? yb : xb)[(long)c * T + tc] - mean;
+        sq = fmaf(v, v, sq);
+    }
+    red[wave][lane] = sq;
+    __syncthreads();
+    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    if (!ok) return;
+    for (int c = wave; c < C; c += 4) {
+        long i = (long)c * T + t;
+        float v = (DW ? yb : xb)[i];
+        yb[i] = fmaf((v - mean) * rstd, g[c], bta[c]);
+    }
+}
+
+// gx[b][c] = || h[b][c][:] ||_2   (one wavefront per row)
+static __global__ void grn_norm_kernel(const float* __restrict__ h, float* __restrict__ gx, long rows, int T) {
+    const int lane = threadIdx.x & 63;
+    long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long r = wave; r < rows; r += nwaves) {
+        const float* p = h + r * T;
+        float s = 0.f;
+        for (int t = lane; t < T; t += 64) s = fmaf(p[t], p[t], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) gx[r] = sqrtf(s);
+    }
+}
+
+// nx[b][c] = gx[b][c] / (mean_c gx[b][:] + 1e-6)   (one workgroup per utterance)
+static __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restrict__ gx, float* __restrict__ nx, int C2) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* g = gx + (long)b * C2;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C2; c += 256) s += g[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C2;
+    const float den = mean + 1e-6f;
+    for (int c = threadIdx.x; c < C2; c += 256) nx[(long)b * C2 + c] = g[c] / den;
+}
+
+int run_layernorm(tvc_ctx* ctx, hipStream_t s, float* x, const float* g, const float* b, int B, int C, int T) {
+    hipLaunchKernelGGL((dwconv_ln_kernel<false>), dim3((T + 63) / 64, B), dim3(256), 0, s, x, x, nullptr, nullptr, g, b, C, T, 1);
+    return launch_check(ctx, "layernorm");
+}
+
+int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW& w, float* x, int B, int T) {
+    const int C = w.C, C2 = 2 * w.C, ncols = B * T;
+    size_t mk = ws.mark();
+    float* y = ws.get<float>((size_t)B * C * T);
+    float* h = ws.get<float>((size_t)B * C2 * T);
+    float* gx = ws.get<float>((size_t)B * C2);
+    float* nx = ws.get<float>((size_t)B * C2);
+    ws.release(mk);
+    if (dry) return 0;
+    hipLaunchKernelGGL((dwconv_ln_kernel<true>), dim3((T + 63) / 64, B), dim3(256), 0, s, x, y, w.dw_w, w.dw_b, w.ln_g, w.ln_b, C, T, w.dilation);
+    {
+        LoadPlain ld{y, C, T, (long)C * T};
+        EpiBias<ACT_GELU, false> ep{h, w.c2.bias, nullptr, C2, T, ncols, (long)C2 * T, 0};
+        igemm_launch(s, w.c2.At, w.c2.Mpad, w.c2.Kpad, ncols, T, ld, ep);
+    }
+    hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)B * C2 * 64)), dim3(256), 0, s, h, gx, (long)B * C2, T);
+    hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, s, gx, nx, C2);
+    {
+        LoadGrn ld{h, nx, w.grn_g, w.grn_b, C2, T};
+        EpiBias<ACT_NONE, true> ep{x, w.c3.bias, x, C, T, ncols, (long)C * T, (long)C * T};
+        igemm_launch(s, w.c3.At, w.c3.Mpad, w.c3.Kpad, ncols, T, ld, ep);
+    }
+    return launch_check(ctx, "convnext");
+}
+
+// stacked input 1x1 (961 -> 384 | 128): rows < M0 go to y0, the rest to y1
+struct EpiSplit {
+    float* y0;
+    float* y1;
+    const float* bias;
+    int M0, M1, T, ncols;
+    __device__ __forceinline__ void store(int n, int m, const float v[4]) const {
+        if (n >= ncols) return;
+        int b = n / T, t = n - b * T;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int mm = m + r;
+            float o = v[r] + bias[mm < M0 + M1 ? mm : 0];
+            if (mm < M0)
+                y0[((long)b * M0 + mm) * T + t] = o;
+            else if (mm < M0 + M1)
+                y1[((long)b * M1 + mm - M0) * T + t] = o;
+        }
+    }
+};
+
+// PitchEstimator.decode (encoder.py:61-67): top-4 logits (ties -> lower class id), softmax over
+// them, expectation of the class frequencies, <= 20 Hz -> 0.   One thread per (b, t) column.
+static __global__ void pitch_decode_kernel(const float* __restrict__ logits, const float* __restrict__ freq,
+                                           float* __restrict__ f0, int B, int T) {
+    long n = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (n >= (long)B * T) return;
+    int b = (int)(n / T), t = (int)(n - (long)b * T);
+    const float* p = logits + (long)b * kPitchClasses * T + t;
+    float v0 = -INFINITY, v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
+    int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    for (int c = 0; c < kPitchClasses; ++c) {
+        float v = p[(long)c * T];
+        if (v > v3) {
+            if (v > v0) { v3 = v2; i3 = i2; v2 = v1; i2 = i1; v1 = v0; i1 = i0; v0 = v; i0 = c; }
+            else if (v > v1) { v3 = v2; i3 = i2; v2 = v1; i2 = i1; v1 = v; i1 = c; }
+            else if (v > v2) { v3 = v2; i3 = i2; v2 = v; i2 = c; }
+            else { v3 = v; i3 = c; }
+        }
+    }
+    float e0 = 1.f, e1 = expf(v1 - v0), e2 = expf(v2 - v0), e3 = expf(v3 - v0);
+    float den = ((e0 + e1) + e2) + e3;
+    float acc = __fmul_rn(e0 / den, freq[i0]);
+    acc = __fadd_rn(acc, __fmul_rn(e1 / den, freq[i1]));
+    acc = __fadd_rn(acc, __fmul_rn(e2 / den, freq[i2]));
+    acc = __fadd_rn(acc, __fmul_rn(e3 / den, freq[i3]));
+    f0[n] = acc <= 20.f ? 0.f : acc;
+}
+
+int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec, float* ssl, float* f0,
+                float* logits, int B, int T) {
+    const int ncols = B * T;
+    float* xs = ws.get<float>((size_t)B * kSslCh * T);
+    float* xp = ws.get<float>((size_t)B * kPitchCh * T);
+    float* lg = logits ? logits : ws.get<float>((size_t)B * kPitchClasses * T);
+    if (!dry) {
+        LoadPlain ld{spec, kBins, T, (long)kBins * T};
+        EpiSplit ep{xs, xp, ctx->enc_in.bias, kSslCh, kPitchCh, T, ncols};
+        igemm_launch(s, ctx->enc_in.At, ctx->enc_in.Mpad, ctx->enc_in.Kpad, ncols, T, ld, ep);
+        TVC_CHECK(run_layernorm(ctx, s, xs, ctx->ssl_ln_g, ctx->ssl_ln_b, B, kSslCh, T));
+        TVC_CHECK(run_layernorm(ctx, s, xp, ctx->pit_ln_g, ctx->pit_ln_b, B, kPitchCh, T));
+    }
+    for (int i = 0; i < 6; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->ssl_mid[i], xs, B, T));
+    for (int i = 0; i < 4; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->pit_mid[i], xp, B, T));
+    if (dry) return 0;
+    {
+        LoadPlain ld{xs, kSslCh, T, (long)kSslCh * T};
+        EpiBias<ACT_NONE, false> ep{ssl, ctx->ssl_out.bias, nullptr, kSslDim, T, ncols, (long)kSslDim * T, 0};
+        igemm_launch(s, ctx->ssl_out.At, ctx->ssl_out.Mpad, ctx->ssl_out.Kpad, ncols, T, ld, ep);
+    }
+    {
+        LoadPlain ld{xp, kPitchCh, T, (long)kPitchCh * T};
+        EpiBias<ACT_NONE, false> ep{lg, ctx->pit_out.bias, nullptr, kPitchClasses, T, ncols, (long)kPitchClasses * T, 0};
+        igemm_launch(s, ctx->pit_out.At, ctx->pit_out.Mpad, ctx->pit_out.Kpad, ncols, T, ld, ep);
+    }
+    hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 255) / 256), dim3(256), 0, s, lg, ctx->pitch_freq, f0, B, T);
+    return launch_check(ctx, "encoder");
+}
+
+}  // namespace tvc

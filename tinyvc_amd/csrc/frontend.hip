@@ -1,0 +1,74 @@
+// Front end: |STFT| (spectrogram.py:8-15), energy envelope (energy_estimation.py:9-14),
+// semitone shift (pitch_shift.py:5-15).
+#include "igemm.h"
+#include "small_kernels.h"
+#include "tvc_common.h"
+
+namespace tvc {
+
+// ---- |STFT| as a windowed-DFT contraction on the fp32 matrix pipe --------------------------------
+// spec[b][f][t] = | sum_n hann[n] x_b[(t+1)*480 + n - 960 (reflected)] e^{-2 pi i f n / 1920} |
+// M = 1922 (re/im interleaved), K = 1920, columns = (b, t).  7.4 MFLOP per frame, dense.
+int run_stft(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, float* spec, int B, int64_t L) {
+    (void)ws;
+    if (dry) return 0;
+    const int T = (int)(L / kHop);
+    const int ncols = B * T;
+    LoadStftFrame ld{wav, (int)L};
+    EpiStftMag ep{spec, T, ncols};
+    igemm_launch(s, ctx->stft_dft.At, ctx->stft_dft.Mpad, ctx->stft_dft.Kpad, ncols, T, ld, ep);
+    return launch_check(ctx, "stft");
+}
+
+// ---- energy -------------------------------------------------------------------------------------
+// e[j] = max |x[64 j - 32 .. 64 j + 95]| (max_pool1d(|x|, 128, 64, 32): out-of-range = -inf)
+static __global__ void energy_pool_kernel(const float* __restrict__ wav, float* __restrict__ e, int B, int L, int ne) {
+    long total = (long)B * ne;
+    const int lane = threadIdx.x & 63;
+    long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long i = wave; i < total; i += nwaves) {
+        int b = (int)(i / ne), j = (int)(i - (long)b * ne);
+        const float* x = wav + (long)b * L;
+        int lo = 64 * j - 32;
+        float m = -INFINITY;
+        for (int k = lane; k < 128; k += 64) {
+            int p = lo + k;
+            if (p >= 0 && p < L) m = fmaxf(m, fabsf(x[p]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) e[i] = m;
+    }
+}
+
+int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, float* energy, int B, int64_t L) {
+    const int ne = (int)((L + 2 * 32 - 128) / 64 + 1);
+    float* e = ws.get<float>((size_t)B * ne);
+    if (dry) return 0;
+    hipLaunchKernelGGL(energy_pool_kernel, dim3(grid_for((long)B * ne * 64)), dim3(256), 0, s, wav, e, B, (int)L, ne);
+    // F.interpolate(e, L): `size` given -> scale = float(in) / float(out)
+    float scale = (float)ne / (float)L;
+    hipLaunchKernelGGL(lerp_resize_kernel, dim3(grid_for((long)B * L)), dim3(256), 0, s, e, energy, (long)B, ne, (int)L, scale);
+    return launch_check(ctx, "energy");
+}
+
+// ---- shift_frequency ----------------------------------------------------------------------------
+// midi = log2(relu(f/440) + 1e-6) * 12 + 69 + shift;  f' = 440 * 2^((midi - 69) / 12)
+static __global__ void shift_kernel(const float* __restrict__ f0, float* __restrict__ out, long n, float shift) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float r = __fdiv_rn(f0[i], 440.f);
+        r = r > 0.f ? r : 0.f;
+        float midi = __fadd_rn(__fmul_rn(log2f(__fadd_rn(r, 1e-6f)), 12.f), 69.f);
+        midi = __fadd_rn(midi, shift);
+        float e = __fdiv_rn(__fsub_rn(midi, 69.f), 12.f);
+        out[i] = __fmul_rn(440.f, exp2f(e));
+    }
+}
+
+int run_shift(tvc_ctx* ctx, hipStream_t s, const float* f0, float* out, int64_t n, float semitones) {
+    hipLaunchKernelGGL(shift_kernel, dim3(grid_for(n)), dim3(256), 0, s, f0, out, (long)n, semitones);
+    return launch_check(ctx, "shift_frequency");
+}
+
+}  // namespace tvc

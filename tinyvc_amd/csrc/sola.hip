@@ -1,0 +1,144 @@
+// Streaming tail: SOLA alignment + cross-fade (stream.py:74-95) and the optional phase-vocoder
+// cross-fade (stream.py:9-26), batched over streams, with the arg-max kept on the device (the
+// reference's `.item()` host sync at stream.py:79 is what serialises concurrent streams).
+#include "tvc_common.h"
+
+namespace tvc {
+
+constexpr int CROSS = kSolaCross, SEARCH = kSolaSearch, DELAY = kSolaDelay;
+
+// phase_vocoder(a = sola buffer, b = new head, fade_out, fade_in) for n = 1920, written into `res`.
+// Direct DFT of the two windowed segments (961 bins x 1920 samples each), then the 961-term cosine
+// bank per output sample — O(n^2) like the reference's [1920, 961] broadcast.
+static __device__ void phase_vocoder_block(const float* a, const float* b, const float* fin, float* res,
+                                           float* re_a, float* im_a, float* re_b, float* im_b) {
+    const int n = CROSS, nb = n / 2 + 1;
+    const float two_pi = 6.283185307179586f;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        float ra = 0.f, ia = 0.f, rb = 0.f, ib = 0.f;
+        for (int j = 0; j < n; ++j) {
+            float w = sqrtf((1.f - fin[j]) * fin[j]);
+            float sn, cs;
+            int r = (int)(((long)k * j) % n);
+            sincosf(two_pi * (float)r / (float)n, &sn, &cs);
+            float av = a[j] * w, bv = b[j] * w;
+            ra = fmaf(av, cs, ra);
+            ia = fmaf(-av, sn, ia);
+            rb = fmaf(bv, cs, rb);
+            ib = fmaf(-bv, sn, ib);
+        }
+        re_a[k] = ra; im_a[k] = ia; re_b[k] = rb; im_b[k] = ib;
+    }
+    __syncthreads();
+    // per-bin magnitude sum, phase of a, wrapped phase advance
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        float mag = hypotf(re_a[k], im_a[k]) + hypotf(re_b[k], im_b[k]);
+        if (k >= 1 && k < nb - 1) mag *= 2.f;
+        float pa = atan2f(im_a[k], re_a[k]);
+        float pb = atan2f(im_b[k], re_b[k]);
+        float dp = pb - pa;
+        dp = dp - two_pi * floorf(dp / 2.f / 3.14159265358979f + 0.5f);
+        re_a[k] = mag;                       // reuse: magnitude
+        im_a[k] = pa;                        // phase of a
+        re_b[k] = two_pi * (float)k + dp;    // w
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        float t = (float)j / (float)n;
+        float acc = 0.f;
+        for (int k = 0; k < nb; ++k) acc += re_a[k] * cosf(re_b[k] * t + im_a[k]);
+        float fi = fin[j], fo = 1.f - fi;
+        float w = sqrtf(fo * fi);
+        res[j] = a[j] * (fo * fo) + b[j] * (fi * fi) + acc * w / (float)n;
+    }
+    __syncthreads();
+}
+
+// one workgroup per stream
+static __global__ __launch_bounds__(256) void sola_kernel(const float* __restrict__ y, float* __restrict__ sola_buf,
+                                                          const float* __restrict__ fade_in, float* __restrict__ out,
+                                                          int32_t* __restrict__ shift_out, long Ly, int block, int use_pv) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* ci = sm;                       // [CROSS + SEARCH] head of temp_wav
+    float* sb = sm + CROSS + SEARCH;      // [CROSS] sola buffer
+    float* sq = sb + CROSS;               // [CROSS + SEARCH] squares of ci
+    __shared__ float bestv[4];
+    __shared__ int besti[4];
+    __shared__ int s_shift;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int st = blockIdx.x;
+    const int tw_len = block + CROSS + SEARCH;  // temp_wav = y[-tw_len-DELAY : -DELAY]
+    const float* tw = y + (long)st * Ly + (Ly - tw_len - DELAY);
+    float* sbuf = sola_buf + (long)st * CROSS;
+
+    for (int i = tid; i < CROSS + SEARCH; i += 256) {
+        float v = tw[i];
+        ci[i] = v;
+        sq[i] = v * v;
+    }
+    for (int i = tid; i < CROSS; i += 256) sb[i] = sbuf[i];
+    __syncthreads();
+
+    // normalised cross-correlation over SEARCH+1 lags (two F.conv1d in stream.py:77-78)
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int lag = tid; lag <= SEARCH; lag += 256) {
+        float nom = 0.f, den = 0.f;
+        for (int j = 0; j < CROSS; ++j) {
+            nom = fmaf(ci[lag + j], sb[j], nom);
+            den += sq[lag + j];
+        }
+        float v = nom / sqrtf(den + 1e-8f);
+        if (v > bv) { bv = v; bi = lag; }   // ascending lags per thread: first maximum kept
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(bv, o);
+        int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { bestv[wave] = bv; besti[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        float v = bestv[0];
+        int i = besti[0];
+        for (int w = 1; w < 4; ++w)
+            if (bestv[w] > v || (bestv[w] == v && besti[w] < i)) { v = bestv[w]; i = besti[w]; }
+        s_shift = i;
+        if (shift_out) shift_out[st] = i;
+    }
+    __syncthreads();
+    const int shift = s_shift;
+    const float* seg = tw + shift;  // temp_wav[shift : shift + block + CROSS]
+
+    // cross-faded head (first CROSS samples) into ci[0:CROSS]
+    if (use_pv) {
+        float* head = sq;            // b = seg[:CROSS]
+        for (int i = tid; i < CROSS; i += 256) head[i] = seg[i];
+        __syncthreads();
+        float* scratch = sm + 2 * (CROSS + SEARCH) + CROSS + 8;
+        phase_vocoder_block(sb, head, fade_in, ci, scratch, scratch + 968, scratch + 2 * 968, scratch + 3 * 968);
+    } else {
+        for (int i = tid; i < CROSS; i += 256) {
+            float fi = fade_in[i];
+            ci[i] = __fadd_rn(__fmul_rn(seg[i], fi), __fmul_rn(sb[i], 1.f - fi));
+        }
+        __syncthreads();
+    }
+    // temp = [head (CROSS) | seg[CROSS : block + CROSS]];  out = temp[:block]; sola = temp[block:]
+    float* o = out + (long)st * block;
+    for (int i = tid; i < block; i += 256) o[i] = i < CROSS ? ci[i] : seg[i];
+    for (int i = tid; i < CROSS; i += 256) {
+        int src = block + i;
+        sbuf[i] = src < CROSS ? ci[src] : seg[src];
+    }
+}
+
+int run_sola(tvc_ctx* ctx, hipStream_t s, const float* y, float* sola_buf, const float* fade_in, float* out,
+             int32_t* shift_out, int S, int64_t Ly, int block, int use_pv) {
+    size_t lds = (size_t)(2 * (CROSS + SEARCH) + CROSS + 8 + 4 * 968) * sizeof(float) + 64;
+    hipLaunchKernelGGL(sola_kernel, dim3(S), dim3(256), lds, s, y, sola_buf, fade_in, out, shift_out, (long)Ly, block, use_pv);
+    return launch_check(ctx, "sola");
+}
+
+}  // namespace tvc

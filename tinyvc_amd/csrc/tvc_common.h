@@ -1,0 +1,200 @@
+// Internal declarations shared by the translation units of libtinyvc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tinyvc_hip.h"
+
+namespace tvc {
+
+constexpr int kSampleRate = 24000;
+constexpr int kNfft = 1920;
+constexpr int kHop = 480;
+constexpr int kBins = 961;
+constexpr int kSslDim = 768;
+constexpr int kSslCh = 384;
+constexpr int kPitchCh = 128;
+constexpr int kPitchClasses = 512;
+constexpr int kSrcCh = 128;
+constexpr int kHarm = 15;  // num_harmonics + 1 sinusoids
+constexpr int kSolaCross = 1920, kSolaSearch = 1920, kSolaDelay = 3840;
+
+// A conv / 1x1 weight packed for the implicit-GEMM kernel: At[k][m] (k = ci*taps + tap, m = cout),
+// zero padded to Kpad x Mpad (Kpad % 16 == 0, Mpad % 32 == 0), plus the bias [Mpad].
+struct PackedW {
+    const float* At = nullptr;
+    const float* bias = nullptr;
+    int M = 0, K = 0, Mpad = 0, Kpad = 0, cin = 0, taps = 1;
+};
+
+struct ConvNeXtW {
+    const float* dw_w = nullptr;  // [C][7]
+    const float* dw_b = nullptr;  // [C]
+    const float* ln_g = nullptr;
+    const float* ln_b = nullptr;
+    PackedW c2, c3;
+    const float* grn_g = nullptr;  // [2C]
+    const float* grn_b = nullptr;
+    int C = 0, dilation = 1;
+};
+
+struct DownW {
+    PackedW res, c1, c2, c3;
+    int cin = 0, cout = 0, factor = 1;
+};
+struct UpW {
+    PackedW c1, c2, c3, c4, c5, film1, film2;  // film = [to_scale ; to_shift] stacked on M (2C)
+    int cin = 0, cout = 0, factor = 1;
+};
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+}  // namespace tvc
+
+struct tvc_prof_region {
+    std::string name;
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+struct tvc_ctx {
+    int device = 0;
+    bool profiling = false;                   // tvc_profile_enable: hipEvent pairs around named regions
+    std::vector<tvc_prof_region> regions;
+    bool enc_ready = false, dec_ready = false;  // which checkpoint groups tvc_finalize_weights packed
+    char enc_missing[160] = {0}, dec_missing[160] = {0};
+    std::map<std::string, tvc::HostTensor> host;  // staged checkpoint tensors
+    std::vector<float> pitch_table;
+    float* arena = nullptr;        // packed checkpoint weights, one allocation per finalize
+    float* const_arena = nullptr;  // DFT tables, built at ctx_create
+    size_t arena_floats = 0;
+    char err[512] = {0};
+
+    // constant tables
+    tvc::PackedW stft_dft;   // A = windowed forward DFT [1920 -> 1922 interleaved re/im]
+    tvc::PackedW istft_dft;  // A = inverse real DFT [1922 (re|im) -> 1920], 1/N folded in
+    const float* pitch_freq = nullptr;  // [512]
+
+    // encoder
+    tvc::PackedW enc_in;  // ssl(384) and pitch(128) input 1x1 stacked: M = 512
+    const float* ssl_ln_g = nullptr;
+    const float* ssl_ln_b = nullptr;
+    const float* pit_ln_g = nullptr;
+    const float* pit_ln_b = nullptr;
+    tvc::ConvNeXtW ssl_mid[6], pit_mid[4], src_mid[3];
+    tvc::PackedW ssl_out, pit_out;
+    // source net
+    tvc::PackedW src_content_in, src_to_amps, src_to_kernel;
+    const float* src_e_w = nullptr;
+    const float* src_e_b = nullptr;
+    const float* src_f_w = nullptr;
+    const float* src_f_b = nullptr;
+    // filter net
+    tvc::PackedW flt_content_in, flt_down0, flt_out;
+    const float* flt_f_w = nullptr;
+    const float* flt_f_b = nullptr;
+    tvc::DownW downs[4];
+    tvc::UpW ups[5];
+};
+
+namespace tvc {
+
+inline int fail(tvc_ctx* ctx, int code, const char* fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define TVC_HIP(ctx, call)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return tvc::fail(ctx, TVC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                                \
+    } while (0)
+
+#define TVC_CHECK(expr)        \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+// RAII region timer: records a hipEvent pair on the launch stream when ctx->profiling is on.
+struct ProfScope {
+    tvc_ctx* ctx;
+    hipStream_t s;
+    int idx = -1;
+    ProfScope(tvc_ctx* c, hipStream_t st, bool dry, const char* name) : ctx(c), s(st) {
+        if (!c || !c->profiling || dry) return;
+        tvc_prof_region r;
+        r.name = name;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        (void)hipEventRecord(r.a, s);
+        c->regions.push_back(r);
+        idx = (int)c->regions.size() - 1;
+    }
+    ~ProfScope() {
+        if (idx >= 0) (void)hipEventRecord(ctx->regions[idx].b, s);
+    }
+};
+
+// Bump allocator over the caller's workspace.  In dry mode it only measures.
+struct Ws {
+    char* base;
+    size_t cap, off = 0, peak = 0;
+    bool dry;
+    Ws(void* p, size_t c, bool d) : base((char*)p), cap(c), dry(d) {}
+    template <class T>
+    T* get(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        size_t o = off;
+        off += bytes;
+        if (off > peak) peak = off;
+        if (dry) return (T*)(uintptr_t)256;  // never dereferenced
+        return (T*)(base + o);
+    }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+    bool ok() const { return dry || peak <= cap; }
+};
+
+inline int launch_check(tvc_ctx* ctx, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "launch %s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// ---- stage drivers (each enqueues kernels on `s`; `dry` = measure workspace only) ----------
+int run_stft(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* spec, int B, int64_t L);
+int run_energy(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* energy, int B, int64_t L);
+int run_encoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* spec, float* ssl, float* f0,
+                float* logits, int B, int T);
+int run_knn(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* src, const float* prepared, int64_t N,
+            float* out, int64_t* idx_out, int B, int T);
+int run_shift(tvc_ctx*, hipStream_t, const float* f0, float* out, int64_t n, float semitones);
+int run_decoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* content, const float* f0,
+                const float* energy, const float* angle, uint64_t seed, float* wave, float* amps_out,
+                float* kernel_out, float* source_out, int B, int T);
+int run_dsp(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* f0, const float* amps, const float* kern,
+            const float* angle, uint64_t seed, float* source, int B, int T);
+int run_sola(tvc_ctx*, hipStream_t, const float* y, float* sola_buf, const float* fade_in, float* out, int32_t* shift_out,
+             int S, int64_t Ly, int block, int use_pv);
+int run_prepare_index(tvc_ctx*, hipStream_t, const float* index, float* prepared, int64_t N);
+
+// ConvNeXt-v2 layer on x [B, C, T] in place (convnext.py:49-58); tmp buffers from ws.
+int run_convnext(tvc_ctx*, hipStream_t, Ws&, bool dry, const ConvNeXtW& w, float* x, int B, int T);
+
+}  // namespace tvc

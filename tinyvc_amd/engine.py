@@ -1,0 +1,272 @@
+"""Thin host-side wrapper around one `tvc_ctx` (one per device and weight set).
+
+PyTorch is used here for device memory (tensors in, tensors out), the current HIP stream and the
+scratch workspace; every computation is a call into libtinyvc_hip.so.
+"""
+import ctypes
+import math
+import threading
+
+import torch
+
+from . import _lib, spec
+
+_F32 = torch.float32
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _check_dev(t, name, device):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.device.type != "cuda":
+        raise _lib.TinyVCError(
+            f"{name} is on {t.device}: tinyvc_amd runs on an AMD GPU only (no CPU fallback). "
+            "Move the model and inputs to 'cuda'.")
+    if device is not None and t.device != device:
+        raise _lib.TinyVCError(f"{name} is on {t.device}, engine is on {device}")
+
+
+def _prep(t, name, device):
+    _check_dev(t, name, device)
+    if t.dtype != _F32:
+        t = t.float()
+    return t.contiguous()
+
+
+def pitch_class_table():
+    """PitchEstimator.id2freq over ids 0..511 (reference encoder.py:48-54), on the host."""
+    ids = torch.arange(spec.PITCH_CLASSES).to(torch.float)
+    x = spec.PITCH_FMIN * (2 ** (ids / spec.PITCH_CPO))
+    x[x <= spec.PITCH_FMIN] = 0
+    return x.contiguous()
+
+
+class Engine:
+    """Owns a tvc_ctx on `device`, its weights and a grow-only scratch workspace."""
+
+    def __init__(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.TinyVCError(f"tinyvc_amd needs a GPU device, got {device}")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = device
+        self.lib = _lib.load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.tvc_ctx_create(device.index, ctypes.byref(h))
+        if rc != 0 or not h:
+            raise _lib.TinyVCError(f"tvc_ctx_create(device={device.index}) failed with {rc}")
+        self.ctx = h
+        self._ws = None
+        self._seed = 0x1234ABCD
+        self.weights_key = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.tvc_ctx_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def _ok(self, rc, what):
+        if rc != 0:
+            msg = self.lib.tvc_last_error(self.ctx)
+            raise _lib.TinyVCError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, B, L, N):
+        need = ctypes.c_size_t()
+        self._ok(self.lib.tvc_workspace_bytes(self.ctx, int(B), int(L), int(max(N, 4)), ctypes.byref(need)), "tvc_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _wsargs(self, B, L, N=4):
+        ws = self.workspace(B, L, N)
+        return _ptr(ws), ctypes.c_size_t(ws.numel())
+
+    def next_seed(self):
+        self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        return self._seed
+
+    def profile(self, on=True):
+        """Bracket every stage with hipEvents on the launch stream (see tvc_profile_read)."""
+        self._ok(self.lib.tvc_profile_enable(self.ctx, int(on)), "tvc_profile_enable")
+
+    def profile_read(self):
+        """{region: milliseconds} summed since the last read; synchronises the recorded events."""
+        buf = ctypes.create_string_buffer(8192)
+        self._ok(self.lib.tvc_profile_read(self.ctx, buf, len(buf)), "tvc_profile_read")
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if "=" in item:
+                k, v = item.split("=")
+                out[k] = float(v)
+        return out
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, tensors):
+        """tensors: {state_dict key: tensor} for an encoder, a decoder or both."""
+        keep = []
+        for k, v in tensors.items():
+            t = v.detach().to("cpu", _F32).contiguous()
+            keep.append(t)
+            shape = (ctypes.c_int64 * t.dim())(*t.shape)
+            self._ok(self.lib.tvc_load_tensor(self.ctx, k.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()), f"tvc_load_tensor({k})")
+        tab = pitch_class_table()
+        self._ok(self.lib.tvc_set_pitch_table(self.ctx, ctypes.c_void_p(tab.data_ptr()), tab.numel()), "tvc_set_pitch_table")
+        self._ok(self.lib.tvc_finalize_weights(self.ctx), "tvc_finalize_weights")
+
+    # ------------------------------------------------------------------ stages
+    def stft_mag(self, wav):
+        wav = _prep(wav, "wave", self.device)
+        B, L = wav.shape
+        if L % spec.HOP:
+            raise ValueError("waveform length must be a multiple of 480 (autopad_waveform)")
+        out = torch.empty(B, spec.FFT_BIN, L // spec.HOP, dtype=_F32, device=self.device)
+        p, n = self._wsargs(B, L)
+        self._ok(self.lib.tvc_stft_mag_f32(self.ctx, self._stream(), _ptr(wav), _ptr(out), B, L, p, n), "tvc_stft_mag_f32")
+        return out
+
+    def energy(self, wav):
+        wav = _prep(wav, "wave", self.device)
+        B, L = wav.shape
+        out = torch.empty(B, 1, L, dtype=_F32, device=self.device)
+        p, n = self._wsargs(B, max(L - L % spec.HOP, spec.HOP))
+        self._ok(self.lib.tvc_energy_f32(self.ctx, self._stream(), _ptr(wav), _ptr(out), B, L, p, n), "tvc_energy_f32")
+        return out
+
+    def encoder(self, spec_t, want_logits=False):
+        x = _prep(spec_t, "spec", self.device)
+        B, C, T = x.shape
+        if C != spec.FFT_BIN:
+            raise ValueError(f"spec must have {spec.FFT_BIN} bins, got {C}")
+        ssl = torch.empty(B, spec.SSL_DIM, T, dtype=_F32, device=self.device)
+        f0 = torch.empty(B, 1, T, dtype=_F32, device=self.device)
+        logits = torch.empty(B, spec.PITCH_CLASSES, T, dtype=_F32, device=self.device) if want_logits else None
+        p, n = self._wsargs(B, T * spec.HOP)
+        self._ok(self.lib.tvc_encoder_f32(self.ctx, self._stream(), _ptr(x), _ptr(ssl), _ptr(f0), _ptr(logits), B, T, p, n), "tvc_encoder_f32")
+        return ssl, f0, logits
+
+    def knn_prepare(self, index):
+        """index: [768, N] or [1, 768, N] -> prepared blob (1-D float tensor)."""
+        idx = _prep(index, "index", self.device)
+        if idx.dim() == 3:
+            if idx.shape[0] != 1:
+                raise ValueError("knn_prepare takes one index ([1, 768, N])")
+            idx = idx[0]
+        if idx.shape[0] != spec.SSL_DIM:
+            raise ValueError(f"index must be [768, N], got {tuple(idx.shape)}")
+        N = idx.shape[1]
+        if N < 4:
+            raise RuntimeError("selected index k out of range")  # what torch.topk raises in the reference
+        blob = torch.empty(self.lib.tvc_knn_prepared_elems(N), dtype=_F32, device=self.device)
+        self._ok(self.lib.tvc_knn_prepare_index_f32(self.ctx, self._stream(), _ptr(idx.contiguous()), _ptr(blob), N), "tvc_knn_prepare_index_f32")
+        return blob, N
+
+    def knn_match(self, src, prepared, N, want_indices=False):
+        src = _prep(src, "source", self.device)
+        B, C, T = src.shape
+        if C != spec.SSL_DIM:
+            raise ValueError(f"source must have {spec.SSL_DIM} channels")
+        out = torch.empty_like(src)
+        idx = torch.empty(B, T, 4, dtype=torch.int64, device=self.device) if want_indices else None
+        p, n = self._wsargs(B, T * spec.HOP, N)
+        self._ok(self.lib.tvc_knn_match_f32(self.ctx, self._stream(), _ptr(src), _ptr(prepared), N, _ptr(out), _ptr(idx), B, T, p, n), "tvc_knn_match_f32")
+        return (out, idx) if want_indices else out
+
+    def shift_frequency(self, f0, semitones):
+        f0 = _prep(f0, "f0", self.device)
+        out = torch.empty_like(f0)
+        if f0.numel():
+            self._ok(self.lib.tvc_shift_frequency_f32(self.ctx, self._stream(), _ptr(f0), _ptr(out), f0.numel(), float(semitones)), "tvc_shift_frequency_f32")
+        return out
+
+    def _angle(self, noise_angle, B, T):
+        if noise_angle is None:
+            return None, self.next_seed()
+        a = _prep(noise_angle, "noise_angle", self.device)
+        if tuple(a.shape) != (B, spec.FFT_BIN, T):
+            raise ValueError(f"noise_angle must be [{B}, {spec.FFT_BIN}, {T}], got {tuple(a.shape)}")
+        return a, 0
+
+    def decoder(self, content, f0, energy, noise_angle=None, stages=False):
+        content = _prep(content, "content", self.device)
+        f0 = _prep(f0, "f0", self.device)
+        energy = _prep(energy, "energy", self.device)
+        B, C, T = content.shape
+        L = T * spec.HOP
+        if C != spec.SSL_DIM or tuple(f0.shape) != (B, 1, T) or tuple(energy.shape) != (B, 1, L):
+            raise ValueError(f"decoder shapes: content [B,768,T], f0 [B,1,T], energy [B,1,T*480]; got {tuple(content.shape)}, {tuple(f0.shape)}, {tuple(energy.shape)}")
+        a, seed = self._angle(noise_angle, B, T)
+        wave = torch.empty(B, L, dtype=_F32, device=self.device)
+        p, n = self._wsargs(B, L)
+        if not stages:
+            self._ok(self.lib.tvc_decoder_f32(self.ctx, self._stream(), _ptr(content), _ptr(f0), _ptr(energy), _ptr(a), seed, _ptr(wave), B, T, p, n), "tvc_decoder_f32")
+            return wave
+        amps = torch.empty(B, spec.NUM_HARMONICS + 1, T, dtype=_F32, device=self.device)
+        kern = torch.empty(B, spec.FFT_BIN, T, dtype=_F32, device=self.device)
+        source = torch.empty(B, 16, L, dtype=_F32, device=self.device)
+        self._ok(self.lib.tvc_decoder_stages_f32(self.ctx, self._stream(), _ptr(content), _ptr(f0), _ptr(energy), _ptr(a), seed, _ptr(wave),
+                                                 _ptr(amps), _ptr(kern), _ptr(source), B, T, p, n), "tvc_decoder_stages_f32")
+        return wave, amps, kern, source
+
+    def dsp(self, f0, amps, kernel, noise_angle=None):
+        f0 = _prep(f0, "f0", self.device)
+        amps = _prep(amps, "amps", self.device)
+        kernel = _prep(kernel, "kernel", self.device)
+        B, _, T = f0.shape
+        a, seed = self._angle(noise_angle, B, T)
+        source = torch.empty(B, 16, T * spec.HOP, dtype=_F32, device=self.device)
+        p, n = self._wsargs(B, T * spec.HOP)
+        self._ok(self.lib.tvc_dsp_f32(self.ctx, self._stream(), _ptr(f0), _ptr(amps), _ptr(kernel), _ptr(a), seed, _ptr(source), B, T, p, n), "tvc_dsp_f32")
+        return source
+
+    def convert(self, wav, prepared, N, pitch_shift, noise_angle=None, out=None):
+        wav = _prep(wav, "wave", self.device)
+        B, L = wav.shape
+        if L % spec.HOP:
+            raise ValueError("waveform length must be a multiple of 480 (autopad_waveform)")
+        a, seed = self._angle(noise_angle, B, L // spec.HOP)
+        wave = out if out is not None else torch.empty(B, L, dtype=_F32, device=self.device)
+        p, n = self._wsargs(B, L, N)
+        self._ok(self.lib.tvc_convert_f32(self.ctx, self._stream(), _ptr(wav), _ptr(prepared), N, float(pitch_shift), _ptr(a), seed, _ptr(wave), B, L, p, n), "tvc_convert_f32")
+        return wave
+
+    def sola(self, y, sola_buf, fade_in, block, use_phase_vocoder=False, want_shift=False):
+        """y [S, Ly]; sola_buf [S, 1920] updated in place; returns out [S, block] (and shifts)."""
+        y = _prep(y, "y", self.device)
+        _check_dev(sola_buf, "sola_buffer", self.device)
+        fade_in = _prep(fade_in, "fade_in_window", self.device)
+        if not sola_buf.is_contiguous() or sola_buf.dtype != _F32:
+            raise ValueError("sola_buffer must be contiguous fp32")
+        S, Ly = y.shape
+        out = torch.empty(S, block, dtype=_F32, device=self.device)
+        shift = torch.empty(S, dtype=torch.int32, device=self.device) if want_shift else None
+        self._ok(self.lib.tvc_sola_f32(self.ctx, self._stream(), _ptr(y), _ptr(sola_buf), _ptr(fade_in), _ptr(out), _ptr(shift), S, Ly, int(block), int(bool(use_phase_vocoder))), "tvc_sola_f32")
+        return (out, shift) if want_shift else out
+
+
+# ---------------------------------------------------------------------- shared weightless engines
+_default = {}
+_lock = threading.Lock()
+
+
+def default_engine(device):
+    """Engine without checkpoint weights, for the free functions of module.utils / match_features."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.TinyVCError(f"tinyvc_amd runs on an AMD GPU only; got a tensor on {device}")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    with _lock:
+        if idx not in _default:
+            _default[idx] = Engine(torch.device("cuda", idx))
+        return _default[idx]

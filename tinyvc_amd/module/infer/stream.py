@@ -1,0 +1,69 @@
+"""Real-time wrapper: rolling input buffer, full convert per block, SOLA alignment and cross-fade
+(reference module/infer/stream.py:30-96).  `StreamInfer` is the reference's single-stream class;
+`BatchedStreamInfer` runs S independent streams through one batched convert + one SOLA launch with
+the lag arg-max kept on the device."""
+import numpy as np
+import torch
+
+from .generator import Generator
+
+
+def _fade_windows(crossfade_size, device):
+    # stream.py:61-62, computed on the host exactly as the reference does, then uploaded
+    fade_in = torch.sin(np.pi * torch.arange(0, 1, 1 / crossfade_size) / 2) ** 2
+    return fade_in.to(device), (1 - fade_in).to(device)
+
+
+class BatchedStreamInfer:
+    def __init__(self, generator: Generator, n_streams=1, target=None, pitch_shift=0., device=None,
+                 block_size=1920, extra_size=0, use_phase_vocoder=False, f0_estimation="default"):
+        self.generator = generator
+        self.n_streams = n_streams
+        self.target = target
+        self.pitch_shift = pitch_shift
+        self.device = torch.device(device) if device is not None else generator._module_device()
+        self.block_size = block_size
+        self.extra_size = extra_size
+        self.sola_search_size = 1920
+        self.last_dilay_size = 3840          # (sic) the reference's attribute name, stream.py:49
+        self.crossfade_size = 1920
+        self.use_phase_vocoder = use_phase_vocoder
+        self.f0_estimation = f0_estimation
+        self.input_size = max(self.block_size + self.crossfade_size + self.sola_search_size + 2 * self.last_dilay_size,
+                              self.block_size + self.extra_size)
+        self.last_shift = None
+
+    def init_buffer(self):
+        self.fade_in_window, self.fade_out_window = _fade_windows(self.crossfade_size, self.device)
+        self.input_wav = torch.zeros(self.n_streams, self.input_size, device=self.device)
+        self.sola_buffer = torch.zeros(self.n_streams, self.crossfade_size, device=self.device)
+
+    @torch.no_grad()
+    def audio_callback(self, blocks, noise_angle=None):
+        """blocks [S, block_size] -> converted blocks [S, block_size]."""
+        blocks = blocks.to(self.device)
+        self.input_wav = torch.roll(self.input_wav, -self.block_size, dims=1)
+        self.input_wav[:, -self.block_size:] = blocks
+        y = self.generator.convert(self.input_wav, self.target, self.pitch_shift, device=self.device,
+                                   f0_estimation=self.f0_estimation, noise_angle=noise_angle)
+        eng = self.generator.engine(self.device)
+        out, shift = eng.sola(y, self.sola_buffer, self.fade_in_window, self.block_size,
+                              self.use_phase_vocoder, want_shift=True)
+        self.last_shift = shift
+        return out
+
+
+class StreamInfer(BatchedStreamInfer):
+    """Single stream with the reference's constructor and 1-D buffers (stream.py:31-57)."""
+
+    def __init__(self, generator: Generator, target=None, pitch_shift=0., device=torch.device("cpu"),
+                 block_size=1920, extra_size=0, use_phase_vocoder=False, f0_estimation="default"):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            dev = generator._module_device()     # the reference defaults to CPU; there is no CPU path here
+        super().__init__(generator, 1, target, pitch_shift, dev, block_size, extra_size, use_phase_vocoder, f0_estimation)
+
+    @torch.no_grad()
+    def audio_callback(self, block, noise_angle=None):
+        """block [block_size] -> converted block [block_size] (stream.py:68-96)."""
+        return super().audio_callback(block[None], noise_angle)[0]

@@ -1,0 +1,56 @@
+"""kNN-VC feature matching (reference module/tinyvc/feature_retrieval.py:15-33) on the streamed
+top-k kernel of csrc/knn.hip."""
+from collections import OrderedDict
+
+import torch
+
+from ...engine import default_engine
+
+_prepared = OrderedDict()   # (data_ptr, version, shape, device) -> (blob, N); tiny LRU
+_PREPARED_MAX = 8
+
+
+def prepare_reference(reference):
+    """Normalise + repack an index [1, 768, N] once; cached on the tensor's identity/version."""
+    key = (reference.data_ptr(), reference._version, tuple(reference.shape), str(reference.device))
+    hit = _prepared.get(key)
+    if hit is not None:
+        _prepared.move_to_end(key)
+        return hit
+    eng = default_engine(reference.device)
+    blob, n = eng.knn_prepare(reference)
+    _prepared[key] = (blob, n)
+    while len(_prepared) > _PREPARED_MAX:
+        _prepared.popitem(last=False)
+    return blob, n
+
+
+@torch.no_grad()
+def match_features(source, reference, k=4, alpha=0.0, metrics="cos", return_indices=False):
+    """source [B, C, T], reference [B or 1, C, N] -> [B, C, T] (mean of the k nearest index vectors,
+    blended with the input by alpha)."""
+    if k != 4 or metrics != "cos":
+        raise NotImplementedError("the HIP kernel implements the inference path's k=4, metrics='cos'")
+    if reference.device != source.device:
+        reference = reference.to(source.device)
+    eng = default_engine(source.device)
+    B = source.shape[0]
+    if reference.shape[0] == 1:
+        blob, n = prepare_reference(reference)
+        res = eng.knn_match(source, blob, n, want_indices=return_indices)
+        out, idx = res if return_indices else (res, None)
+    elif reference.shape[0] == B:
+        outs, idxs = [], []
+        for b in range(B):                       # one index per utterance
+            blob, n = prepare_reference(reference[b:b + 1])
+            res = eng.knn_match(source[b:b + 1], blob, n, want_indices=return_indices)
+            o, i = res if return_indices else (res, None)
+            outs.append(o)
+            idxs.append(i)
+        out = torch.cat(outs, 0)
+        idx = torch.cat(idxs, 0) if return_indices else None
+    else:
+        raise RuntimeError(f"batch of reference ({reference.shape[0]}) must be 1 or match source ({B})")
+    if alpha != 0.0:
+        out = out * (1 - alpha) + source * alpha
+    return (out, idx) if return_indices else out
