@@ -48,6 +48,9 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles the HIP runtime (SONAME libamdhip64.so.7) and must be the one copy
+    # in the process; loaded after our .so it would come in as a second runtime next to /opt/rocm's.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise TinyVCError(
             f"{LIB_PATH} is missing: build it with `python -m tinyvc_amd.build` (needs hipcc). "
