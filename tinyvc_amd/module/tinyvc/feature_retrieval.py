@@ -1,27 +1,23 @@
 """kNN-VC feature matching (reference module/tinyvc/feature_retrieval.py:15-33) on the streamed
 top-k kernel of csrc/knn.hip."""
-from collections import OrderedDict
-
 import torch
 
 from ...engine import default_engine
 
-_prepared = OrderedDict()   # (data_ptr, version, shape, device) -> (blob, N); tiny LRU
-_PREPARED_MAX = 8
-
 
 def prepare_reference(reference):
-    """Normalise + repack an index [1, 768, N] once; cached on the tensor's identity/version."""
-    key = (reference.data_ptr(), reference._version, tuple(reference.shape), str(reference.device))
-    hit = _prepared.get(key)
-    if hit is not None:
-        _prepared.move_to_end(key)
-        return hit
+    """Normalise + repack an index [1, 768, N] once.  The prepared blob rides on the tensor object
+    itself (keyed by its in-place version counter), so it lives exactly as long as the index and can
+    never be confused with another tensor that later reuses the same device address."""
+    hit = getattr(reference, "_tvc_prepared", None)
+    if hit is not None and hit[0] == reference._version and hit[1] == str(reference.device):
+        return hit[2], hit[3]
     eng = default_engine(reference.device)
     blob, n = eng.knn_prepare(reference)
-    _prepared[key] = (blob, n)
-    while len(_prepared) > _PREPARED_MAX:
-        _prepared.popitem(last=False)
+    try:
+        reference._tvc_prepared = (reference._version, str(reference.device), blob, n)
+    except Exception:
+        pass
     return blob, n
 
 
