@@ -95,13 +95,13 @@ def main():
     from tinyvc_amd.module.tinyvc.feature_retrieval import prepare_reference
     blob, n_idx = prepare_reference(tgt)
     out = torch.empty(B, L, device=dev)
-    gathered = [torch.empty(B, L, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from tinyvc_amd import parallel
 
     def step():
         # on-device phase draw (library RNG): the reference draws fresh torch.rand phases per call too
         eng.convert(wf, blob, n_idx, 0.0, None, out=out)
         if world > 1:
-            dist.gather(out, gathered, dst=0)
+            parallel.gather_waves(out, world * B, dst=0)       # the job's only collective (RCCL gather)
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,77 @@
+"""The C ABI boundary, without a GPU: libtinyvc_hip.so loads, exports every prototype declared in
+include/tinyvc_hip.h, and the ctypes table in tinyvc_amd/_lib.py mirrors the header one to one."""
+import os
+import re
+
+import pytest
+
+from tinyvc_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "tinyvc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = re.findall(r"\b(tvc_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)
+    return {name: [a.strip() for a in args.split(",")] if args.strip() != "void" else [] for name, args in protos}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from tinyvc_amd import build
+    build.build(verbose=False)          # hipcc cross-compiles for gfx950 without a GPU
+    return _lib.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    decl = header_functions()
+    assert len(decl) >= 20
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in tinyvc_hip.h but not exported"
+
+
+def test_ctypes_table_matches_header(lib):
+    decl = header_functions()
+    assert set(decl) == set(_lib.SIGNATURES), set(decl) ^ set(_lib.SIGNATURES)
+    for name, args in decl.items():
+        assert len(args) == len(_lib.SIGNATURES[name][1]), f"{name}: header has {len(args)} parameters"
+
+
+def test_version_and_null_safety(lib):
+    assert lib.tvc_version() == 1
+    assert lib.tvc_knn_prepared_elems(1000) == 768 * 1024 + 1000 * 768
+    assert lib.tvc_knn_prepared_elems(0) == 0
+    # argument validation happens before any device work
+    assert lib.tvc_finalize_weights(None) == -1
+    assert lib.tvc_profile_enable(None, 1) == -1
+    assert lib.tvc_last_error(None) == b"null ctx"
+
+
+def test_no_cpu_fallback_in_product_path():
+    """The product package never imports the oracle and fails loudly off-GPU."""
+    import torch
+    from tinyvc_amd.module.tinyvc import Decoder, Encoder
+    from tinyvc_amd.module import utils
+    with pytest.raises(_lib.TinyVCError):
+        Encoder().infer(torch.zeros(1, 961, 4))
+    with pytest.raises(_lib.TinyVCError):
+        Decoder().infer(torch.zeros(1, 768, 4), torch.zeros(1, 1, 4), torch.zeros(1, 1, 1920))
+    with pytest.raises(_lib.TinyVCError):
+        utils.spectrogram(torch.zeros(1, 4800))
+    for dirpath, _d, files in os.walk(os.path.join(ROOT, "tinyvc_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f"{f} imports the oracle"
+
+
+def test_host_helpers():
+    import torch
+    from tinyvc_amd.engine import pitch_class_table
+    from tinyvc_amd.module import utils
+    t = pitch_class_table()
+    assert t.shape == (512,) and t[0] == 0 and abs(float(t[48]) - 40.0) < 1e-4 and float(t[1]) > 20.0
+    x = torch.ones(2, 1000)
+    y = utils.autopad_waveform(x)
+    assert y.shape == (2, 1440) and float(y[:, 1000:].abs().sum()) == 0 and utils.autopad_waveform(y) is y
