@@ -89,6 +89,16 @@ struct Packer {
         }
         fix.push_back({&pw->At, ab.put(At)});
         fix.push_back({&pw->bias, ab.put(bias)});
+        if (taps > 1) {   // tap-major copy: row (tap*cin + ci)
+            std::vector<float> Att((size_t)pw->Kpad * pw->Mpad, 0.f);
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < taps; ++t)
+                    for (int m = 0; m < pw->Mpad; ++m)
+                        Att[(size_t)(t * cin + ci) * pw->Mpad + m] = At[(size_t)(ci * taps + t) * pw->Mpad + m];
+            fix.push_back({&pw->At_tap, ab.put(Att)});
+        } else {
+            fix.push_back({&pw->At_tap, fix[fix.size() - 2].off});
+        }
     }
     void convnext(const std::string& p, ConvNeXtW* w, int C, int dil) {
         w->C = C;
@@ -101,6 +111,18 @@ struct Packer {
         raw(p + ".grn.gamma", &w->grn_g, 2 * C);
         raw(p + ".grn.beta", &w->grn_b, 2 * C);
         conv({p + ".c3"}, &w->c3, 2 * C, 1);
+        const HostTensor* w3 = find(p + ".c3.weight");
+        const HostTensor* b3 = find(p + ".c3.bias");
+        const HostTensor* gb = find(p + ".grn.beta");
+        if (w3 && b3 && gb && gb->data.size() == (size_t)2 * C && w3->data.size() == (size_t)C * 2 * C) {
+            std::vector<float> fb(w->c3.Mpad, 0.f);
+            for (int m = 0; m < C; ++m) {
+                double acc = b3->data[m];
+                for (int k = 0; k < 2 * C; ++k) acc += (double)w3->data[(size_t)m * 2 * C + k] * (double)gb->data[k];
+                fb[m] = (float)acc;
+            }
+            fix.push_back({&w->c3_bias_grn, ab.put(fb)});
+        }
     }
 };
 
@@ -279,8 +301,14 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
         pk.conv({p + ".c5"}, &u.c5, u.cin, 1);
         pk.conv({p + ".film1.to_scale", p + ".film1.to_shift"}, &u.film1, u.cin, 1);
         pk.conv({p + ".film2.to_scale", p + ".film2.to_shift"}, &u.film2, u.cin, 1);
+        pk.conv({p + ".film1.to_scale"}, &u.sc1, u.cin, 1);
+        pk.conv({p + ".film1.to_shift"}, &u.sh1, u.cin, 1);
+        pk.conv({p + ".film2.to_scale"}, &u.sc2, u.cin, 1);
+        pk.conv({p + ".film2.to_shift"}, &u.sh2, u.cin, 1);
     }
     pk.conv({"filter_net.output_layer"}, &ctx->flt_out, ch[4], 7);
+    pk.raw("filter_net.output_layer.weight", &ctx->flt_out_w, (size_t)ch[4] * 7);
+    pk.raw("filter_net.output_layer.bias", &ctx->flt_out_b, 1);
 
     const std::string missing_dec = pk.missing;
     snprintf(ctx->enc_missing, sizeof(ctx->enc_missing), "%s", missing_enc.c_str());

@@ -1,0 +1,225 @@
+// k=3 dilated Conv1d (replicate padding, optional leaky_relu(0.1) pre-activation) as an implicit GEMM
+// on v_mfma_f32_32x32x2_f32 with an LDS halo tile: FilterNet's Downsample/Upsample convs
+// (decoder.py:143-146, 166-171) for the levels whose activations do not fit on chip as a whole block.
+//
+// A workgroup owns BM output channels x BN consecutive samples of ONE utterance.  K is walked in slabs
+// of KC = 8 input channels: the slab's activations are staged once as Xs[8][BN + 2*dil] (clamped to
+// the utterance = replicate padding, pre-activation applied on the way in) and serve all three taps
+// from LDS; the weight slab is 24 contiguous rows of At[k = ci*3 + tap][m].  Each lane precomputes
+// the 12 LDS offsets (ci_local * row + tap * dil) of its k-steps once, so the inner loop is
+// ds_read + MFMA only.  Double-buffered slabs, one barrier per slab.
+#pragma once
+#include "igemm.h"
+
+namespace tvc {
+
+template <int WM_, int WN_, int TM_, int TN_>
+struct Conv3Tile {
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static constexpr int KC = 8, KS = 24;            // channels / k-rows per slab
+    static constexpr int MAXD = 27;
+    static constexpr int XROW = BN + 2 * MAXD + 2;   // LDS row stride of the halo tile
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+};
+
+struct Conv3Args {
+    const float* At;    // [Kpad][Mpad], k = ci*3 + tap
+    const float* x;     // [B][Cin][len]
+    int Mpad, Cin, len, dil, tiles_per_utt;
+};
+
+// Epilogue interface: store(b, t, m, v[4]) for 4 consecutive channels m..m+3 at (b, t); t < len guaranteed.
+template <bool RES>
+struct C3EpiBias {
+    float* y;
+    const float* bias;
+    const float* res;
+    int M, len;
+    __device__ __forceinline__ void store(int b, int t, int m, const float v[4]) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (m + r < M) {
+                long i = ((long)b * M + m + r) * len + t;
+                float o = v[r] + bias[m + r];
+                if (RES) o += res[i];
+                y[i] = o;
+            }
+    }
+};
+
+// conv -> FiLM -> + residual (decoder.py:94-97,181-182); film = stacked [scale ; shift] [B][2M][len]
+struct C3EpiFilm {
+    float* y;
+    const float* bias;
+    const float* film;
+    const float* res;
+    int M, len;
+    __device__ __forceinline__ void store(int b, int t, int m, const float v[4]) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (m + r < M) {
+                long i = ((long)b * M + m + r) * len + t;
+                float h = v[r] + bias[m + r];
+                float sc = film[((long)b * 2 * M + m + r) * len + t];
+                float sh = film[((long)b * 2 * M + M + m + r) * len + t];
+                y[i] = __fadd_rn(__fadd_rn(__fmul_rn(h, sc), sh), res[i]);
+            }
+    }
+};
+
+template <class TL, bool LRELU, class Epi>
+__global__ __launch_bounds__(256) void conv3_kernel(Conv3Args a, Epi ep) {
+    constexpr int BM = TL::BM, BN = TL::BN, TM = TL::TM, TN = TL::TN, KC = TL::KC, KS = TL::KS, XROW = TL::XROW;
+    __shared__ __attribute__((aligned(16))) float As[2][KS * BM];
+    __shared__ __attribute__((aligned(16))) float Xs[2][KC * XROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / TL::WN, wn = wave % TL::WN;
+    const int mtiles = a.Mpad / BM;
+    const int m0 = (blockIdx.x % mtiles) * BM;
+    const int nt_id = blockIdx.x / mtiles;
+    const int b = nt_id / a.tiles_per_utt;
+    const int t0 = (nt_id - b * a.tiles_per_utt) * BN;
+    const int len = a.len, dil = a.dil;
+    const int xw = BN + 2 * dil;                      // staged columns: positions t0-dil .. t0+BN+dil
+    const float* xb = a.x + (long)b * a.Cin * len;
+
+    // per-lane LDS offsets of the 12 k-steps of a slab: k = 2*ks + lh -> (ci_local, tap)
+    int boff[KS / 2];
+#pragma unroll
+    for (int ks = 0; ks < KS / 2; ++ks) {
+        int k = 2 * ks + lh;
+        int cil = k / 3, tap = k - 3 * cil;
+        boff[ks] = cil * XROW + tap * dil;
+    }
+
+    constexpr int A_F4 = KS * BM / 4;
+    constexpr int A_PER = (A_F4 + 255) / 256;
+    constexpr int X_PER = (KC * XROW + 255) / 256;
+    float4 areg[A_PER];
+    float xreg[X_PER];
+    // staging map of this thread, fixed across slabs: element i -> (local channel r, staged column c)
+    int xg[X_PER], xl[X_PER];
+#pragma unroll
+    for (int i = 0; i < X_PER; ++i) {
+        int idx = tid + i * 256;
+        int r = idx / xw, c = idx - r * xw;
+        int p = t0 - dil + c;
+        p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+        xg[i] = r < KC ? r * len + p : -1;
+        xl[i] = r * XROW + c;
+    }
+
+    auto load_slab = [&](int ci0) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int idx = tid + i * 256;
+            if (A_F4 % 256 == 0 || idx < A_F4) {
+                int kk = idx / (BM / 4), c4 = idx - kk * (BM / 4);
+                areg[i] = *reinterpret_cast<const float4*>(a.At + (long)(ci0 * 3 + kk) * a.Mpad + m0 + c4 * 4);
+            }
+        }
+        const float* xc = xb + (long)ci0 * len;
+#pragma unroll
+        for (int i = 0; i < X_PER; ++i) {
+            float v = xg[i] >= 0 ? xc[xg[i]] : 0.f;
+            if (LRELU) v = v > 0.f ? v : 0.1f * v;
+            xreg[i] = v;
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int idx = tid + i * 256;
+            if (A_F4 % 256 == 0 || idx < A_F4) *reinterpret_cast<float4*>(&As[buf][idx * 4]) = areg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < X_PER; ++i)
+            if (xg[i] >= 0) Xs[buf][xl[i]] = xreg[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nslab = a.Cin / KC;   // Cin % 8 == 0 for every FilterNet level that uses this kernel
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int cur = s & 1;
+        const int snext = s + 1 < nslab ? s + 1 : s;
+        load_slab(snext * KC);
+        const float* as = As[cur];
+        const float* xs = Xs[cur] + l31;
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ++ks) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = as[(2 * ks + lh) * BM + (wm * TM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = xs[boff[ks] + (wn * TN + j) * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        store_slab(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int t = t0 + (wn * TN + j) * 32 + l31;
+            if (t < len) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + (wm * TM + i) * 32 + 8 * q + 4 * lh;
+                    float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    ep.store(b, t, m, v);
+                }
+            }
+        }
+}
+
+template <class TL, bool LRELU, class Epi>
+inline void conv3_launch_t(hipStream_t s, const float* At, int Mpad, const float* x, int B, int Cin, int len, int dil, const Epi& ep) {
+    Conv3Args a;
+    a.At = At;
+    a.x = x;
+    a.Mpad = Mpad;
+    a.Cin = Cin;
+    a.len = len;
+    a.dil = dil;
+    a.tiles_per_utt = (len + TL::BN - 1) / TL::BN;
+    dim3 g((unsigned)((Mpad / TL::BM) * a.tiles_per_utt * B));
+    hipLaunchKernelGGL((conv3_kernel<TL, LRELU, Epi>), g, dim3(256), 0, s, a, ep);
+}
+
+// Tile choice: BM from Mpad, BN from the utterance length at this level (short levels get 64-wide tiles).
+template <bool LRELU, class Epi>
+inline void conv3_launch(hipStream_t s, const float* At, int Mpad, const float* x, int B, int Cin, int len, int dil, const Epi& ep) {
+    const bool shortlen = len < 1024;
+    if (Mpad % 128 == 0) {
+        if (shortlen) conv3_launch_t<Conv3Tile<4, 1, 1, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);   // 128 x 64
+        else conv3_launch_t<Conv3Tile<2, 2, 2, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);            // 128 x 128
+    } else if (Mpad % 96 == 0) {
+        if (shortlen) conv3_launch_t<Conv3Tile<1, 4, 3, 1>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);   // 96 x 128
+        else conv3_launch_t<Conv3Tile<1, 4, 3, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);            // 96 x 256
+    } else if (Mpad % 64 == 0) {
+        conv3_launch_t<Conv3Tile<1, 4, 2, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);                 // 64 x 256
+    } else {
+        conv3_launch_t<Conv3Tile<1, 4, 1, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);                 // 32 x 256
+    }
+}
+
+}  // namespace tvc

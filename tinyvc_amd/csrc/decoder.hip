@@ -1,5 +1,6 @@
 // Source-filter decoder (decoder.py:24-266): SourceNet, additive harmonic oscillator, filtered-noise
 // iSTFT, and the FilterNet U-Net.
+#include "conv3.h"
 #include "igemm.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
@@ -225,7 +226,8 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
 // =================================================================================================
 template <int TAPS, bool LRELU, class Epi>
 static void conv_launch(hipStream_t s, const PackedW& w, const float* x, int cin, int len, int dil, int B, const Epi& ep) {
-    LoadConv<TAPS, LRELU> ld{x, cin, len, dil, (long)cin * len};
+    static_assert(TAPS == 3, "k3 convs only");
+    LoadConv3<LRELU> ld{x, cin, len, dil, (long)cin * len};
     igemm_launch(s, w.At, w.Mpad, w.Kpad, B * len, len, ld, ep);
 }
 
@@ -269,9 +271,9 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 EpiBias<ACT_NONE, false> ep{res, d.res.bias, nullptr, d.cout, len, nc, (long)d.cout * len, 0};
                 igemm_launch(s, d.res.At, d.res.Mpad, d.res.Kpad, nc, len, ld, ep);
             }
-            conv_launch<3, true>(s, d.c1, xi, d.cin, len, 1, B, EpiBias<ACT_NONE, false>{h1, d.c1.bias, nullptr, d.cin, len, nc, (long)d.cin * len, 0});
-            conv_launch<3, true>(s, d.c2, h1, d.cin, len, 2, B, EpiBias<ACT_NONE, false>{h2, d.c2.bias, nullptr, d.cin, len, nc, (long)d.cin * len, 0});
-            conv_launch<3, true>(s, d.c3, h2, d.cin, len, 4, B, EpiBias<ACT_NONE, true>{skip[i], d.c3.bias, res, d.cout, len, nc, (long)d.cout * len, (long)d.cout * len});
+            conv3_launch<true>(s, d.c1.At, d.c1.Mpad, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
+            conv3_launch<true>(s, d.c2.At, d.c2.Mpad, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
+            conv3_launch<true>(s, d.c3.At, d.c3.Mpad, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
         }
         ws.release(mk);
     }
@@ -296,7 +298,10 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         float* film = ws.get<float>((size_t)B * 2 * C * lo);
         float* h = ws.get<float>((size_t)B * C * lo);
         float* x1 = ws.get<float>((size_t)B * C * lo);
-        if (!dry) {
+        if (!dry && C == 24) {
+            ProfScope ps(ctx, s, dry, "filter.up4");
+            TVC_CHECK(run_up24_fused(ctx, s, u, x, cond, x1, xlev[i], B, lo));
+        } else if (!dry) {
             static const char* names[5] = {"filter.up0", "filter.up1", "filter.up2", "filter.up3", "filter.up4"};
             ProfScope ps(ctx, s, dry, names[i]);
             // F.interpolate(scale_factor=f): ATen uses scale = float(1/f)
@@ -314,8 +319,8 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                     EpiBias<ACT_NONE, false> ep{film, fw.bias, nullptr, 2 * C, lo, nc, (long)2 * C * lo, 0};
                     igemm_launch(s, fw.At, fw.Mpad, fw.Kpad, nc, lo, ld, ep);
                 }
-                conv_launch<3, true>(s, ca, xin, C, lo, da, B, EpiBias<ACT_NONE, false>{h, ca.bias, nullptr, C, lo, nc, (long)C * lo, 0});
-                conv_launch<3, true>(s, cb, h, C, lo, db, B, EpiFilm{xout, cb.bias, film, xin, C, lo, nc});
+                conv3_launch<true>(s, ca.At, ca.Mpad, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo});
+                conv3_launch<true>(s, cb.At, cb.Mpad, h, B, C, lo, db, C3EpiFilm{xout, cb.bias, film, xin, C, lo});
             }
             LoadPlain ld{xu, C, lo, (long)C * lo};
             EpiBias<ACT_NONE, false> ep{xlev[i], u.c5.bias, nullptr, u.cout, lo, nc, (long)u.cout * lo, 0};
@@ -326,7 +331,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
     }
     if (!dry) {
         ProfScope ps(ctx, s, dry, "filter.out");
-        conv_launch<7, false>(s, ctx->flt_out, x, 24, (int)L, 1, B, EpiBias<ACT_NONE, false>{wave, ctx->flt_out.bias, nullptr, 1, (int)L, (int)(B * L), L, 0});
+        TVC_CHECK(run_out_conv7(ctx, s, x, ctx->flt_out_w, ctx->flt_out_b, wave, B, 24, (int)L));
     }
     return dry ? 0 : launch_check(ctx, "filter_net");
 }

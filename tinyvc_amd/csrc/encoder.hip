@@ -78,8 +78,10 @@ static __global__ void grn_norm_kernel(const float* __restrict__ h, float* __res
     }
 }
 
-// nx[b][c] = gx[b][c] / (mean_c gx[b][:] + 1e-6)   (one workgroup per utterance)
-static __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restrict__ gx, float* __restrict__ nx, int C2) {
+// s[b][c] = 1 + gamma[c] * gx[b][c] / (mean_c gx[b][:] + 1e-6)   (one workgroup per utterance):
+// GRN(x) = gamma*(x*nx) + beta + x = x*s + beta; the beta term is folded into the next conv's bias.
+static __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restrict__ gx, const float* __restrict__ gamma,
+                                                                  float* __restrict__ nx, int C2) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const float* g = gx + (long)b * C2;
@@ -91,7 +93,7 @@ static __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* _
     __syncthreads();
     const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C2;
     const float den = mean + 1e-6f;
-    for (int c = threadIdx.x; c < C2; c += 256) nx[(long)b * C2 + c] = g[c] / den;
+    for (int c = threadIdx.x; c < C2; c += 256) nx[(long)b * C2 + c] = fmaf(gamma[c], g[c] / den, 1.f);
 }
 
 int run_layernorm(tvc_ctx* ctx, hipStream_t s, float* x, const float* g, const float* b, int B, int C, int T) {
@@ -115,10 +117,10 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
         igemm_launch(s, w.c2.At, w.c2.Mpad, w.c2.Kpad, ncols, T, ld, ep);
     }
     hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)B * C2 * 64)), dim3(256), 0, s, h, gx, (long)B * C2, T);
-    hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, s, gx, nx, C2);
+    hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, s, gx, w.grn_g, nx, C2);
     {
-        LoadGrn ld{h, nx, w.grn_g, w.grn_b, C2, T};
-        EpiBias<ACT_NONE, true> ep{x, w.c3.bias, x, C, T, ncols, (long)C * T, (long)C * T};
+        LoadScaled ld{h, nx, C2, T};
+        EpiBias<ACT_NONE, true> ep{x, w.c3_bias_grn, x, C, T, ncols, (long)C * T, (long)C * T};
         igemm_launch(s, w.c3.At, w.c3.Mpad, w.c3.Kpad, ncols, T, ld, ep);
     }
     return launch_check(ctx, "convnext");

@@ -1,13 +1,18 @@
-// Implicit-GEMM core for every channel contraction of the path (1x1 convs, k3/k7 dilated convs,
+// Implicit-GEMM core for every channel contraction of the path (1x1 convs, k3 dilated convs,
 // forward/inverse DFT) on the gfx950 fp32 matrix pipe.
 //
 //   Y[m][n] = sum_k A[m][k] * Bop(k, n)         m = output channel, n = flattened (batch, time)
 //
 // A is a static weight, pre-transposed on the host to At[k][m] so that a K-slab of a tile is BK
 // rows of BM contiguous floats (coalesced 16-B loads, 16-B LDS writes).  Bop is produced on the fly
-// by a Loader functor (conv taps with replicate clamp, pre-activation, GRN, STFT framing, ...), so
-// no im2col or activation copy ever goes through HBM.  The accumulator tile is handed to an Epilogue
-// functor (bias, activation, residual, FiLM, |.|, ...) in quads of 4 consecutive output channels.
+// by a Loader functor (conv taps with replicate clamp, pre-activation, GRN scale, STFT framing, ...),
+// so no im2col or activation copy ever goes through HBM.  The accumulator tile is handed to an
+// Epilogue functor (bias, activation, residual, FiLM, |.|, ...) in quads of 4 consecutive channels.
+//
+// Pipeline: LDS double-buffered K-slabs (BK = 16), one barrier per slab; the next slab's global
+// loads are issued (branch-free) before the current slab's MFMAs and land in LDS after them.
+// Loaders precompute everything that depends only on the thread's column (batch base pointer,
+// clamped tap offsets) once, so the per-element cost in the K loop is one mad + one load.
 //
 // v_mfma_f32_32x32x2_f32: exact fp32 FMA chain at the fp32 vector-peak rate (157 TF on MI355X);
 // wave64 layouts: A lane l -> A[i = l&31][k = l>>5], B lane l -> B[k = l>>5][j = l&31],
@@ -27,78 +32,129 @@ struct Tile {
 };
 
 // ------------------------------------------------------------------------------------------
-// Column helper: flattened column n -> (b, t)
-struct Col {
-    int b, t;
+// Loaders.  `Ctx ctx(n, ncols, T)` is built once per thread for its column n = (b, t);
+// `float get(ctx, k)` returns Bop(k, n).
+
+struct ColCtx {
+    const float* base;  // &x[b][0][0] (+ t for plain loaders)
+    int b;
     bool ok;
 };
-__device__ __forceinline__ Col make_col(int n, int ncols, int T) {
-    Col c;
-    c.ok = n < ncols;
-    int nn = c.ok ? n : 0;
-    c.b = nn / T;
-    c.t = nn - c.b * T;
-    return c;
-}
 
-// ------------------------------------------------------------------------------------------
-// Loaders: `float get(const Col&, int k)` returns Bop(k, n).  K is the true contraction length.
-
-// X[b][k][t], batch stride given (1x1 conv input).
+// X[b][k][t] (1x1 conv input), batch stride given.
 struct LoadPlain {
     const float* x;
     int K, T;
     long bstride;
-    __device__ __forceinline__ float get(const Col& c, int k) const {
-        return (c.ok && k < K) ? x[c.b * bstride + (long)k * T + c.t] : 0.f;
+    typedef ColCtx Ctx;
+    __device__ __forceinline__ Ctx ctx(int n, int ncols, int Tt) const {
+        Ctx c;
+        c.ok = n < ncols;
+        int nn = c.ok ? n : 0;
+        c.b = nn / Tt;
+        c.base = x + c.b * bstride + (nn - c.b * Tt);
+        return c;
+    }
+    __device__ __forceinline__ float get(const Ctx& c, int k) const {
+        return (c.ok && k < K) ? c.base[k * T] : 0.f;
     }
 };
 
-// GRN applied on the fly to the 1x1-conv input: gamma*(x*nx) + beta + x  (convnext.py:31-34)
-struct LoadGrn {
+// GRN folded into the 1x1-conv input (convnext.py:31-34): gamma*(x*nx) + beta + x
+// = x * s[b][k] + beta[k] with s = 1 + gamma*nx; the beta term is constant per output channel and
+// lives in the packed bias (bias + W.beta), so the loader is one multiply.
+struct LoadScaled {
     const float* x;
-    const float* nx;  // [B][K]
-    const float* gamma;
-    const float* beta;
+    const float* s;  // [B][K]
     int K, T;
-    __device__ __forceinline__ float get(const Col& c, int k) const {
-        if (!(c.ok && k < K)) return 0.f;
-        float v = x[((long)c.b * K + k) * T + c.t];
-        return __fadd_rn(__fadd_rn(__fmul_rn(gamma[k], __fmul_rn(v, nx[c.b * K + k])), beta[k]), v);
+    struct Ctx {
+        const float* base;
+        const float* srow;
+        bool ok;
+    };
+    __device__ __forceinline__ Ctx ctx(int n, int ncols, int Tt) const {
+        Ctx c;
+        c.ok = n < ncols;
+        int nn = c.ok ? n : 0;
+        int b = nn / Tt;
+        c.base = x + (long)b * K * T + (nn - b * Tt);
+        c.srow = s + (long)b * K;
+        return c;
+    }
+    __device__ __forceinline__ float get(const Ctx& c, int k) const {
+        return (c.ok && k < K) ? c.base[k * T] * c.srow[k] : 0.f;
     }
 };
 
-// k-tap dilated conv input with replicate padding, optional leaky_relu(0.1) pre-activation.
-// k = ci*TAPS + tap (PyTorch's [cout][cin][tap] weight order).
-template <int TAPS, bool LRELU>
-struct LoadConv {
+// 3-tap dilated conv input with replicate padding, optional leaky_relu(0.1) pre-activation.
+// K is channel-major, k = ci*3 + tap (PyTorch's [cout][cin][tap] order): the three taps of a channel
+// sit in the same K-slab and hit the same cache lines.
+template <bool LRELU>
+struct LoadConv3 {
     const float* x;
     int Cin, T, dil;
     long bstride;
-    __device__ __forceinline__ float get(const Col& c, int k) const {
-        int ci = k / TAPS;
+    struct Ctx {
+        const float* base;
+        int off[3];
+        bool ok;
+    };
+    __device__ __forceinline__ Ctx ctx(int n, int ncols, int Tt) const {
+        Ctx c;
+        c.ok = n < ncols;
+        int nn = c.ok ? n : 0;
+        int b = nn / Tt, t = nn - b * Tt;
+        c.base = x + b * bstride;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int tt = t + (j - 1) * dil;
+            c.off[j] = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+        }
+        return c;
+    }
+    __device__ __forceinline__ float get(const Ctx& c, int k) const {
+        int ci = k / 3;
         if (!(c.ok && ci < Cin)) return 0.f;
-        int tap = k - ci * TAPS;
-        int tt = c.t + (tap - TAPS / 2) * dil;
-        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
-        float v = x[c.b * bstride + (long)ci * T + tt];
+        int tap = k - 3 * ci;
+        int o = tap == 0 ? c.off[0] : (tap == 1 ? c.off[1] : c.off[2]);
+        float v = c.base[ci * T + o];
         if (LRELU) v = v > 0.f ? v : 0.1f * v;
         return v;
     }
 };
 
-// FilterNet downs[0]: 3-tap conv over cat[source (16 ch), energy (1 ch)] (decoder.py:224,227).
+// FilterNet downs[0]: 3-tap conv over cat[source (16 ch), energy (1 ch)] (decoder.py:224,227);
+// k = ci*3 + tap with Cin = 17.
 struct LoadConvCat17 {
     const float* src;     // [B][16][L]
     const float* energy;  // [B][1][L]
     int T;
-    __device__ __forceinline__ float get(const Col& c, int k) const {
+    struct Ctx {
+        const float* sb;
+        const float* eb;
+        int off[3];
+        bool ok;
+    };
+    __device__ __forceinline__ Ctx ctx(int n, int ncols, int Tt) const {
+        Ctx c;
+        c.ok = n < ncols;
+        int nn = c.ok ? n : 0;
+        int b = nn / Tt, t = nn - b * Tt;
+        c.sb = src + (long)b * 16 * T;
+        c.eb = energy + (long)b * T;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int tt = t + j - 1;
+            c.off[j] = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+        }
+        return c;
+    }
+    __device__ __forceinline__ float get(const Ctx& c, int k) const {
         int ci = k / 3;
         if (!(c.ok && ci < 17)) return 0.f;
-        int tap = k - ci * 3;
-        int tt = c.t + tap - 1;
-        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
-        return ci < 16 ? src[((long)c.b * 16 + ci) * T + tt] : energy[(long)c.b * T + tt];
+        int tap = k - 3 * ci;
+        int o = tap == 0 ? c.off[0] : (tap == 1 ? c.off[1] : c.off[2]);
+        return ci < 16 ? c.sb[ci * T + o] : c.eb[o];
     }
 };
 
@@ -107,12 +163,26 @@ struct LoadConvCat17 {
 struct LoadStftFrame {
     const float* wav;  // [B][L]
     int L;
-    __device__ __forceinline__ float get(const Col& c, int k) const {
+    struct Ctx {
+        const float* wb;
+        int start;
+        bool ok;
+    };
+    __device__ __forceinline__ Ctx ctx(int n, int ncols, int Tt) const {
+        Ctx c;
+        c.ok = n < ncols;
+        int nn = c.ok ? n : 0;
+        int b = nn / Tt, t = nn - b * Tt;
+        c.wb = wav + (long)b * L;
+        c.start = (t + 1) * 480 - 960;
+        return c;
+    }
+    __device__ __forceinline__ float get(const Ctx& c, int k) const {
         if (!(c.ok && k < 1920)) return 0.f;
-        int pos = (c.t + 1) * 480 + k - 960;
+        int pos = c.start + k;
         if (pos < 0) pos = -pos;
         if (pos >= L) pos = 2 * (L - 1) - pos;
-        return wav[(long)c.b * L + pos];
+        return c.wb[pos];
     }
 };
 
@@ -230,33 +300,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const float* __restrict__ At
                                                     int ncols, int T, Loader ld, Epi ep) {
     constexpr int BM = TL::BM, BN = TL::BN, BK = TL::BK;
     constexpr int TM = TL::TM, TN = TL::TN;
-    __shared__ __attribute__((aligned(16))) float As[BK * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+    static_assert(BN <= 256, "one column per thread");
+    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / TL::WN, wn = wave % TL::WN;
     // 1-D grid, m-tiles fastest: the workgroups that share one B column tile are dispatched together
     const int mtiles = Mpad / BM;
     const int m0 = (blockIdx.x % mtiles) * BM;
     const int n0 = (blockIdx.x / mtiles) * BN;
 
-    // A staging: BK*BM/4 float4 per slab
-    constexpr int A_F4 = BK * BM / 4;
+    constexpr int A_F4 = BK * BM / 4;                 // float4s per A slab
     constexpr int A_PER = (A_F4 + 255) / 256;
-    // B staging: thread owns column (tid % BN), rows (tid / BN) + j * (256 / BN)
-    constexpr int B_RSTEP = 256 / BN > 0 ? 256 / BN : 1;
-    constexpr int B_COLS_PER = BN > 256 ? BN / 256 : 1;
-    constexpr int B_ROWS_PER = BN > 256 ? BK : BK / B_RSTEP;
+    constexpr int B_RSTEP = 256 / BN;                 // thread owns column tid % BN, rows brow0 + j*B_RSTEP
+    constexpr int B_ROWS_PER = BK / B_RSTEP;
 
-    Col cols[B_COLS_PER];
-#pragma unroll
-    for (int c = 0; c < B_COLS_PER; ++c)
-        cols[c] = make_col(n0 + (tid % (BN > 256 ? 256 : BN)) + c * 256, ncols, T);
-    const int brow0 = BN > 256 ? 0 : tid / BN;
+    const int bcol = tid % BN;
+    const int brow0 = tid / BN;
+    const typename Loader::Ctx lc = ld.ctx(n0 + bcol, ncols, T);
 
     float4 areg[A_PER];
-    float breg[B_COLS_PER][B_ROWS_PER];
+    float breg[B_ROWS_PER];
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -276,48 +343,46 @@ __global__ __launch_bounds__(256) void igemm_kernel(const float* __restrict__ At
             }
         }
 #pragma unroll
-        for (int c = 0; c < B_COLS_PER; ++c)
-#pragma unroll
-            for (int j = 0; j < B_ROWS_PER; ++j) breg[c][j] = ld.get(cols[c], k0 + brow0 + j * B_RSTEP);
+        for (int j = 0; j < B_ROWS_PER; ++j) breg[j] = ld.get(lc, k0 + brow0 + j * B_RSTEP);
     };
-    auto store_slab = [&]() {
+    auto store_slab = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int idx = tid + i * 256;
-            if (A_F4 % 256 == 0 || idx < A_F4) *reinterpret_cast<float4*>(As + idx * 4) = areg[i];
+            if (A_F4 % 256 == 0 || idx < A_F4) *reinterpret_cast<float4*>(&As[buf][idx * 4]) = areg[i];
         }
 #pragma unroll
-        for (int c = 0; c < B_COLS_PER; ++c)
-#pragma unroll
-            for (int j = 0; j < B_ROWS_PER; ++j)
-                Bs[(brow0 + j * B_RSTEP) * BN + (tid % (BN > 256 ? 256 : BN)) + c * 256] = breg[c][j];
+        for (int j = 0; j < B_ROWS_PER; ++j) Bs[buf][(brow0 + j * B_RSTEP) * BN + bcol] = breg[j];
     };
 
     const int nk = Kpad / BK;
     load_slab(0);
+    store_slab(0);
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        store_slab();
-        __syncthreads();
-        if (kt + 1 < nk) load_slab((kt + 1) * BK);  // next slab's global loads fly under the MFMAs
-        const int l31 = lane & 31, lh = lane >> 5;
+        const int cur = kt & 1;
+        const int knext = kt + 1 < nk ? kt + 1 : kt;   // last iteration re-reads its own slab (no branch)
+        load_slab(knext * BK);
+        const float* as = As[cur];
+        const float* bs = Bs[cur];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             const int k = 2 * ks + lh;
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[k * BM + (wm * TM + i) * 32 + l31];
+            for (int i = 0; i < TM; ++i) a[i] = as[k * BM + (wm * TM + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[k * BN + (wn * TN + j) * 32 + l31];
+            for (int j = 0; j < TN; ++j) b[j] = bs[k * BN + (wn * TN + j) * 32 + l31];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        store_slab(cur ^ 1);   // the other buffer was last read before the previous barrier
         __syncthreads();
     }
 
-    const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -102,7 +102,7 @@ static __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __res
     const int mt_hi = min(mtiles, mt_lo + tiles_per_split);
 
     LoadPlain ld{qn, KD, T, (long)KD * T};
-    const Col col = make_col(n0 + (tid & 127), ncols, T);
+    const LoadPlain::Ctx col = ld.ctx(n0 + (tid & 127), ncols, T);
     const int brow0 = tid >> 7;
 
     Top4 top[TN];

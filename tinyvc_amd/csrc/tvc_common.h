@@ -30,6 +30,7 @@ constexpr int kSolaCross = 1920, kSolaSearch = 1920, kSolaDelay = 3840;
 // zero padded to Kpad x Mpad (Kpad % 16 == 0, Mpad % 32 == 0), plus the bias [Mpad].
 struct PackedW {
     const float* At = nullptr;
+    const float* At_tap = nullptr;  // same weight with k = tap*cin + ci (tap-major), for the LDS-tiled conv kernels
     const float* bias = nullptr;
     int M = 0, K = 0, Mpad = 0, Kpad = 0, cin = 0, taps = 1;
 };
@@ -42,6 +43,7 @@ struct ConvNeXtW {
     PackedW c2, c3;
     const float* grn_g = nullptr;  // [2C]
     const float* grn_b = nullptr;
+    const float* c3_bias_grn = nullptr;  // c3.bias + c3.weight . grn.beta  [Mpad] (GRN's beta folded through the 1x1)
     int C = 0, dilation = 1;
 };
 
@@ -51,6 +53,7 @@ struct DownW {
 };
 struct UpW {
     PackedW c1, c2, c3, c4, c5, film1, film2;  // film = [to_scale ; to_shift] stacked on M (2C)
+    PackedW sc1, sh1, sc2, sh2;                // the same FiLM 1x1s packed separately (fused block kernels)
     int cin = 0, cout = 0, factor = 1;
 };
 
@@ -100,6 +103,8 @@ struct tvc_ctx {
     const float* src_f_b = nullptr;
     // filter net
     tvc::PackedW flt_content_in, flt_down0, flt_out;
+    const float* flt_out_w = nullptr;  // output_layer weight, raw [1][24][7]
+    const float* flt_out_b = nullptr;
     const float* flt_f_w = nullptr;
     const float* flt_f_b = nullptr;
     tvc::DownW downs[4];
@@ -193,6 +198,10 @@ int run_dsp(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* f0, const float* 
 int run_sola(tvc_ctx*, hipStream_t, const float* y, float* sola_buf, const float* fade_in, float* out, int32_t* shift_out,
              int S, int64_t Ly, int block, int use_pv);
 int run_prepare_index(tvc_ctx*, hipStream_t, const float* index, float* prepared, int64_t N);
+
+// fused FilterNet kernels (filter_fused.hip)
+int run_up24_fused(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len);
+int run_out_conv7(tvc_ctx*, hipStream_t, const float* x, const float* w_raw, const float* bias, float* y, int B, int C, int len);
 
 // ConvNeXt-v2 layer on x [B, C, T] in place (convnext.py:49-58); tmp buffers from ws.
 int run_convnext(tvc_ctx*, hipStream_t, Ws&, bool dry, const ConvNeXtW& w, float* x, int B, int T);
