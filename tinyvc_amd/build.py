@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtinyvc_hip.so")
-SOURCES = ["api.hip", "frontend.hip", "encoder.hip", "knn.hip", "decoder.hip", "filter_fused.hip", "sola.hip"]
+SOURCES = ["api.hip", "frontend.hip", "encoder.hip", "knn.hip", "decoder.hip", "filter_fused.hip", "filter_up24.hip", "sola.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -20,6 +20,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = FLAGS + os.environ.get("TVC_EXTRA_FLAGS", "").split()   # e.g. -DUP24_NT=1024 for A/B runs
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "tinyvc_hip.h"))
     objs, jobs = [], []
@@ -28,7 +29,7 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -205,16 +205,17 @@ inline void conv3_launch_t(hipStream_t s, const float* At, int Mpad, const float
     hipLaunchKernelGGL((conv3_kernel<TL, LRELU, Epi>), g, dim3(256), 0, s, a, ep);
 }
 
-// Tile choice: BM from Mpad, BN from the utterance length at this level (short levels get 64-wide tiles).
+// Tile choice: BM from Mpad; BN as wide as still yields enough workgroups to fill 256 CUs several times.
 template <bool LRELU, class Epi>
 inline void conv3_launch(hipStream_t s, const float* At, int Mpad, const float* x, int B, int Cin, int len, int dil, const Epi& ep) {
-    const bool shortlen = len < 1024;
+    constexpr long kEnough = 1536;
+    auto blocks = [&](int BM, int BN) { return (long)(Mpad / BM) * ((len + BN - 1) / BN) * B; };
     if (Mpad % 128 == 0) {
-        if (shortlen) conv3_launch_t<Conv3Tile<4, 1, 1, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);   // 128 x 64
-        else conv3_launch_t<Conv3Tile<2, 2, 2, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);            // 128 x 128
+        if (blocks(128, 128) >= kEnough) conv3_launch_t<Conv3Tile<2, 2, 2, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);   // 128 x 128
+        else conv3_launch_t<Conv3Tile<4, 1, 1, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);                               // 128 x 64
     } else if (Mpad % 96 == 0) {
-        if (shortlen) conv3_launch_t<Conv3Tile<1, 4, 3, 1>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);   // 96 x 128
-        else conv3_launch_t<Conv3Tile<1, 4, 3, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);            // 96 x 256
+        if (blocks(96, 256) >= kEnough) conv3_launch_t<Conv3Tile<1, 4, 3, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);    // 96 x 256
+        else conv3_launch_t<Conv3Tile<1, 4, 3, 1>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);                               // 96 x 128
     } else if (Mpad % 64 == 0) {
         conv3_launch_t<Conv3Tile<1, 4, 2, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);                 // 64 x 256
     } else {

@@ -246,9 +246,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         LoadPlain ld{content, kSslDim, T, (long)kSslDim * T};
         EpiSumCond ep{x, ctx->flt_content_in.bias, nullptr, f0, nullptr, nullptr, ctx->flt_f_w, ctx->flt_f_b, ch[0], T, B * T};
         igemm_launch(s, ctx->flt_content_in.At, ctx->flt_content_in.Mpad, ctx->flt_content_in.Kpad, B * T, T, ld, ep);
-        LoadConvCat17 l0{source, energy, (int)L};
-        EpiBias<ACT_NONE, false> e0{skip[0], ctx->flt_down0.bias, nullptr, 24, (int)L, (int)(B * L), 24 * L, 0};
-        igemm_launch(s, ctx->flt_down0.At, ctx->flt_down0.Mpad, ctx->flt_down0.Kpad, (int)(B * L), (int)L, l0, e0);
+        TVC_CHECK(run_down0(ctx, s, ctx->flt_down0, source, energy, skip[0], B, (int)L));
     }
     // down path
     for (int i = 1; i <= 4; ++i) {
@@ -287,6 +285,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         }
     }
     long len = T;
+    bool fused_out = false;
     for (int i = 0; i < 5; ++i) {
         const UpW& u = ctx->ups[i];
         const int lin = (int)len;
@@ -299,8 +298,10 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         float* h = ws.get<float>((size_t)B * C * lo);
         float* x1 = ws.get<float>((size_t)B * C * lo);
         if (!dry && C == 24) {
-            ProfScope ps(ctx, s, dry, "filter.up4");
-            TVC_CHECK(run_up24_fused(ctx, s, u, x, cond, x1, xlev[i], B, lo));
+            // last level: Upsample block + output_layer in two launches, waveform written directly
+            ProfScope ps(ctx, s, dry, "filter.up4+out");
+            TVC_CHECK(run_up24_fused(ctx, s, u, x, cond, x1, wave, B, lo, ctx->flt_out_w, ctx->flt_out_b));
+            fused_out = true;
         } else if (!dry) {
             static const char* names[5] = {"filter.up0", "filter.up1", "filter.up2", "filter.up3", "filter.up4"};
             ProfScope ps(ctx, s, dry, names[i]);
@@ -329,7 +330,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         ws.release(mk);
         x = xlev[i];
     }
-    if (!dry) {
+    if (!dry && !fused_out) {
         ProfScope ps(ctx, s, dry, "filter.out");
         TVC_CHECK(run_out_conv7(ctx, s, x, ctx->flt_out_w, ctx->flt_out_b, wave, B, 24, (int)L));
     }

@@ -398,27 +398,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const float* __restrict__ At
         }
 }
 
-// Host-side launch: picks the tile shape from Mpad.
+// Host-side launch.  The tile shape is picked from Mpad and from the grid it yields: these GEMMs are
+// small for a 256-CU chip (N = B*T is 12 800 columns for 64 x 4 s), so a 128 x 128 tiling can leave
+// 300 workgroups for 1024 resident slots; smaller tiles trade operand reuse for a full machine.
+template <class TL, class Loader, class Epi>
+inline void igemm_launch_t(hipStream_t s, const float* At, int Mpad, int Kpad, int ncols, int T,
+                           const Loader& ld, const Epi& ep) {
+    dim3 g((unsigned)((Mpad / TL::BM) * ((ncols + TL::BN - 1) / TL::BN)));
+    hipLaunchKernelGGL((igemm_kernel<TL, Loader, Epi>), g, dim3(256), 0, s, At, Mpad, Kpad, ncols, T, ld, ep);
+}
+
+inline long igemm_blocks(int Mpad, int ncols, int BM, int BN) { return (long)(Mpad / BM) * ((ncols + BN - 1) / BN); }
+
 template <class Loader, class Epi>
 inline void igemm_launch(hipStream_t s, const float* At, int Mpad, int Kpad, int ncols, int T,
                          const Loader& ld, const Epi& ep) {
     if (ncols <= 0) return;
+    constexpr long kEnough = 1536;   // ~6 workgroups per CU
     if (Mpad % 128 == 0) {
-        using TL = Tile<2, 2, 2, 2>;  // 128 x 128
-        dim3 g((unsigned)((Mpad / TL::BM) * ((ncols + TL::BN - 1) / TL::BN)));
-        hipLaunchKernelGGL((igemm_kernel<TL, Loader, Epi>), g, dim3(256), 0, s, At, Mpad, Kpad, ncols, T, ld, ep);
+        if (igemm_blocks(Mpad, ncols, 128, 128) >= kEnough) igemm_launch_t<Tile<2, 2, 2, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
+        else if (igemm_blocks(Mpad, ncols, 64, 128) >= kEnough) igemm_launch_t<Tile<2, 2, 1, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
+        else igemm_launch_t<Tile<2, 2, 1, 1>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
     } else if (Mpad % 96 == 0) {
-        using TL = Tile<1, 4, 3, 1>;  // 96 x 128
-        dim3 g((unsigned)((Mpad / TL::BM) * ((ncols + TL::BN - 1) / TL::BN)));
-        hipLaunchKernelGGL((igemm_kernel<TL, Loader, Epi>), g, dim3(256), 0, s, At, Mpad, Kpad, ncols, T, ld, ep);
+        igemm_launch_t<Tile<1, 4, 3, 1>>(s, At, Mpad, Kpad, ncols, T, ld, ep);   // 96 x 128
     } else if (Mpad % 64 == 0) {
-        using TL = Tile<1, 4, 2, 2>;  // 64 x 256
-        dim3 g((unsigned)((Mpad / TL::BM) * ((ncols + TL::BN - 1) / TL::BN)));
-        hipLaunchKernelGGL((igemm_kernel<TL, Loader, Epi>), g, dim3(256), 0, s, At, Mpad, Kpad, ncols, T, ld, ep);
+        if (igemm_blocks(Mpad, ncols, 64, 256) >= kEnough) igemm_launch_t<Tile<1, 4, 2, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
+        else if (igemm_blocks(Mpad, ncols, 64, 128) >= kEnough) igemm_launch_t<Tile<2, 2, 1, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
+        else igemm_launch_t<Tile<2, 2, 1, 1>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
     } else {
-        using TL = Tile<1, 4, 1, 2>;  // 32 x 256
-        dim3 g((unsigned)((Mpad / TL::BM) * ((ncols + TL::BN - 1) / TL::BN)));
-        hipLaunchKernelGGL((igemm_kernel<TL, Loader, Epi>), g, dim3(256), 0, s, At, Mpad, Kpad, ncols, T, ld, ep);
+        igemm_launch_t<Tile<1, 4, 1, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);   // 32 x 256
     }
 }
 

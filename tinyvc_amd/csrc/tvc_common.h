@@ -200,7 +200,9 @@ int run_sola(tvc_ctx*, hipStream_t, const float* y, float* sola_buf, const float
 int run_prepare_index(tvc_ctx*, hipStream_t, const float* index, float* prepared, int64_t N);
 
 // fused FilterNet kernels (filter_fused.hip)
-int run_up24_fused(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len);
+int run_up24_fused(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len,
+                   const float* w7, const float* b7);
+int run_down0(tvc_ctx*, hipStream_t, const PackedW& w, const float* source, const float* energy, float* out, int B, int len);
 int run_out_conv7(tvc_ctx*, hipStream_t, const float* x, const float* w_raw, const float* bias, float* y, int B, int C, int len);
 
 // ConvNeXt-v2 layer on x [B, C, T] in place (convnext.py:49-58); tmp buffers from ws.
