@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Offline voice conversion on an MI355X: the reference's `infer.py` entry point (same flags,
+reference infer.py:17-29) driving the HIP path.
+
+  python infer.py -i ./inputs/ -o ./outputs/ -encp models/encoder.pt -decp models/decoder.pt \\
+                  -t target.wav | -idx models/index.pt   [-p SEMITONES] [-d cuda]
+
+Differences from the reference, all at the edges of the path: files are read/written with the
+package's own WAV I/O and resampler (torchaudio is not a dependency; ogg/mp3 need a codec and are
+skipped with a message); `-d` defaults to `cuda` and must be a GPU (there is no CPU path);
+all inputs of equal padded length are converted as one batch.  `--chunk-size / --buffer-size /
+--no-chunking` are accepted and, as in the reference (infer.py:27-29,40-41,66), do not change the
+computation: every file is converted whole.
+"""
+import argparse
+import glob
+import os
+import sys
+
+import torch
+
+from tinyvc_amd import audio_io
+from tinyvc_amd.module.infer import Generator
+from tinyvc_amd.module.tinyvc import Decoder, Encoder
+from tinyvc_amd.resample import resample
+
+SAMPLE_RATE = 24000
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="tinyvc offline conversion (MI355X)")
+    p.add_argument("-i", "--inputs", default="./inputs/")
+    p.add_argument("-o", "--outputs", default="./outputs/")
+    p.add_argument("-encp", "--encoder-path", default="./models/encoder.pt")
+    p.add_argument("-decp", "--decoder-path", default="./models/decoder.pt")
+    p.add_argument("-f0-est", "--f0-estimation", default="default")
+    p.add_argument("-idx", "--index", default="NONE")
+    p.add_argument("-t", "--target", default="target.wav")
+    p.add_argument("-d", "--device", default="cuda")
+    p.add_argument("-p", "--pitch-shift", default=0.0, type=float)
+    p.add_argument("-c", "--chunk-size", default=1920, type=int)
+    p.add_argument("-b", "--buffer-size", default=4, type=int)
+    p.add_argument("-nc", "--no-chunking", default=False, type=bool)
+    return p
+
+
+def load_generator(encoder_path, decoder_path, device):
+    enc, dec = Encoder(), Decoder()
+    enc.load_state_dict(torch.load(encoder_path, map_location="cpu"))
+    dec.load_state_dict(torch.load(decoder_path, map_location="cpu"))
+    return Generator(enc.eval(), dec.eval()).to(device)
+
+
+def load_target(gen, args, device):
+    """Speaker target: features of a target utterance, or a prebuilt index.pt [1, 768, N]."""
+    if args.index == "NONE":
+        wf, sr = audio_io.load(args.target)
+        wf = resample(wf, sr, SAMPLE_RATE).to(device)
+        tgt, _f0 = gen.encode(wf.mean(dim=0, keepdim=True) if wf.shape[0] > 1 else wf)
+        return tgt
+    return torch.load(args.index, map_location="cpu").to(device)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    device = torch.device(args.device)
+    if device.type != "cuda":
+        sys.exit("infer.py: this build runs on an AMD GPU only; pass -d cuda (the reference's CPU path is not part of it)")
+    gen = load_generator(args.encoder_path, args.decoder_path, device)
+    tgt = load_target(gen, args, device)
+    os.makedirs(args.outputs, exist_ok=True)
+
+    paths = []
+    for ext in ("wav", "ogg", "mp3"):
+        paths += sorted(glob.glob(os.path.join(args.inputs, "*." + ext)))
+    jobs = []
+    for path in paths:
+        if not path.lower().endswith(".wav"):
+            print(f"Skipping {path}: no decoder for this container in this build")
+            continue
+        wf, sr = audio_io.load(path)
+        wf = resample(wf, sr, SAMPLE_RATE).mean(dim=0, keepdim=True)       # mono, 24 kHz (infer.py:63-64)
+        jobs.append((path, wf))
+
+    # group equal-length inputs so each group is one batched convert
+    by_len = {}
+    for path, wf in jobs:
+        by_len.setdefault(wf.shape[1], []).append((path, wf))
+    for length, group in by_len.items():
+        print(f"Converting {len(group)} file(s) of {length} samples ...")
+        batch = torch.cat([wf for _p, wf in group], dim=0).to(device)
+        out = gen.convert(batch, tgt, args.pitch_shift).cpu()
+        for (path, _wf), y in zip(group, out):
+            name = os.path.splitext(os.path.basename(path))[0]
+            audio_io.save(os.path.join(args.outputs, f"{name}.wav"), y[None], SAMPLE_RATE)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

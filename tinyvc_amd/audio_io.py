@@ -1,0 +1,34 @@
+"""WAV file I/O for the entry scripts (the reference uses torchaudio.load / torchaudio.save,
+infer.py:45,62,69; torchaudio is not a dependency here).  Conventions follow torchaudio:
+`load` returns (float32 tensor [channels, frames] scaled to [-1, 1), sample_rate); `save` takes
+[channels, frames] float32 and writes a 32-bit float WAV (what torchaudio.save does for a float32
+tensor by default)."""
+import numpy as np
+import torch
+from scipy.io import wavfile
+
+SUPPORTED = ("wav",)
+
+
+def load(path):
+    if not str(path).lower().endswith(".wav"):
+        raise ValueError(f"{path}: only WAV is readable without an audio codec library (ogg/mp3 need torchaudio/ffmpeg)")
+    sr, data = wavfile.read(path)
+    if data.ndim == 1:
+        data = data[:, None]
+    if data.dtype == np.int16:
+        x = data.astype(np.float32) / 32768.0
+    elif data.dtype == np.int32:
+        x = data.astype(np.float32) / 2147483648.0
+    elif data.dtype == np.uint8:
+        x = (data.astype(np.float32) - 128.0) / 128.0
+    else:
+        x = data.astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(x.T)), int(sr)
+
+
+def save(path, src, sample_rate):
+    x = src.detach().to("cpu", torch.float32)
+    if x.dim() == 1:
+        x = x[None]
+    wavfile.write(path, int(sample_rate), np.ascontiguousarray(x.numpy().T))
