@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=220)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--index", type=int, default=1000)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP-graph replay per block")
     args = ap.parse_args()
     from bench import build_generator
     from tinyvc_amd.module.infer import BatchedStreamInfer
@@ -33,7 +34,7 @@ def main():
     gen = build_generator(dev)
     S = args.streams
     st = BatchedStreamInfer(gen, n_streams=S, target=synth.synth_index(args.index, seed=2).to(dev), device=dev,
-                            block_size=1920, extra_size=3840)
+                            block_size=1920, extra_size=3840, use_graph=not args.no_graph)
     st.init_buffer()
     waves = torch.stack([synth.synth_wave(1, args.blocks * 1920, seed=200 + s)[0] for s in range(min(S, 4))])
     waves = waves[torch.arange(S) % waves.shape[0]].to(dev).view(S, args.blocks, 1920)
@@ -49,7 +50,7 @@ def main():
     l = np.sort(np.array(lat[args.warmup:])) * 1e3
     res = {"metric": "chunk latency, concurrent real-time streams", "streams": S, "block_samples": 1920, "budget_ms": 80.0,
            "p50_ms": float(l[len(l) // 2]), "p95_ms": float(l[int(len(l) * 0.95)]), "max_ms": float(l[-1]),
-           "blocks": len(l), "streams_per_gpu_at_realtime_p95": int(S * 80.0 / l[int(len(l) * 0.95)]),
+           "blocks": len(l), "hip_graph": not args.no_graph, "streams_per_gpu_at_realtime_p95": int(S * 80.0 / l[int(len(l) * 0.95)]),
            "config": {"workload": f"infer_streaming.py {S} concurrent streams, 13440-sample buffer, {args.index}-vector index (BASELINE.json configs[2])"}}
     print(json.dumps(res))
 

@@ -16,7 +16,7 @@ def _fade_windows(crossfade_size, device):
 
 class BatchedStreamInfer:
     def __init__(self, generator: Generator, n_streams=1, target=None, pitch_shift=0., device=None,
-                 block_size=1920, extra_size=0, use_phase_vocoder=False, f0_estimation="default"):
+                 block_size=1920, extra_size=0, use_phase_vocoder=False, f0_estimation="default", use_graph=False):
         self.generator = generator
         self.n_streams = n_streams
         self.target = target
@@ -32,36 +32,61 @@ class BatchedStreamInfer:
         self.input_size = max(self.block_size + self.crossfade_size + self.sola_search_size + 2 * self.last_dilay_size,
                               self.block_size + self.extra_size)
         self.last_shift = None
+        # use_graph: after two eager warm-up blocks the whole per-block pipeline (buffer roll, noise draw,
+        # convert, SOLA) is captured once into a HIP graph and replayed per block: ~170 launches become one.
+        self.use_graph = use_graph
+        self._graph = None
+        self._calls = 0
 
     def init_buffer(self):
         self.fade_in_window, self.fade_out_window = _fade_windows(self.crossfade_size, self.device)
         self.input_wav = torch.zeros(self.n_streams, self.input_size, device=self.device)
         self.sola_buffer = torch.zeros(self.n_streams, self.crossfade_size, device=self.device)
+        self._graph = None
+        self._calls = 0
+
+    def _step(self, blocks, noise_angle):
+        # torch.roll + slice assignment of the reference (stream.py:69-70), in place on a fixed buffer
+        self.input_wav.copy_(torch.roll(self.input_wav, -self.block_size, dims=1))
+        self.input_wav[:, -self.block_size:] = blocks
+        y = self.generator.convert(self.input_wav, self.target, self.pitch_shift, device=self.device,
+                                   f0_estimation=self.f0_estimation, noise_angle=noise_angle)
+        eng = self.generator.engine(self.device)
+        return eng.sola(y, self.sola_buffer, self.fade_in_window, self.block_size,
+                        self.use_phase_vocoder, want_shift=True)
 
     @torch.no_grad()
     def audio_callback(self, blocks, noise_angle=None):
         """blocks [S, block_size] -> converted blocks [S, block_size]."""
         blocks = blocks.to(self.device)
-        self.input_wav = torch.roll(self.input_wav, -self.block_size, dims=1)
-        self.input_wav[:, -self.block_size:] = blocks
-        y = self.generator.convert(self.input_wav, self.target, self.pitch_shift, device=self.device,
-                                   f0_estimation=self.f0_estimation, noise_angle=noise_angle)
-        eng = self.generator.engine(self.device)
-        out, shift = eng.sola(y, self.sola_buffer, self.fade_in_window, self.block_size,
-                              self.use_phase_vocoder, want_shift=True)
-        self.last_shift = shift
-        return out
+        self._calls += 1
+        if not self.use_graph or noise_angle is not None or self._calls <= 2:
+            out, shift = self._step(blocks, noise_angle)
+            self.last_shift = shift
+            return out
+        if self._graph is None:
+            self._g_in = torch.zeros(self.n_streams, self.block_size, device=self.device)
+            self._g_in.copy_(blocks)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._g_out, self._g_shift = self._step(self._g_in, None)
+            self._graph = g          # capture does not execute: fall through to the first replay
+        self._g_in.copy_(blocks)
+        self._graph.replay()
+        self.last_shift = self._g_shift
+        return self._g_out.clone()
 
 
 class StreamInfer(BatchedStreamInfer):
     """Single stream with the reference's constructor and 1-D buffers (stream.py:31-57)."""
 
     def __init__(self, generator: Generator, target=None, pitch_shift=0., device=torch.device("cpu"),
-                 block_size=1920, extra_size=0, use_phase_vocoder=False, f0_estimation="default"):
+                 block_size=1920, extra_size=0, use_phase_vocoder=False, f0_estimation="default", use_graph=False):
         dev = torch.device(device)
         if dev.type != "cuda":
             dev = generator._module_device()     # the reference defaults to CPU; there is no CPU path here
-        super().__init__(generator, 1, target, pitch_shift, dev, block_size, extra_size, use_phase_vocoder, f0_estimation)
+        super().__init__(generator, 1, target, pitch_shift, dev, block_size, extra_size, use_phase_vocoder, f0_estimation, use_graph)
 
     @torch.no_grad()
     def audio_callback(self, block, noise_angle=None):
