@@ -27,6 +27,11 @@ struct Conv3Args {
     const float* At;    // [Kpad][Mpad], k = ci*3 + tap
     const float* x;     // [B][Cin][len]
     int Mpad, Cin, len, dil, tiles_per_utt;
+    // FiLM fused behind the conv (FILM kernels only): scale/shift = 1x1 convs of cond [B][Ccond][len]
+    const float* sc_At;  // [Ccond_pad][Mpad]
+    const float* sh_At;
+    const float* cond;
+    int Ccond;
 };
 
 // Epilogue interface: store(b, t, m, v[4]) for 4 consecutive channels m..m+3 at (b, t); t < len guaranteed.
@@ -68,7 +73,26 @@ struct C3EpiFilm {
     }
 };
 
-template <class TL, bool LRELU, class Epi>
+// conv -> FiLM -> + residual with scale/shift computed in-kernel: store(b, t, m, h[4], sc[4], sh[4])
+struct C3EpiFilmFused {
+    float* y;
+    const float* bias;
+    const float* bsc;
+    const float* bsh;
+    const float* res;
+    int M, len;
+    __device__ __forceinline__ void store(int b, int t, int m, const float h[4], const float sc[4], const float sh[4]) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (m + r < M) {
+                long i = ((long)b * M + m + r) * len + t;
+                float hv = h[r] + bias[m + r];
+                y[i] = __fadd_rn(__fadd_rn(__fmul_rn(hv, sc[r] + bsc[m + r]), sh[r] + bsh[m + r]), res[i]);
+            }
+    }
+};
+
+template <class TL, bool LRELU, class Epi, bool FILM = false>
 __global__ __launch_bounds__(256) void conv3_kernel(Conv3Args a, Epi ep) {
     constexpr int BM = TL::BM, BN = TL::BN, TM = TL::TM, TN = TL::TN, KC = TL::KC, KS = TL::KS, XROW = TL::XROW;
     __shared__ __attribute__((aligned(16))) float As[2][KS * BM];
@@ -175,25 +199,130 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Args a, Epi ep) {
         __syncthreads();
     }
 
+    if constexpr (FILM) {
+        // ---- FiLM: two 1x1 contractions over the cond tile on the same MFMA tiles (8-row slabs, the conv's
+        // LDS buffers are reused); results stay in registers next to the conv accumulators -----------------
+        f32x16 asc[TM][TN], ash[TM][TN];
+        constexpr int FK = 8;                          // cond channels per slab
+        constexpr int FA_F4 = FK * BM / 4, FA_PER = (FA_F4 + 255) / 256;
+        constexpr int FB_PER = (FK * BN + 255) / 256;
+        const float* cb = a.cond + (long)b * a.Ccond * len;
+        auto film_phase = [&](const float* Wt, f32x16 (&out)[TM][TN]) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int t = t0 + (wn * TN + j) * 32 + l31;
-            if (t < len) {
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = m0 + (wm * TM + i) * 32 + 8 * q + 4 * lh;
-                    float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    ep.store(b, t, m, v);
+                    for (int r = 0; r < 16; ++r) out[i][j][r] = 0.f;
+            float4 fa[FA_PER];
+            float fb[FB_PER];
+            auto fload = [&](int c0) {
+#pragma unroll
+                for (int i = 0; i < FA_PER; ++i) {
+                    int idx = tid + i * 256;
+                    if (FA_F4 % 256 == 0 || idx < FA_F4) {
+                        int kk = idx / (BM / 4), c4 = idx - kk * (BM / 4);
+                        fa[i] = *reinterpret_cast<const float4*>(Wt + (long)(c0 + kk) * a.Mpad + m0 + c4 * 4);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < FB_PER; ++i) {
+                    int idx = tid + i * 256;
+                    int r = idx / BN, c = idx - r * BN;
+                    int t = t0 + c;
+                    t = t > len - 1 ? len - 1 : t;
+                    fb[i] = (r < FK && c0 + r < a.Ccond) ? cb[(long)(c0 + r) * len + t] : 0.f;
+                }
+            };
+            auto fstore = [&](int buf) {
+#pragma unroll
+                for (int i = 0; i < FA_PER; ++i) {
+                    int idx = tid + i * 256;
+                    if (FA_F4 % 256 == 0 || idx < FA_F4) *reinterpret_cast<float4*>(&As[buf][idx * 4]) = fa[i];
+                }
+#pragma unroll
+                for (int i = 0; i < FB_PER; ++i) {
+                    int idx = tid + i * 256;
+                    if (idx < FK * BN) Xs[buf][idx] = fb[i];
+                }
+            };
+            const int ns = (a.Ccond + FK - 1) / FK;
+            fload(0);
+            fstore(0);
+            __syncthreads();
+            for (int s2 = 0; s2 < ns; ++s2) {
+                const int cur = s2 & 1;
+                fload((s2 + 1 < ns ? s2 + 1 : s2) * FK);
+                const float* as = As[cur];
+                const float* bs = Xs[cur];
+#pragma unroll
+                for (int ks = 0; ks < FK / 2; ++ks) {
+                    float av[TM], bv[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) av[i] = as[(2 * ks + lh) * BM + (wm * TM + i) * 32 + l31];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bv[j] = bs[(2 * ks + lh) * BN + (wn * TN + j) * 32 + l31];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            out[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], out[i][j], 0, 0, 0);
+                }
+                fstore(cur ^ 1);
+                __syncthreads();
+            }
+        };
+        film_phase(a.sc_At, asc);
+        film_phase(a.sh_At, ash);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int t = t0 + (wn * TN + j) * 32 + l31;
+                if (t < len) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int m = m0 + (wm * TM + i) * 32 + 8 * q + 4 * lh;
+                        float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        float c1[4] = {asc[i][j][4 * q], asc[i][j][4 * q + 1], asc[i][j][4 * q + 2], asc[i][j][4 * q + 3]};
+                        float c2[4] = {ash[i][j][4 * q], ash[i][j][4 * q + 1], ash[i][j][4 * q + 2], ash[i][j][4 * q + 3]};
+                        ep.store(b, t, m, v, c1, c2);
+                    }
                 }
             }
-        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int t = t0 + (wn * TN + j) * 32 + l31;
+                if (t < len) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int m = m0 + (wm * TM + i) * 32 + 8 * q + 4 * lh;
+                        float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        ep.store(b, t, m, v);
+                    }
+                }
+            }
+    }
 }
 
-template <class TL, bool LRELU, class Epi>
-inline void conv3_launch_t(hipStream_t s, const float* At, int Mpad, const float* x, int B, int Cin, int len, int dil, const Epi& ep) {
+struct FilmOps {
+    const float* sc_At = nullptr;
+    const float* sh_At = nullptr;
+    const float* cond = nullptr;
+    int Ccond = 0;
+};
+
+template <class TL, bool LRELU, class Epi, bool FILM = false>
+inline void conv3_launch_t(hipStream_t s, const float* At, int Mpad, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
+                           const FilmOps& f = FilmOps()) {
     Conv3Args a;
+    a.sc_At = f.sc_At;
+    a.sh_At = f.sh_At;
+    a.cond = f.cond;
+    a.Ccond = f.Ccond;
     a.At = At;
     a.x = x;
     a.Mpad = Mpad;
@@ -202,24 +331,25 @@ inline void conv3_launch_t(hipStream_t s, const float* At, int Mpad, const float
     a.dil = dil;
     a.tiles_per_utt = (len + TL::BN - 1) / TL::BN;
     dim3 g((unsigned)((Mpad / TL::BM) * a.tiles_per_utt * B));
-    hipLaunchKernelGGL((conv3_kernel<TL, LRELU, Epi>), g, dim3(256), 0, s, a, ep);
+    hipLaunchKernelGGL((conv3_kernel<TL, LRELU, Epi, FILM>), g, dim3(256), 0, s, a, ep);
 }
 
 // Tile choice: BM from Mpad; BN as wide as still yields enough workgroups to fill 256 CUs several times.
-template <bool LRELU, class Epi>
-inline void conv3_launch(hipStream_t s, const float* At, int Mpad, const float* x, int B, int Cin, int len, int dil, const Epi& ep) {
+template <bool LRELU, class Epi, bool FILM = false>
+inline void conv3_launch(hipStream_t s, const float* At, int Mpad, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
+                         const FilmOps& f = FilmOps()) {
     constexpr long kEnough = 1536;
     auto blocks = [&](int BM, int BN) { return (long)(Mpad / BM) * ((len + BN - 1) / BN) * B; };
     if (Mpad % 128 == 0) {
-        if (blocks(128, 128) >= kEnough) conv3_launch_t<Conv3Tile<2, 2, 2, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);   // 128 x 128
-        else conv3_launch_t<Conv3Tile<4, 1, 1, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);                               // 128 x 64
+        if (blocks(128, 128) >= kEnough) conv3_launch_t<Conv3Tile<2, 2, 2, 2>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);   // 128 x 128
+        else conv3_launch_t<Conv3Tile<4, 1, 1, 2>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                               // 128 x 64
     } else if (Mpad % 96 == 0) {
-        if (blocks(96, 256) >= kEnough) conv3_launch_t<Conv3Tile<1, 4, 3, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);    // 96 x 256
-        else conv3_launch_t<Conv3Tile<1, 4, 3, 1>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);                               // 96 x 128
+        if (blocks(96, 256) >= kEnough) conv3_launch_t<Conv3Tile<1, 4, 3, 2>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);    // 96 x 256
+        else conv3_launch_t<Conv3Tile<1, 4, 3, 1>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                               // 96 x 128
     } else if (Mpad % 64 == 0) {
-        conv3_launch_t<Conv3Tile<1, 4, 2, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);                 // 64 x 256
+        conv3_launch_t<Conv3Tile<1, 4, 2, 2>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                 // 64 x 256
     } else {
-        conv3_launch_t<Conv3Tile<1, 4, 1, 2>, LRELU>(s, At, Mpad, x, B, Cin, len, dil, ep);                 // 32 x 256
+        conv3_launch_t<Conv3Tile<1, 4, 1, 2>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                 // 32 x 256
     }
 }
 

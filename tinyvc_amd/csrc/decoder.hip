@@ -294,7 +294,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         const float* cond = skip[4 - i];
         size_t mk = ws.mark();
         float* xu = ws.get<float>((size_t)B * C * lo);
-        float* film = ws.get<float>((size_t)B * 2 * C * lo);
+        float* film = (C < 96 && C != 24) ? ws.get<float>((size_t)B * 2 * C * lo) : nullptr;
         float* h = ws.get<float>((size_t)B * C * lo);
         float* x1 = ws.get<float>((size_t)B * C * lo);
         if (!dry && C == 24) {
@@ -309,19 +309,28 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
             hipLaunchKernelGGL(lerp_resize_kernel, dim3(grid_for((long)B * C * lo)), dim3(256), 0, s, x, xu, (long)B * C, lin, lo,
                                (float)(1.0 / (double)u.factor));
             for (int half = 0; half < 2; ++half) {
-                const PackedW& fw = half ? u.film2 : u.film1;
                 const PackedW& ca = half ? u.c3 : u.c1;
                 const PackedW& cb = half ? u.c4 : u.c2;
                 const int da = half ? 9 : 1, db = half ? 27 : 3;
                 const float* xin = half ? x1 : xu;
                 float* xout = half ? xu : x1;  // 2nd half writes over xu (its input and residual are x1)
-                {
+                const PackedW& wsc = half ? u.sc2 : u.sc1;
+                const PackedW& wsh = half ? u.sh2 : u.sh1;
+                conv3_launch<true>(s, ca.At, ca.Mpad, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo});
+                if (C >= 96) {
+                    // second conv with FiLM(cond) and the residual fused: scale/shift never touch HBM
+                    // (measured time-neutral at C >= 96, and it removes the [B][2C][len] film tensor)
+                    conv3_launch<true, C3EpiFilmFused, true>(s, cb.At, cb.Mpad, h, B, C, lo, db,
+                                                             C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
+                                                             FilmOps{wsc.At, wsh.At, cond, C});
+                } else {
+                    // C = 48: three live accumulator sets cost more occupancy than the film round-trip (measured)
+                    const PackedW& fw = half ? u.film2 : u.film1;
                     LoadPlain ld{cond, C, lo, (long)C * lo};
                     EpiBias<ACT_NONE, false> ep{film, fw.bias, nullptr, 2 * C, lo, nc, (long)2 * C * lo, 0};
                     igemm_launch(s, fw.At, fw.Mpad, fw.Kpad, nc, lo, ld, ep);
+                    conv3_launch<true>(s, cb.At, cb.Mpad, h, B, C, lo, db, C3EpiFilm{xout, cb.bias, film, xin, C, lo});
                 }
-                conv3_launch<true>(s, ca.At, ca.Mpad, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo});
-                conv3_launch<true>(s, cb.At, cb.Mpad, h, B, C, lo, db, C3EpiFilm{xout, cb.bias, film, xin, C, lo});
             }
             LoadPlain ld{xu, C, lo, (long)C * lo};
             EpiBias<ACT_NONE, false> ep{xlev[i], u.c5.bias, nullptr, u.cout, lo, nc, (long)u.cout * lo, 0};

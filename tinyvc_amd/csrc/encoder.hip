@@ -7,15 +7,16 @@ namespace tvc {
 
 // -------------------------------------------------------------------------------------------------
 // [depthwise k7 dilated replicate-padded conv] + LayerNorm over channels, per time column.
-// One workgroup = 64 consecutive time steps of one utterance; the 4 waves split the channels
-// (c = wave, wave+4, ...), lanes run along time (coalesced).  Two-pass moments (mean, then
-// centred variance) through a 4x64 LDS exchange; every thread re-reads only values it wrote.
+// One workgroup = 64 consecutive time steps of one utterance; its 16 waves split the channels
+// (c = wave, wave+16, ...), lanes run along time (coalesced).  Two-pass moments (mean, then
+// centred variance) through a 16x64 LDS exchange; every thread re-reads only values it wrote.
 template <bool DW>
-static __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* x, float* y,
+static __global__ __launch_bounds__(1024) void dwconv_ln_kernel(const float* x, float* y,
                                                                const float* __restrict__ dw_w, const float* __restrict__ dw_b,
                                                                const float* __restrict__ g, const float* __restrict__ bta,
                                                                int C, int T, int dil) {
-    __shared__ float red[4][64];
+    constexpr int NW = 16;
+    __shared__ float red[NW][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int t = blockIdx.x * 64 + lane;
@@ -25,7 +26,7 @@ static __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* x, f
     float* yb = y + (long)b * C * T;
 
     float sum = 0.f;
-    for (int c = wave; c < C; c += 4) {
+    for (int c = wave; c < C; c += NW) {
         float v;
         if (DW) {
             const float* xr = xb + (long)c * T;
@@ -44,19 +45,25 @@ static __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* x, f
     }
     red[wave][lane] = sum;
     __syncthreads();
-    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[w][lane];
+    const float mean = tot / (float)C;
     __syncthreads();
     float sq = 0.f;
-    for (int c = wave; c < C; c += 4) {
+    for (int c = wave; c < C; c += NW) {
         float v = (DW ? yb : xb)[(long)c * T + tc] - mean;
         sq = fmaf(v, v, sq);
     }
     red[wave][lane] = sq;
     __syncthreads();
-    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    float tot2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot2 += red[w][lane];
+    const float var = tot2 / (float)C;
     const float rstd = 1.f / sqrtf(var + 1e-5f);
     if (!ok) return;
-    for (int c = wave; c < C; c += 4) {
+    for (int c = wave; c < C; c += NW) {
         long i = (long)c * T + t;
         float v = (DW ? yb : xb)[i];
         yb[i] = fmaf((v - mean) * rstd, g[c], bta[c]);
@@ -97,7 +104,7 @@ static __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* _
 }
 
 int run_layernorm(tvc_ctx* ctx, hipStream_t s, float* x, const float* g, const float* b, int B, int C, int T) {
-    hipLaunchKernelGGL((dwconv_ln_kernel<false>), dim3((T + 63) / 64, B), dim3(256), 0, s, x, x, nullptr, nullptr, g, b, C, T, 1);
+    hipLaunchKernelGGL((dwconv_ln_kernel<false>), dim3((T + 63) / 64, B), dim3(1024), 0, s, x, x, nullptr, nullptr, g, b, C, T, 1);
     return launch_check(ctx, "layernorm");
 }
 
@@ -110,7 +117,7 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     float* nx = ws.get<float>((size_t)B * C2);
     ws.release(mk);
     if (dry) return 0;
-    hipLaunchKernelGGL((dwconv_ln_kernel<true>), dim3((T + 63) / 64, B), dim3(256), 0, s, x, y, w.dw_w, w.dw_b, w.ln_g, w.ln_b, C, T, w.dilation);
+    hipLaunchKernelGGL((dwconv_ln_kernel<true>), dim3((T + 63) / 64, B), dim3(1024), 0, s, x, y, w.dw_w, w.dw_b, w.ln_g, w.ln_b, C, T, w.dilation);
     {
         LoadPlain ld{y, C, T, (long)C * T};
         EpiBias<ACT_GELU, false> ep{h, w.c2.bias, nullptr, C2, T, ncols, (long)C2 * T, 0};
