@@ -29,7 +29,19 @@ from tinyvc_amd import synth  # noqa: E402
 
 SR = 24000
 FILTER_BYTES_PER_SAMPLE = 87.86e6 / SR      # layer-boundary activation bytes of FilterNet
+FILTER_FLOPS_PER_SAMPLE = 2.483e9 / SR       # FilterNet FLOPs per 24 kHz output sample
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_* peak = fp32 vector peak
+
+
+def measured_filter_traffic(B, L):
+    """HBM bytes moved by one step's FilterNet launches, from the committed rocprofv3 PMC passes
+    (FETCH_SIZE / WRITE_SIZE, collected and corrected as MI355X_MICROARCH.md prescribes); only valid
+    for the workload it was measured on."""
+    p = os.path.join(ROOT, "profiles", "r01_filter_traffic_pmc.json")
+    if B == 64 and L == 96000 and os.path.exists(p):
+        return json.load(open(p)).get("traffic_bytes")
+    return None
 
 
 def build_generator(device):
@@ -142,9 +154,12 @@ def main():
                        "global_batch": world * B, "utterance_samples_24k": L, "index_vectors": args.index,
                        "parallelism": f"utterance-dp{world}", "x_realtime": audio_s / dt},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
-                         "kernel": "FilterNet Conv1d stack (all filter_net launches of one step, hipEvent-bracketed on the launch stream)",
-                         "algorithmic_bytes_per_launch": FILTER_BYTES_PER_SAMPLE * B * L},
+                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": measured_filter_traffic(B, L),
+                         "kernel": "FilterNet Conv1d stack = the filter_net launches of one step (fused ups.4+output kernels, conv3/igemm for the other levels), hipEvent pair on the launch stream",
+                         "algorithmic_bytes_per_launch": FILTER_BYTES_PER_SAMPLE * B * L,
+                         "launch_ms": t_filter * 1e3,
+                         "fp32_mfma_tflops": FILTER_FLOPS_PER_SAMPLE * B * L / t_filter / 1e12 if t_filter > 0 else None,
+                         "fp32_mfma_frac": FILTER_FLOPS_PER_SAMPLE * B * L / t_filter / 1e12 / FP32_MFMA_PEAK_TFLOPS if t_filter > 0 else None},
             "stage_ms_per_step": {k: v / args.steps for k, v in sorted(prof.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
