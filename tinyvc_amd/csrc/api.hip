@@ -126,50 +126,66 @@ struct Packer {
     }
 };
 
+// Real-DFT tables exploiting the symmetry about n = N/2 (cos even, sin odd; the periodic Hann window is
+// even too, so it stays folded into the matrices): each transform is two half-size real contractions.
+//   forward:  Re X[f] = sum_{n=1..960} c_n w[n] cos(2 pi f n/N) e[n],  e[n] = x[n] + x[N-n] (e[960] = x[960])
+//             Im X[f] = -sum_{n=1..959} w[n] sin(2 pi f n/N) o[n],     o[n] = x[n] - x[N-n]      (w[0] = 0)
+//   inverse:  E[n] = (1/N) sum_{f=0..960} c_f Re X[f] cos(2 pi f n/N),  O[n] = (2/N) sum_{f=1..959} Im X[f] sin(2 pi f n/N)
+//             x[n] = E[n] - O[n],  x[N-n] = E[n] + O[n]  (n = 1..959);  x[0] = E[0], x[960] = E[960]
 void build_dft_tables(Packer& pk, tvc_ctx* ctx) {
-    const int N = kNfft;
+    const int N = kNfft, Hn = N / 2;   // 1920, 960
     const double two_pi = 6.283185307179586476925286766559;
-    // forward: At[k = n][m], m = 2f -> cos * hann, 2f+1 -> -sin * hann   (torch.stft convention)
-    {
-        PackedW& pw = ctx->stft_dft;
-        pw.M = 2 * kBins;
-        pw.K = N;
-        pw.Mpad = pad_m(pw.M);
-        pw.Kpad = N;
-        pw.cin = N;
+    auto put = [&](PackedW& pw, int M, int K, std::vector<float>& At) {
+        pw.M = M;
+        pw.K = K;
+        pw.cin = K;
         pw.taps = 1;
-        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f), bias(pw.Mpad, 0.f);
-        for (int n = 0; n < N; ++n) {
+        std::vector<float> bias(pw.Mpad, 0.f);
+        pk.fix.push_back({&pw.At, pk.ab.put(At)});
+        pk.fix.push_back({&pw.bias, pk.ab.put(bias)});
+    };
+    auto ang = [&](long f, long n) { return two_pi * (double)((f * n) % N) / N; };
+    {   // forward real part: rows k = n-1 (n = 1..960), columns f = 0..960
+        PackedW& pw = ctx->stft_re;
+        pw.Mpad = pad_m(kBins);
+        pw.Kpad = Hn;
+        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f);
+        for (int n = 1; n <= Hn; ++n) {
             double hann = 0.5 - 0.5 * std::cos(two_pi * n / N);
-            for (int f = 0; f < kBins; ++f) {
-                double ang = two_pi * (double)(((long)f * n) % N) / N;
-                At[(size_t)n * pw.Mpad + 2 * f] = (float)(std::cos(ang) * hann);
-                At[(size_t)n * pw.Mpad + 2 * f + 1] = (float)(-std::sin(ang) * hann);
-            }
+            for (int f = 0; f < kBins; ++f) At[(size_t)(n - 1) * pw.Mpad + f] = (float)(std::cos(ang(f, n)) * hann);
         }
-        pk.fix.push_back({&pw.At, pk.ab.put(At)});
-        pk.fix.push_back({&pw.bias, pk.ab.put(bias)});
+        put(pw, kBins, Hn, At);
     }
-    // inverse (c2r, 'backward' 1/N norm): At[k][m = n]; k < 961: Re X_k, k >= 961: Im X_{k-961}
-    {
-        PackedW& pw = ctx->istft_dft;
-        pw.M = N;
-        pw.K = 2 * kBins;
-        pw.Mpad = pad_m(pw.M);
-        pw.Kpad = (pw.K + 15) / 16 * 16;
-        pw.cin = pw.K;
-        pw.taps = 1;
-        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f), bias(pw.Mpad, 0.f);
-        for (int f = 0; f < kBins; ++f) {
-            double c = (f == 0 || f == N / 2) ? 1.0 : 2.0;
-            for (int n = 0; n < N; ++n) {
-                double ang = two_pi * (double)(((long)f * n) % N) / N;
-                At[(size_t)f * pw.Mpad + n] = (float)(c * std::cos(ang) / N);
-                if (f != 0 && f != N / 2) At[(size_t)(kBins + f) * pw.Mpad + n] = (float)(-c * std::sin(ang) / N);
-            }
+    {   // forward imaginary part: rows k = n-1 (n = 1..959)
+        PackedW& pw = ctx->stft_im;
+        pw.Mpad = pad_m(kBins);
+        pw.Kpad = Hn;
+        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f);
+        for (int n = 1; n < Hn; ++n) {
+            double hann = 0.5 - 0.5 * std::cos(two_pi * n / N);
+            for (int f = 0; f < kBins; ++f) At[(size_t)(n - 1) * pw.Mpad + f] = (float)(-std::sin(ang(f, n)) * hann);
         }
-        pk.fix.push_back({&pw.At, pk.ab.put(At)});
-        pk.fix.push_back({&pw.bias, pk.ab.put(bias)});
+        put(pw, kBins, Hn - 1, At);
+    }
+    {   // inverse even part: rows k = f (0..960), columns n = 0..960
+        PackedW& pw = ctx->istft_e;
+        pw.Mpad = pad_m(kBins);
+        pw.Kpad = (kBins + 15) / 16 * 16;
+        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f);
+        for (int f = 0; f < kBins; ++f) {
+            double c = (f == 0 || f == Hn) ? 1.0 : 2.0;
+            for (int n = 0; n <= Hn; ++n) At[(size_t)f * pw.Mpad + n] = (float)(c * std::cos(ang(f, n)) / N);
+        }
+        put(pw, kBins, kBins, At);
+    }
+    {   // inverse odd part: rows k = f-1 (f = 1..959), columns m = n-1 (n = 1..959)
+        PackedW& pw = ctx->istft_o;
+        pw.Mpad = pad_m(Hn - 1);
+        pw.Kpad = Hn;
+        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f);
+        for (int f = 1; f < Hn; ++f)
+            for (int n = 1; n < Hn; ++n) At[(size_t)(f - 1) * pw.Mpad + (n - 1)] = (float)(2.0 * std::sin(ang(f, n)) / N);
+        put(pw, Hn - 1, Hn - 1, At);
     }
 }
 
@@ -205,6 +221,11 @@ int tvc_ctx_create(int hip_device, tvc_ctx** out) {
 void tvc_ctx_destroy(tvc_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (auto& r : ctx->regions) {
+        if (r.a) (void)hipEventDestroy(r.a);
+        if (r.b) (void)hipEventDestroy(r.b);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->const_arena) (void)hipFree(ctx->const_arena);
     delete ctx;
@@ -519,8 +540,8 @@ int tvc_profile_read(tvc_ctx* ctx, char* buf, size_t buf_bytes) {
                 }
             if (!found) agg.push_back({r.name, ms});
         }
-        if (r.a) (void)hipEventDestroy(r.a);
-        if (r.b) (void)hipEventDestroy(r.b);
+        if (r.a) ctx->event_pool.push_back(r.a);
+        if (r.b) ctx->event_pool.push_back(r.b);
     }
     ctx->regions.clear();
     std::string out;

@@ -210,10 +210,13 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
         angle = ang;
     }
     hipLaunchKernelGGL(noise_spec_kernel, dim3(grid_for((long)B * kBins * T)), dim3(256), 0, s, kern, angle, yri, (long)kBins * T, B);
-    {
-        LoadPlain ld{yri, 2 * kBins, T, (long)2 * kBins * T};
-        EpiFrames ep{frames, ncols};
-        igemm_launch(s, ctx->istft_dft.At, ctx->istft_dft.Mpad, ctx->istft_dft.Kpad, ncols, T, ld, ep);
+    {   // even part from the real halves (rows 0..960 of yri), then odd part from the imaginary halves of bins 1..959
+        LoadPlain le{yri, kBins, T, (long)2 * kBins * T};
+        EpiFramesPart<false> ee{frames, ncols};
+        igemm_launch(s, ctx->istft_e.At, ctx->istft_e.Mpad, ctx->istft_e.Kpad, ncols, T, le, ee);
+        LoadPlain lo{yri + (long)(kBins + 1) * T, kBins - 2, T, (long)2 * kBins * T};
+        EpiFramesPart<true> eo{frames, ncols};
+        igemm_launch(s, ctx->istft_o.At, ctx->istft_o.Mpad, ctx->istft_o.Kpad, ncols, T, lo, eo);
     }
     hipLaunchKernelGGL(noise_ola_kernel, dim3(grid_for((long)B * L)), dim3(256), 0, s, frames, source, B, T);
     return launch_check(ctx, "dsp");

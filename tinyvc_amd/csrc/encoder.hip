@@ -117,14 +117,18 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     float* nx = ws.get<float>((size_t)B * C2);
     ws.release(mk);
     if (dry) return 0;
-    hipLaunchKernelGGL((dwconv_ln_kernel<true>), dim3((T + 63) / 64, B), dim3(1024), 0, s, x, y, w.dw_w, w.dw_b, w.ln_g, w.ln_b, C, T, w.dilation);
+    {
+        hipLaunchKernelGGL((dwconv_ln_kernel<true>), dim3((T + 63) / 64, B), dim3(1024), 0, s, x, y, w.dw_w, w.dw_b, w.ln_g, w.ln_b, C, T, w.dilation);
+    }
     {
         LoadPlain ld{y, C, T, (long)C * T};
         EpiBias<ACT_GELU, false> ep{h, w.c2.bias, nullptr, C2, T, ncols, (long)C2 * T, 0};
         igemm_launch(s, w.c2.At, w.c2.Mpad, w.c2.Kpad, ncols, T, ld, ep);
     }
-    hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)B * C2 * 64)), dim3(256), 0, s, h, gx, (long)B * C2, T);
-    hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, s, gx, w.grn_g, nx, C2);
+    {
+        hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)B * C2 * 64)), dim3(256), 0, s, h, gx, (long)B * C2, T);
+        hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, s, gx, w.grn_g, nx, C2);
+    }
     {
         LoadScaled ld{h, nx, C2, T};
         EpiBias<ACT_NONE, true> ep{x, w.c3_bias_grn, x, C, T, ncols, (long)C * T, (long)C * T};

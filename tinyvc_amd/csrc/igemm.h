@@ -158,32 +158,22 @@ struct LoadConvCat17 {
     }
 };
 
-// STFT framing (spectrogram.py:12-13): column (b, t) is stft frame t+1 of the reflect-padded
-// waveform; k = sample within the 1920-sample frame.  The Hann window lives in A.
-struct LoadStftFrame {
-    const float* wav;  // [B][L]
-    int L;
+// A plain [K][ncols] operand matrix (column n contiguous along lanes): the folded STFT frames.
+struct LoadMatrix {
+    const float* x;
+    int K;
+    long ld;
     struct Ctx {
-        const float* wb;
-        int start;
+        const float* base;
         bool ok;
     };
-    __device__ __forceinline__ Ctx ctx(int n, int ncols, int Tt) const {
+    __device__ __forceinline__ Ctx ctx(int n, int ncols, int) const {
         Ctx c;
         c.ok = n < ncols;
-        int nn = c.ok ? n : 0;
-        int b = nn / Tt, t = nn - b * Tt;
-        c.wb = wav + (long)b * L;
-        c.start = (t + 1) * 480 - 960;
+        c.base = x + (c.ok ? n : 0);
         return c;
     }
-    __device__ __forceinline__ float get(const Ctx& c, int k) const {
-        if (!(c.ok && k < 1920)) return 0.f;
-        int pos = c.start + k;
-        if (pos < 0) pos = -pos;
-        if (pos >= L) pos = 2 * (L - 1) - pos;
-        return c.wb[pos];
-    }
+    __device__ __forceinline__ float get(const Ctx& c, int k) const { return (c.ok && k < K) ? c.base[k * ld] : 0.f; }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -271,26 +261,51 @@ struct EpiSumCond {
     }
 };
 
-// |STFT|: rows (2f, 2f+1) are (re, im) of bin f  -> spec[b][f][t]
-struct EpiStftMag {
+// |STFT| in two passes: pass 1 parks Re X in `spec`; pass 2 holds Im X in its accumulators and
+// overwrites spec with sqrt(re^2 + im^2).  Rows are bins.
+template <bool FINAL>
+struct EpiStftPart {
     float* spec;
     int T, ncols;
     __device__ __forceinline__ void store(int n, int m, const float v[4]) const {
         if (n >= ncols) return;
         int b = n / T, t = n - b * T;
-        int f = m >> 1;
-        if (f < 961) spec[((long)b * 961 + f) * T + t] = sqrtf(v[0] * v[0] + v[1] * v[1]);
-        if (f + 1 < 961) spec[((long)b * 961 + f + 1) * T + t] = sqrtf(v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (m + r < 961) {
+                float* p = spec + ((long)b * 961 + m + r) * T + t;
+                if (FINAL) {
+                    float re = *p;
+                    *p = sqrtf(re * re + v[r] * v[r]);
+                } else {
+                    *p = v[r];
+                }
+            }
     }
 };
 
-// inverse-DFT frames: frames[(b*T + t)][m .. m+3]  (m = sample within the 1920-sample frame)
-struct EpiFrames {
+// inverse real DFT frames, two passes: pass 1 writes E[n] (n = 0..960) into frames[col][n];
+// pass 2 holds O[n] (rows m = n-1, n = 1..959) and finishes x[n] = E - O, x[1920-n] = E + O in place.
+template <bool FINAL>
+struct EpiFramesPart {
     float* frames;
     int ncols;
     __device__ __forceinline__ void store(int n, int m, const float v[4]) const {
-        if (n >= ncols || m >= 1920) return;
-        *reinterpret_cast<float4*>(frames + (long)n * 1920 + m) = make_float4(v[0], v[1], v[2], v[3]);
+        if (n >= ncols) return;
+        float* fr = frames + (long)n * 1920;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (FINAL) {
+                int nn = m + r + 1;
+                if (nn <= 959) {
+                    float e = fr[nn];
+                    fr[nn] = e - v[r];
+                    fr[1920 - nn] = e + v[r];
+                }
+            } else if (m + r <= 960) {
+                fr[m + r] = v[r];
+            }
+        }
     }
 };
 

@@ -73,6 +73,7 @@ struct tvc_ctx {
     int device = 0;
     bool profiling = false;                   // tvc_profile_enable: hipEvent pairs around named regions
     std::vector<tvc_prof_region> regions;
+    std::vector<hipEvent_t> event_pool;       // recycled hipEvents: no hipEventCreate on the hot path
     bool enc_ready = false, dec_ready = false;  // which checkpoint groups tvc_finalize_weights packed
     char enc_missing[160] = {0}, dec_missing[160] = {0};
     std::map<std::string, tvc::HostTensor> host;  // staged checkpoint tensors
@@ -83,8 +84,8 @@ struct tvc_ctx {
     char err[512] = {0};
 
     // constant tables
-    tvc::PackedW stft_dft;   // A = windowed forward DFT [1920 -> 1922 interleaved re/im]
-    tvc::PackedW istft_dft;  // A = inverse real DFT [1922 (re|im) -> 1920], 1/N folded in
+    tvc::PackedW stft_re, stft_im;   // windowed forward real DFT, even/odd halves (see build_dft_tables)
+    tvc::PackedW istft_e, istft_o;   // inverse real DFT, even/odd halves, 1/N folded in
     const float* pitch_freq = nullptr;  // [512]
 
     // encoder
@@ -146,7 +147,15 @@ struct ProfScope {
         if (!c || !c->profiling || dry) return;
         tvc_prof_region r;
         r.name = name;
-        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        auto take = [&](hipEvent_t* e) {
+            if (!c->event_pool.empty()) {
+                *e = c->event_pool.back();
+                c->event_pool.pop_back();
+                return true;
+            }
+            return hipEventCreate(e) == hipSuccess;
+        };
+        if (!take(&r.a) || !take(&r.b)) return;
         (void)hipEventRecord(r.a, s);
         c->regions.push_back(r);
         idx = (int)c->regions.size() - 1;
