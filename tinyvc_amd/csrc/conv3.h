@@ -20,7 +20,8 @@ struct Conv3Tile {
     static constexpr int KC = 8, KS = 24;            // channels / k-rows per slab
     static constexpr int MAXD = 27;
     static constexpr int XROW = BN + 2 * MAXD + 2;   // LDS row stride of the halo tile
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static constexpr int NW = WM * WN, NTHR = NW * 64;
+    static_assert(NW == 4 || NW == 8 || NW == 12 || NW == 16, "4, 8, 12 or 16 waves per workgroup");
 };
 
 struct Conv3Args {
@@ -93,8 +94,8 @@ struct C3EpiFilmFused {
 };
 
 template <class TL, bool LRELU, class Epi, bool FILM = false>
-__global__ __launch_bounds__(256) void conv3_kernel(Conv3Args a, Epi ep) {
-    constexpr int BM = TL::BM, BN = TL::BN, TM = TL::TM, TN = TL::TN, KC = TL::KC, KS = TL::KS, XROW = TL::XROW;
+__global__ __launch_bounds__(TL::NTHR) void conv3_kernel(Conv3Args a, Epi ep) {
+    constexpr int BM = TL::BM, BN = TL::BN, TM = TL::TM, TN = TL::TN, KC = TL::KC, KS = TL::KS, XROW = TL::XROW, NTHR = TL::NTHR;
     __shared__ __attribute__((aligned(16))) float As[2][KS * BM];
     __shared__ __attribute__((aligned(16))) float Xs[2][KC * XROW];
 
@@ -120,15 +121,15 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Args a, Epi ep) {
     }
 
     constexpr int A_F4 = KS * BM / 4;
-    constexpr int A_PER = (A_F4 + 255) / 256;
-    constexpr int X_PER = (KC * XROW + 255) / 256;
+    constexpr int A_PER = (A_F4 + NTHR - 1) / NTHR;
+    constexpr int X_PER = (KC * XROW + NTHR - 1) / NTHR;
     float4 areg[A_PER];
     float xreg[X_PER];
     // staging map of this thread, fixed across slabs: element i -> (local channel r, staged column c)
     int xg[X_PER], xl[X_PER];
 #pragma unroll
     for (int i = 0; i < X_PER; ++i) {
-        int idx = tid + i * 256;
+        int idx = tid + i * NTHR;
         int r = idx / xw, c = idx - r * xw;
         int p = t0 - dil + c;
         p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
@@ -139,8 +140,8 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Args a, Epi ep) {
     auto load_slab = [&](int ci0) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            int idx = tid + i * 256;
-            if (A_F4 % 256 == 0 || idx < A_F4) {
+            int idx = tid + i * NTHR;
+            if (A_F4 % NTHR == 0 || idx < A_F4) {
                 int kk = idx / (BM / 4), c4 = idx - kk * (BM / 4);
                 areg[i] = *reinterpret_cast<const float4*>(a.At + (long)(ci0 * 3 + kk) * a.Mpad + m0 + c4 * 4);
             }
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Args a, Epi ep) {
     auto store_slab = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            int idx = tid + i * 256;
-            if (A_F4 % 256 == 0 || idx < A_F4) *reinterpret_cast<float4*>(&As[buf][idx * 4]) = areg[i];
+            int idx = tid + i * NTHR;
+            if (A_F4 % NTHR == 0 || idx < A_F4) *reinterpret_cast<float4*>(&As[buf][idx * 4]) = areg[i];
         }
 #pragma unroll
         for (int i = 0; i < X_PER; ++i)
@@ -204,8 +205,8 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Args a, Epi ep) {
         // LDS buffers are reused); results stay in registers next to the conv accumulators -----------------
         f32x16 asc[TM][TN], ash[TM][TN];
         constexpr int FK = 8;                          // cond channels per slab
-        constexpr int FA_F4 = FK * BM / 4, FA_PER = (FA_F4 + 255) / 256;
-        constexpr int FB_PER = (FK * BN + 255) / 256;
+        constexpr int FA_F4 = FK * BM / 4, FA_PER = (FA_F4 + NTHR - 1) / NTHR;
+        constexpr int FB_PER = (FK * BN + NTHR - 1) / NTHR;
         const float* cb = a.cond + (long)b * a.Ccond * len;
         auto film_phase = [&](const float* Wt, f32x16 (&out)[TM][TN]) {
 #pragma unroll
@@ -219,15 +220,15 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Args a, Epi ep) {
             auto fload = [&](int c0) {
 #pragma unroll
                 for (int i = 0; i < FA_PER; ++i) {
-                    int idx = tid + i * 256;
-                    if (FA_F4 % 256 == 0 || idx < FA_F4) {
+                    int idx = tid + i * NTHR;
+                    if (FA_F4 % NTHR == 0 || idx < FA_F4) {
                         int kk = idx / (BM / 4), c4 = idx - kk * (BM / 4);
                         fa[i] = *reinterpret_cast<const float4*>(Wt + (long)(c0 + kk) * a.Mpad + m0 + c4 * 4);
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < FB_PER; ++i) {
-                    int idx = tid + i * 256;
+                    int idx = tid + i * NTHR;
                     int r = idx / BN, c = idx - r * BN;
                     int t = t0 + c;
                     t = t > len - 1 ? len - 1 : t;
@@ -237,12 +238,12 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Args a, Epi ep) {
             auto fstore = [&](int buf) {
 #pragma unroll
                 for (int i = 0; i < FA_PER; ++i) {
-                    int idx = tid + i * 256;
-                    if (FA_F4 % 256 == 0 || idx < FA_F4) *reinterpret_cast<float4*>(&As[buf][idx * 4]) = fa[i];
+                    int idx = tid + i * NTHR;
+                    if (FA_F4 % NTHR == 0 || idx < FA_F4) *reinterpret_cast<float4*>(&As[buf][idx * 4]) = fa[i];
                 }
 #pragma unroll
                 for (int i = 0; i < FB_PER; ++i) {
-                    int idx = tid + i * 256;
+                    int idx = tid + i * NTHR;
                     if (idx < FK * BN) Xs[buf][idx] = fb[i];
                 }
             };
@@ -331,7 +332,7 @@ inline void conv3_launch_t(hipStream_t s, const float* At, int Mpad, const float
     a.dil = dil;
     a.tiles_per_utt = (len + TL::BN - 1) / TL::BN;
     dim3 g((unsigned)((Mpad / TL::BM) * a.tiles_per_utt * B));
-    hipLaunchKernelGGL((conv3_kernel<TL, LRELU, Epi, FILM>), g, dim3(256), 0, s, a, ep);
+    hipLaunchKernelGGL((conv3_kernel<TL, LRELU, Epi, FILM>), g, dim3(TL::NTHR), 0, s, a, ep);
 }
 
 // Tile choice: BM from Mpad; BN as wide as still yields enough workgroups to fill 256 CUs several times.
@@ -340,14 +341,43 @@ inline void conv3_launch(hipStream_t s, const float* At, int Mpad, const float* 
                          const FilmOps& f = FilmOps()) {
     constexpr long kEnough = 1536;
     auto blocks = [&](int BM, int BN) { return (long)(Mpad / BM) * ((len + BN - 1) / BN) * B; };
+#if TVC_W8 >= 3
+    using C128 = Conv3Tile<4, 4, 1, 1>;      // 128 x 128, 16 waves of 32 x 32
+    using C96x256 = Conv3Tile<1, 8, 3, 1>;   // 96 x 256, 8 waves of 96 x 32
+    using C64x256 = Conv3Tile<2, 8, 1, 1>;   // 64 x 256, 16 waves of 32 x 32
+#elif TVC_W8
+    using C128 = Conv3Tile<2, 4, 2, 1>;      // 128 x 128, 8 waves of 64 x 32
+    using C96x256 = Conv3Tile<1, 8, 3, 1>;   // 96 x 256, 8 waves of 96 x 32
+    using C64x256 = Conv3Tile<1, 8, 2, 1>;   // 64 x 256, 8 waves of 64 x 32
+#if TVC_W8 >= 2
+    using C96x128 = Conv3Tile<3, 4, 1, 1>;   // 96 x 128, 12 waves of 32 x 32
+    using C128x64 = Conv3Tile<4, 2, 1, 1>;   // 128 x 64, 8 waves of 32 x 32
+#else
+    using C96x128 = Conv3Tile<1, 4, 3, 1>;
+    using C128x64 = Conv3Tile<4, 1, 1, 2>;
+#endif
+#else
+    using C96x128 = Conv3Tile<1, 4, 3, 1>;
+    using C128x64 = Conv3Tile<4, 1, 1, 2>;
+    using C128 = Conv3Tile<2, 2, 2, 2>;
+    using C96x256 = Conv3Tile<1, 4, 3, 2>;
+    using C64x256 = Conv3Tile<1, 4, 2, 2>;
+#endif
     if (Mpad % 128 == 0) {
-        if (blocks(128, 128) >= kEnough) conv3_launch_t<Conv3Tile<2, 2, 2, 2>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);   // 128 x 128
-        else conv3_launch_t<Conv3Tile<4, 1, 1, 2>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                               // 128 x 64
+#ifndef TVC_BN96
+#define TVC_BN96 1
+#endif
+        // short levels (len = 400 for a 4 s utterance): 96-wide tiles split 400 samples into 5 tiles and the
+        // whole grid fits in one resident round, where 64-wide tiles need 7 tiles and a second, half-empty round
+        if (TVC_BN96 && blocks(128, 128) < kEnough && (len + 95) / 96 * 96 - len < (len + 63) / 64 * 64 - len + 64)
+            conv3_launch_t<Conv3Tile<4, 3, 1, 1>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                 // 128 x 96
+        else if (blocks(128, 128) >= kEnough) conv3_launch_t<C128, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);   // 128 x 128
+        else conv3_launch_t<C128x64, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                               // 128 x 64
     } else if (Mpad % 96 == 0) {
-        if (blocks(96, 256) >= kEnough) conv3_launch_t<Conv3Tile<1, 4, 3, 2>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);    // 96 x 256
-        else conv3_launch_t<Conv3Tile<1, 4, 3, 1>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                               // 96 x 128
+        if (blocks(96, 256) >= kEnough) conv3_launch_t<C96x256, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);    // 96 x 256
+        else conv3_launch_t<C96x128, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                               // 96 x 128
     } else if (Mpad % 64 == 0) {
-        conv3_launch_t<Conv3Tile<1, 4, 2, 2>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                 // 64 x 256
+        conv3_launch_t<C64x256, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                 // 64 x 256
     } else {
         conv3_launch_t<Conv3Tile<1, 4, 1, 2>, LRELU, Epi, FILM>(s, At, Mpad, x, B, Cin, len, dil, ep, f);                 // 32 x 256
     }

@@ -28,7 +28,8 @@ template <int WM_, int WN_, int TM_, int TN_>
 struct Tile {
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static constexpr int NW = WM * WN, NTHR = NW * 64;     // 4 or 8 waves per workgroup
+    static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves per workgroup");
 };
 
 // ------------------------------------------------------------------------------------------
@@ -311,11 +312,11 @@ struct EpiFramesPart {
 
 // ------------------------------------------------------------------------------------------
 template <class TL, class Loader, class Epi>
-__global__ __launch_bounds__(256) void igemm_kernel(const float* __restrict__ At, int Mpad, int Kpad,
+__global__ __launch_bounds__(TL::NTHR) void igemm_kernel(const float* __restrict__ At, int Mpad, int Kpad,
                                                     int ncols, int T, Loader ld, Epi ep) {
     constexpr int BM = TL::BM, BN = TL::BN, BK = TL::BK;
-    constexpr int TM = TL::TM, TN = TL::TN;
-    static_assert(BN <= 256, "one column per thread");
+    constexpr int TM = TL::TM, TN = TL::TN, NTHR = TL::NTHR;
+    static_assert(BN <= NTHR && NTHR % BN == 0 && BK % (NTHR / BN) == 0, "one column per thread");
     __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
 
@@ -329,8 +330,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const float* __restrict__ At
     const int n0 = (blockIdx.x / mtiles) * BN;
 
     constexpr int A_F4 = BK * BM / 4;                 // float4s per A slab
-    constexpr int A_PER = (A_F4 + 255) / 256;
-    constexpr int B_RSTEP = 256 / BN;                 // thread owns column tid % BN, rows brow0 + j*B_RSTEP
+    constexpr int A_PER = (A_F4 + NTHR - 1) / NTHR;
+    constexpr int B_RSTEP = NTHR / BN;                 // thread owns column tid % BN, rows brow0 + j*B_RSTEP
     constexpr int B_ROWS_PER = BK / B_RSTEP;
 
     const int bcol = tid % BN;
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const float* __restrict__ At
     auto load_slab = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            int idx = tid + i * 256;
-            if (A_F4 % 256 == 0 || idx < A_F4) {
+            int idx = tid + i * NTHR;
+            if (A_F4 % NTHR == 0 || idx < A_F4) {
                 int kk = idx / (BM / 4), c4 = idx - kk * (BM / 4);
                 areg[i] = *reinterpret_cast<const float4*>(At + (long)(k0 + kk) * Mpad + m0 + c4 * 4);
             }
@@ -363,8 +364,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const float* __restrict__ At
     auto store_slab = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            int idx = tid + i * 256;
-            if (A_F4 % 256 == 0 || idx < A_F4) *reinterpret_cast<float4*>(&As[buf][idx * 4]) = areg[i];
+            int idx = tid + i * NTHR;
+            if (A_F4 % NTHR == 0 || idx < A_F4) *reinterpret_cast<float4*>(&As[buf][idx * 4]) = areg[i];
         }
 #pragma unroll
         for (int j = 0; j < B_ROWS_PER; ++j) Bs[buf][(brow0 + j * B_RSTEP) * BN + bcol] = breg[j];
@@ -420,7 +421,7 @@ template <class TL, class Loader, class Epi>
 inline void igemm_launch_t(hipStream_t s, const float* At, int Mpad, int Kpad, int ncols, int T,
                            const Loader& ld, const Epi& ep) {
     dim3 g((unsigned)((Mpad / TL::BM) * ((ncols + TL::BN - 1) / TL::BN)));
-    hipLaunchKernelGGL((igemm_kernel<TL, Loader, Epi>), g, dim3(256), 0, s, At, Mpad, Kpad, ncols, T, ld, ep);
+    hipLaunchKernelGGL((igemm_kernel<TL, Loader, Epi>), g, dim3(TL::NTHR), 0, s, At, Mpad, Kpad, ncols, T, ld, ep);
 }
 
 inline long igemm_blocks(int Mpad, int ncols, int BM, int BN) { return (long)(Mpad / BM) * ((ncols + BN - 1) / BN); }
@@ -430,14 +431,28 @@ inline void igemm_launch(hipStream_t s, const float* At, int Mpad, int Kpad, int
                          const Loader& ld, const Epi& ep) {
     if (ncols <= 0) return;
     constexpr long kEnough = 1536;   // ~6 workgroups per CU
+#ifndef TVC_W8
+#define TVC_W8 2                     // many-wave workgroups with small per-wave tiles (<= 32 accumulator registers,
+                                     // 8 or 12 waves): measured 10-30 % faster than 4 waves x 64 accumulators
+#endif
+#if TVC_W8 >= 3
+    using T128 = Tile<4, 4, 1, 1>;   // 128 x 128, 16 waves of 32 x 32
+    using T64x256 = Tile<2, 8, 1, 1>;
+#elif TVC_W8
+    using T128 = Tile<2, 4, 2, 1>;   // 128 x 128, wave = 64 x 32
+    using T64x256 = Tile<1, 8, 2, 1>;
+#else
+    using T128 = Tile<2, 2, 2, 2>;   // 128 x 128, wave = 64 x 64
+    using T64x256 = Tile<1, 4, 2, 2>;
+#endif
     if (Mpad % 128 == 0) {
-        if (igemm_blocks(Mpad, ncols, 128, 128) >= kEnough) igemm_launch_t<Tile<2, 2, 2, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
+        if (igemm_blocks(Mpad, ncols, 128, 128) >= kEnough) igemm_launch_t<T128>(s, At, Mpad, Kpad, ncols, T, ld, ep);
         else if (igemm_blocks(Mpad, ncols, 64, 128) >= kEnough) igemm_launch_t<Tile<2, 2, 1, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
         else igemm_launch_t<Tile<2, 2, 1, 1>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
     } else if (Mpad % 96 == 0) {
         igemm_launch_t<Tile<1, 4, 3, 1>>(s, At, Mpad, Kpad, ncols, T, ld, ep);   // 96 x 128
     } else if (Mpad % 64 == 0) {
-        if (igemm_blocks(Mpad, ncols, 64, 256) >= kEnough) igemm_launch_t<Tile<1, 4, 2, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
+        if (igemm_blocks(Mpad, ncols, 64, 256) >= kEnough) igemm_launch_t<T64x256>(s, At, Mpad, Kpad, ncols, T, ld, ep);
         else if (igemm_blocks(Mpad, ncols, 64, 128) >= kEnough) igemm_launch_t<Tile<2, 2, 1, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
         else igemm_launch_t<Tile<2, 2, 1, 1>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
     } else {

@@ -15,6 +15,12 @@
 namespace tvc {
 
 constexpr int KD = kSslDim;  // 768
+#ifndef KNN_BK
+#define KNN_BK 16      // K-slab depth of the similarity GEMM (deeper slabs cost occupancy: measured slower)
+#endif
+#ifndef KNN_WAVES
+#define KNN_WAVES 8    // waves per workgroup: 8 -> each wave owns 64 x 32 (32 accumulator registers)
+#endif
 
 static inline int64_t npad128(int64_t N) { return (N + 127) / 128 * 128; }
 
@@ -82,17 +88,18 @@ struct Top4 {
 };
 
 // grid = qtiles * nsplit ; workgroup = 128 queries x (tiles_per_split index tiles of 128)
-static __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __restrict__ normT, long Npad, int N,
+static __global__ __launch_bounds__(KNN_WAVES * 64) void knn_topk_kernel(const float* __restrict__ normT, long Npad, int N,
                                                               const float* __restrict__ qn, int ncols, int T,
                                                               int nsplit, int tiles_per_split,
                                                               float* __restrict__ cand_v, int* __restrict__ cand_i) {
-    constexpr int BM = 128, BN = 128, BK = 16, TM = 2, TN = 2;
+    constexpr int BM = 128, BN = 128, BK = KNN_BK, TM = 2, TN = KNN_WAVES == 8 ? 1 : 2;
+    constexpr int NTHR = KNN_WAVES * 64, BRS = NTHR / 128;   // B staging: thread owns column tid % 128, rows tid / 128 + BRS * j
     __shared__ __attribute__((aligned(16))) float smem[BK * BM + BK * BN];
     float* As = smem;
     float* Bs = smem + BK * BM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = KNN_WAVES == 8 ? wave >> 2 : wave >> 1, wn = KNN_WAVES == 8 ? wave & 3 : wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
     const int split = blockIdx.x % nsplit;
     const int qtile = blockIdx.x / nsplit;
@@ -119,24 +126,25 @@ static __global__ __launch_bounds__(256) void knn_topk_kernel(const float* __res
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        float4 areg[2];
-        float breg[8];
+        constexpr int AP = BK * BM / 4 / NTHR, BP = BK * BN / NTHR;   // per-thread float4 / float staging counts
+        float4 areg[AP];
+        float breg[BP];
         auto load_slab = [&](int k0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int idx = tid + i * 256;
+            for (int i = 0; i < AP; ++i) {
+                int idx = tid + i * NTHR;
                 int kk = idx >> 5, c4 = idx & 31;
                 areg[i] = *reinterpret_cast<const float4*>(normT + (long)(k0 + kk) * Npad + m0 + c4 * 4);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) breg[j] = ld.get(col, k0 + brow0 + 2 * j);
+            for (int j = 0; j < BP; ++j) breg[j] = ld.get(col, k0 + brow0 + BRS * j);
         };
         load_slab(0);
         for (int kt = 0; kt < KD / BK; ++kt) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(As + (tid + i * 256) * 4) = areg[i];
+            for (int i = 0; i < AP; ++i) *reinterpret_cast<float4*>(As + (tid + i * NTHR) * 4) = areg[i];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Bs[(brow0 + 2 * j) * BN + (tid & 127)] = breg[j];
+            for (int j = 0; j < BP; ++j) Bs[(brow0 + BRS * j) * BN + (tid & 127)] = breg[j];
             __syncthreads();
             if (kt + 1 < KD / BK) load_slab((kt + 1) * BK);
 #pragma unroll
@@ -269,7 +277,7 @@ int run_knn(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, con
     if (dry) return 0;
     if (N > 0x7fffff00L) return fail(ctx, TVC_ERR_ARG, "index too large");
     hipLaunchKernelGGL(query_normalize_kernel, dim3((ncols + 255) / 256), dim3(256), 0, s, src, qn, B, T);
-    hipLaunchKernelGGL(knn_topk_kernel, dim3((unsigned)(qtiles * nsplit)), dim3(256), 0, s, prepared, Npad, (int)N, qn,
+    hipLaunchKernelGGL(knn_topk_kernel, dim3((unsigned)(qtiles * nsplit)), dim3(KNN_WAVES * 64), 0, s, prepared, Npad, (int)N, qn,
                        ncols, T, nsplit, tps, cv, ci);
     hipLaunchKernelGGL(knn_merge_gather_kernel, dim3((ncols + 31) / 32), dim3(256), 0, s, cv, ci, nsplit, ncols, T,
                        prepared + (size_t)KD * Npad, out, idx_out);
