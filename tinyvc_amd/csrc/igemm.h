@@ -29,7 +29,7 @@ struct Tile {
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16;
     static constexpr int NW = WM * WN, NTHR = NW * 64;     // 4 or 8 waves per workgroup
-    static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves per workgroup");
+    static_assert(NW == 4 || NW == 8 || NW == 12 || NW == 16, "4, 8, 12 or 16 waves per workgroup");
 };
 
 // ------------------------------------------------------------------------------------------
@@ -316,7 +316,9 @@ __global__ __launch_bounds__(TL::NTHR) void igemm_kernel(const float* __restrict
                                                     int ncols, int T, Loader ld, Epi ep) {
     constexpr int BM = TL::BM, BN = TL::BN, BK = TL::BK;
     constexpr int TM = TL::TM, TN = TL::TN, NTHR = TL::NTHR;
-    static_assert(BN <= NTHR && NTHR % BN == 0 && BK % (NTHR / BN) == 0, "one column per thread");
+    // B staging uses the first B_THR threads: the largest multiple of BN whose row step divides BK
+    constexpr int B_THR = (BK % (NTHR / BN) == 0 && NTHR % BN == 0) ? NTHR : (NTHR >= 4 * BN ? 4 * BN : (NTHR >= 2 * BN ? 2 * BN : BN));
+    static_assert(BN <= NTHR && B_THR % BN == 0 && BK % (B_THR / BN) == 0, "one column per staging thread");
     __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
 
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(TL::NTHR) void igemm_kernel(const float* __restrict
 
     constexpr int A_F4 = BK * BM / 4;                 // float4s per A slab
     constexpr int A_PER = (A_F4 + NTHR - 1) / NTHR;
-    constexpr int B_RSTEP = NTHR / BN;                 // thread owns column tid % BN, rows brow0 + j*B_RSTEP
+    constexpr int B_RSTEP = B_THR / BN;                 // thread owns column tid % BN, rows brow0 + j*B_RSTEP
     constexpr int B_ROWS_PER = BK / B_RSTEP;
 
     const int bcol = tid % BN;
@@ -358,8 +360,10 @@ __global__ __launch_bounds__(TL::NTHR) void igemm_kernel(const float* __restrict
                 areg[i] = *reinterpret_cast<const float4*>(At + (long)(k0 + kk) * Mpad + m0 + c4 * 4);
             }
         }
+        if (B_THR == NTHR || tid < B_THR) {
 #pragma unroll
-        for (int j = 0; j < B_ROWS_PER; ++j) breg[j] = ld.get(lc, k0 + brow0 + j * B_RSTEP);
+            for (int j = 0; j < B_ROWS_PER; ++j) breg[j] = ld.get(lc, k0 + brow0 + j * B_RSTEP);
+        }
     };
     auto store_slab = [&](int buf) {
 #pragma unroll
@@ -367,8 +371,10 @@ __global__ __launch_bounds__(TL::NTHR) void igemm_kernel(const float* __restrict
             int idx = tid + i * NTHR;
             if (A_F4 % NTHR == 0 || idx < A_F4) *reinterpret_cast<float4*>(&As[buf][idx * 4]) = areg[i];
         }
+        if (B_THR == NTHR || tid < B_THR) {
 #pragma unroll
-        for (int j = 0; j < B_ROWS_PER; ++j) Bs[buf][(brow0 + j * B_RSTEP) * BN + bcol] = breg[j];
+            for (int j = 0; j < B_ROWS_PER; ++j) Bs[buf][(brow0 + j * B_RSTEP) * BN + bcol] = breg[j];
+        }
     };
 
     const int nk = Kpad / BK;
@@ -450,7 +456,14 @@ inline void igemm_launch(hipStream_t s, const float* At, int Mpad, int Kpad, int
         else if (igemm_blocks(Mpad, ncols, 64, 128) >= kEnough) igemm_launch_t<Tile<2, 2, 1, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
         else igemm_launch_t<Tile<2, 2, 1, 1>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
     } else if (Mpad % 96 == 0) {
+#ifndef TVC_IG12
+#define TVC_IG12 1
+#endif
+#if TVC_IG12
+        igemm_launch_t<Tile<3, 4, 1, 1>>(s, At, Mpad, Kpad, ncols, T, ld, ep);   // 96 x 128, 12 waves of 32 x 32
+#else
         igemm_launch_t<Tile<1, 4, 3, 1>>(s, At, Mpad, Kpad, ncols, T, ld, ep);   // 96 x 128
+#endif
     } else if (Mpad % 64 == 0) {
         if (igemm_blocks(Mpad, ncols, 64, 256) >= kEnough) igemm_launch_t<T64x256>(s, At, Mpad, Kpad, ncols, T, ld, ep);
         else if (igemm_blocks(Mpad, ncols, 64, 128) >= kEnough) igemm_launch_t<Tile<2, 2, 1, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
