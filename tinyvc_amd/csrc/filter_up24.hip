@@ -76,7 +76,9 @@ __device__ __forceinline__ void conv_load16(ConvOps<CIN, TAPS>& o, const float* 
 
 template <int CIN, int TAPS, bool LRELU>
 __device__ __forceinline__ void conv_mma16(f32x4 (&acc)[2], const ConvOps<CIN, TAPS>& o) {
+#if !defined(UP24_NOPRELOAD) || !UP24_NOPRELOAD
     __builtin_amdgcn_sched_barrier(0);   // keep the operand fetch block above, the MFMA block below
+#endif
 #pragma unroll
     for (int s = 0; s < ConvOps<CIN, TAPS>::NS; ++s) {
         float b = o.b[s];

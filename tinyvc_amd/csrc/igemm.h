@@ -441,6 +441,14 @@ inline void igemm_launch(hipStream_t s, const float* At, int Mpad, int Kpad, int
 #define TVC_W8 2                     // many-wave workgroups with small per-wave tiles (<= 32 accumulator registers,
                                      // 8 or 12 waves): measured 10-30 % faster than 4 waves x 64 accumulators
 #endif
+#ifndef TVC_IG64
+#define TVC_IG64 0   // 8-wave 64 x 128 measured 8 % slower than 4 waves of 32 x 64 on the DFT GEMMs
+#endif
+#if TVC_IG64
+    using T64x128 = Tile<2, 4, 1, 1>;   // 64 x 128, 8 waves of 32 x 32
+#else
+    using T64x128 = Tile<2, 2, 1, 2>;   // 64 x 128, 4 waves of 32 x 64
+#endif
 #if TVC_W8 >= 3
     using T128 = Tile<4, 4, 1, 1>;   // 128 x 128, 16 waves of 32 x 32
     using T64x256 = Tile<2, 8, 1, 1>;
@@ -453,7 +461,7 @@ inline void igemm_launch(hipStream_t s, const float* At, int Mpad, int Kpad, int
 #endif
     if (Mpad % 128 == 0) {
         if (igemm_blocks(Mpad, ncols, 128, 128) >= kEnough) igemm_launch_t<T128>(s, At, Mpad, Kpad, ncols, T, ld, ep);
-        else if (igemm_blocks(Mpad, ncols, 64, 128) >= kEnough) igemm_launch_t<Tile<2, 2, 1, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
+        else if (igemm_blocks(Mpad, ncols, 64, 128) >= kEnough) igemm_launch_t<T64x128>(s, At, Mpad, Kpad, ncols, T, ld, ep);
         else igemm_launch_t<Tile<2, 2, 1, 1>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
     } else if (Mpad % 96 == 0) {
 #ifndef TVC_IG12
@@ -466,7 +474,7 @@ inline void igemm_launch(hipStream_t s, const float* At, int Mpad, int Kpad, int
 #endif
     } else if (Mpad % 64 == 0) {
         if (igemm_blocks(Mpad, ncols, 64, 256) >= kEnough) igemm_launch_t<T64x256>(s, At, Mpad, Kpad, ncols, T, ld, ep);
-        else if (igemm_blocks(Mpad, ncols, 64, 128) >= kEnough) igemm_launch_t<Tile<2, 2, 1, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
+        else if (igemm_blocks(Mpad, ncols, 64, 128) >= kEnough) igemm_launch_t<T64x128>(s, At, Mpad, Kpad, ncols, T, ld, ep);
         else igemm_launch_t<Tile<2, 2, 1, 1>>(s, At, Mpad, Kpad, ncols, T, ld, ep);
     } else {
         igemm_launch_t<Tile<1, 4, 1, 2>>(s, At, Mpad, Kpad, ncols, T, ld, ep);   // 32 x 256
