@@ -1,0 +1,97 @@
+"""Edge cases and full-size properties of the HIP path (MI355X): shortest legal inputs, odd frame
+counts, a long utterance with a large index, and size-independent invariants at the bench size."""
+import pytest
+import torch
+
+from helpers import rms, state_dicts
+from oracle import ref_cpu as R
+from tinyvc_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gen():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from tinyvc_amd.module.infer import Generator
+    from tinyvc_amd.module.tinyvc import Decoder, Encoder
+    enc_sd, dec_sd = state_dicts(0)
+    enc, dec = Encoder(), Decoder()
+    enc.load_state_dict(enc_sd)
+    dec.load_state_dict(dec_sd)
+    return Generator(enc, dec).to(DEV)
+
+
+@pytest.mark.parametrize("frames,batch", [(3, 1), (4, 2), (5, 1), (7, 3), (33, 2), (61, 1)])
+def test_short_and_odd_lengths_match_oracle(gen, frames, batch):
+    """torch.stft's reflect padding needs L > 960, so T = 3 (1440 samples) is the shortest legal input."""
+    enc_sd, dec_sd = state_dicts(0)
+    L = frames * 480 - 17                       # ragged: autopad brings it back to frames * 480
+    wf = synth.synth_wave(batch, L, seed=300 + frames)
+    tgt = synth.synth_index(97, seed=frames)
+    angle = synth.synth_angle(batch, frames, 70 + frames)
+    ref = R.convert(enc_sd, dec_sd, wf, tgt, 0.5, angle)
+    out = gen.convert(wf.to(DEV), tgt.to(DEV), 0.5, noise_angle=angle.to(DEV))
+    assert out.shape == ref.shape == (batch, frames * 480)
+    d = rms(out.cpu() - ref)
+    print(f"[edge] T={frames} B={batch}: rms diff {d:.3e}")
+    assert d <= 1e-4
+
+
+def test_too_short_input_is_rejected_like_torch_stft(gen):
+    from tinyvc_amd._lib import TinyVCError
+    with pytest.raises(TinyVCError):
+        gen.convert(torch.zeros(1, 960, device=DEV), synth.synth_index(16, seed=1).to(DEV), 0.0)
+
+
+def test_long_utterance_large_index(gen):
+    """20 s utterance (T = 1000) against a 20 000-vector index: staged comparison with the oracle.
+    The waveform gate is looser here: 1000 frames of f0 integrate fp32-ulp differences into phase."""
+    enc_sd, dec_sd = state_dicts(0)
+    wf = synth.synth_wave(1, 480000, seed=900)
+    tgt = synth.synth_index(20000, seed=901)
+    angle = synth.synth_angle(1, 1000, 902)
+    st = R.convert(enc_sd, dec_sd, wf, tgt, 0.0, angle, return_stages=True)
+    from tinyvc_amd.module import utils
+    from tinyvc_amd.module.tinyvc import match_features
+    w = wf.to(DEV)
+    spec = utils.spectrogram(w)
+    assert rms(spec.cpu() - st["spec"]) / rms(st["spec"]) < 2e-6
+    ssl, f0 = gen.encoder.infer(spec)
+    assert rms(ssl.cpu() - st["ssl"]) / rms(st["ssl"]) < 2e-5
+    m, idx = match_features(st["ssl"].to(DEV), tgt.to(DEV), return_indices=True)
+    _o, oidx, sims = R.match_features(st["ssl"], tgt, return_indices=True)
+    top = torch.topk(sims.double(), 5, dim=2).values
+    decidable = (top[..., :-1] - top[..., 1:]).min(dim=2).values > 1e-5
+    assert decidable.float().mean() > 0.9
+    assert torch.equal(idx.cpu()[decidable], oidx[decidable])
+    wave = gen.decoder.infer(st["matched"].to(DEV), st["f0s"].to(DEV), st["energy"].to(DEV), noise_angle=angle.to(DEV))
+    d = rms(wave.cpu() - st["wave"])
+    print(f"[edge] 20 s decoder (oracle inputs): rms diff {d:.3e}")
+    assert d <= 1e-5
+    full = gen.convert(w, tgt.to(DEV), 0.0, noise_angle=angle.to(DEV))
+    d2 = rms(full.cpu() - st["wave"])
+    print(f"[edge] 20 s end to end: rms diff {d2:.3e}")
+    assert d2 <= 5e-4
+
+
+def test_full_bench_size_properties(gen):
+    """BASELINE configs[1] size (64 x 4 s, 10 k index): invariants that need no oracle run."""
+    wf = synth.synth_wave(64, 96000, seed=100).to(DEV)
+    tgt = synth.synth_index(10000, seed=4).to(DEV)
+    angle = synth.synth_angle(64, 200, 5).to(DEV)
+    out = gen.convert(wf, tgt, 0.0, noise_angle=angle)
+    assert out.shape == (64, 96000) and torch.isfinite(out).all()
+    again = gen.convert(wf, tgt, 0.0, noise_angle=angle)
+    assert torch.equal(out, again)                                     # idempotent / deterministic
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(0)).to(DEV)
+    outp = gen.convert(wf[perm], tgt, 0.0, noise_angle=angle[perm])
+    assert torch.equal(outp, out[perm])                                # utterances do not interact
+    sub = gen.convert(wf[5:9], tgt, 0.0, noise_angle=angle[5:9])
+    assert torch.equal(sub, out[5:9])                                  # batch-size invariant
+    # kNN self-consistency at size: every index vector's nearest neighbour in the index is itself
+    from tinyvc_amd.module.tinyvc import match_features
+    q = tgt[:, :, :512].contiguous()
+    _m, idx = match_features(q, tgt, return_indices=True)
+    assert torch.equal(idx[0, :, 0].cpu(), torch.arange(512))
