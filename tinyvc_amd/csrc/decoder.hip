@@ -1,11 +1,16 @@
 // Source-filter decoder (decoder.py:24-266): SourceNet, additive harmonic oscillator, filtered-noise
 // iSTFT, and the FilterNet U-Net.
 #include "conv3.h"
+#include "conv3m48.h"
 #include "igemm.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
 
 namespace tvc {
+
+#ifndef TVC_USE_C48
+#define TVC_USE_C48 1
+#endif
 
 // =================================================================================================
 // Harmonic oscillator (decoder.py:24-54).  The phase of harmonic m is the running sum over the whole
@@ -272,9 +277,17 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 EpiBias<ACT_NONE, false> ep{res, d.res.bias, nullptr, d.cout, len, nc, (long)d.cout * len, 0};
                 igemm_launch(s, d.res.At, d.res.Mpad, d.res.Kpad, nc, len, ld, ep);
             }
-            conv3_launch<true>(s, d.c1.At, d.c1.Mpad, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
-            conv3_launch<true>(s, d.c2.At, d.c2.Mpad, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
-            conv3_launch<true>(s, d.c3.At, d.c3.Mpad, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
+            if (d.cin == 48 && TVC_USE_C48) {   // 48 = 3 x 16: the 16x16x4 kernel has no row padding
+                conv3m48_launch<true>(s, d.c1.At, d.c1.Mpad, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
+                conv3m48_launch<true>(s, d.c2.At, d.c2.Mpad, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
+            } else {
+                conv3_launch<true>(s, d.c1.At, d.c1.Mpad, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
+                conv3_launch<true>(s, d.c2.At, d.c2.Mpad, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
+            }
+            if (d.cout == 48 && TVC_USE_C48)
+                conv3m48_launch<true>(s, d.c3.At, d.c3.Mpad, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
+            else
+                conv3_launch<true>(s, d.c3.At, d.c3.Mpad, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
         }
         ws.release(mk);
     }
@@ -297,7 +310,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         const float* cond = skip[4 - i];
         size_t mk = ws.mark();
         float* xu = ws.get<float>((size_t)B * C * lo);
-        float* film = (C < 96 && C != 24) ? ws.get<float>((size_t)B * 2 * C * lo) : nullptr;
+        float* film = (C < 96 && C != 24 && !(C == 48 && TVC_USE_C48)) ? ws.get<float>((size_t)B * 2 * C * lo) : nullptr;
         float* h = ws.get<float>((size_t)B * C * lo);
         float* x1 = ws.get<float>((size_t)B * C * lo);
         if (!dry && C == 24) {
@@ -319,6 +332,14 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 float* xout = half ? xu : x1;  // 2nd half writes over xu (its input and residual are x1)
                 const PackedW& wsc = half ? u.sc2 : u.sc1;
                 const PackedW& wsh = half ? u.sh2 : u.sh1;
+                if (C == 48 && TVC_USE_C48) {
+                    // 48-channel level on 16x16x4 tiles (no row padding), FiLM and residual fused
+                    conv3m48_launch<true>(s, ca.At, ca.Mpad, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo});
+                    conv3m48_launch<true, C3EpiFilmFused, true>(s, cb.At, cb.Mpad, h, B, C, lo, db,
+                                                                C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
+                                                                FilmOps{wsc.At, wsh.At, cond, C});
+                    continue;
+                }
                 conv3_launch<true>(s, ca.At, ca.Mpad, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo});
                 if (C >= 96) {
                     // second conv with FiLM(cond) and the residual fused: scale/shift never touch HBM
