@@ -33,6 +33,9 @@ struct Conv3Args {
     const float* sh_At;
     const float* cond;
     int Ccond;
+    // conv3m48.h only: optional second input tensor for channels [split, Cin), and the number of At rows
+    const float* x2 = nullptr;
+    int split = 0, Krows = 0;
 };
 
 // Epilogue interface: store(b, t, m, v[4]) for 4 consecutive channels m..m+3 at (b, t); t < len guaranteed.

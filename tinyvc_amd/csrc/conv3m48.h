@@ -9,14 +9,17 @@
 // quads, so FiLM's scale/shift (two 1x1 contractions over the cond tile) fit in registers beside the conv.
 #pragma once
 #include "conv3.h"
+#include "tvc_common.h"
 
 namespace tvc {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int NW_, int TN_>
+template <int NW_, int TN_, int MT_ = 3>
 struct C48Tile {
-    static constexpr int NW = NW_, TN = TN_, BM = 48, BN = NW * TN * 16, NTHR = NW * 64;
+    static constexpr int NW = NW_, TN = TN_, MT = MT_, BMV = MT_ * 16;          // BMV = valid output rows (48 or 32)
+    static constexpr int BM = BMV % 32 == 16 ? BMV : BMV + 16;                   // LDS weight row stride, = 16 (mod 32)
+    static constexpr int BN = NW * TN * 16, NTHR = NW * 64;
     static constexpr int KC = 8, KS = 24, MAXD = 27;
     static constexpr int XROW = (BN + 2 * MAXD + 31) / 32 * 32 + 16;   // = 16 (mod 32)
     static constexpr int FROW = BN + 16;                               // FiLM cond tile row stride, = 16 (mod 32)
@@ -25,7 +28,7 @@ struct C48Tile {
 
 template <class TL, bool LRELU, class Epi, bool FILM>
 __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep) {
-    constexpr int BM = TL::BM, BN = TL::BN, TN = TL::TN, KC = TL::KC, KS = TL::KS, XROW = TL::XROW, NTHR = TL::NTHR;
+    constexpr int BM = TL::BM, BMV = TL::BMV, MT = TL::MT, BN = TL::BN, TN = TL::TN, KC = TL::KC, KS = TL::KS, XROW = TL::XROW, NTHR = TL::NTHR;
     constexpr int XBUF = KC * XROW > 8 * TL::FROW ? KC * XROW : 8 * TL::FROW;
     __shared__ __attribute__((aligned(16))) float As[2][KS * BM];
     __shared__ __attribute__((aligned(16))) float Xs[2][XBUF];
@@ -36,37 +39,44 @@ __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep)
     const int t0 = (blockIdx.x - b * a.tiles_per_utt) * BN;
     const int len = a.len, dil = a.dil;
     const int xw = BN + 2 * dil;
-    const float* xb = a.x + (long)b * a.Cin * len;
+    const float* xb = a.x + (long)b * a.split * len;
     const int ncol0 = wave * TN * 16;                 // this wave's first column in the tile
 
-    // A staging: 24 rows x 48 floats = 288 float4 per slab; LDS row = tap*8 + ci_local
-    constexpr int A_F4 = KS * BM / 4, A_PER = (A_F4 + NTHR - 1) / NTHR;
+    // A staging: 24 rows x BMV floats per slab; LDS row = tap*8 + ci_local, row stride BM
+    constexpr int A_F4 = KS * BMV / 4, A_PER = (A_F4 + NTHR - 1) / NTHR;
     constexpr int X_PER = (KC * XROW + NTHR - 1) / NTHR;
     float4 areg[A_PER];
     float xreg[X_PER];
-    int xg[X_PER], xl[X_PER];
+    int xg[X_PER], xl[X_PER], xr[X_PER];
 #pragma unroll
     for (int i = 0; i < X_PER; ++i) {
         int idx = tid + i * NTHR;
         int r = idx / xw, c = idx - r * xw;
         int p = t0 - dil + c;
         p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
-        xg[i] = r < KC ? r * len + p : -1;
+        xg[i] = r < KC ? p : -1;          // clamped sample position; the channel row is added per slab
+        xr[i] = r;
         xl[i] = r * XROW + c;
     }
+    const float* x2b = a.x2 ? a.x2 + (long)b * (a.Cin - a.split) * len : nullptr;
     auto load_slab = [&](int ci0) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int idx = tid + i * NTHR;
             if (idx < A_F4) {
-                int kk = idx / (BM / 4), c4 = idx - kk * (BM / 4);      // kk = global row within the slab = ci_l*3 + tap
-                areg[i] = *reinterpret_cast<const float4*>(a.At + (long)(ci0 * 3 + kk) * a.Mpad + c4 * 4);
+                int kk = idx / (BMV / 4), c4 = idx - kk * (BMV / 4);    // kk = global row within the slab = ci_l*3 + tap
+                areg[i] = ci0 * 3 + kk < a.Krows ? *reinterpret_cast<const float4*>(a.At + (long)(ci0 * 3 + kk) * a.Mpad + c4 * 4)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        const float* xc = xb + (long)ci0 * len;
 #pragma unroll
         for (int i = 0; i < X_PER; ++i) {
-            float v = xg[i] >= 0 ? xc[xg[i]] : 0.f;
+            float v = 0.f;
+            if (xg[i] >= 0) {
+                const int ci = ci0 + xr[i];
+                if (ci < a.split) v = xb[(long)ci * len + xg[i]];
+                else if (ci < a.Cin) v = x2b[(long)(ci - a.split) * len + xg[i]];
+            }
             if (LRELU) v = v > 0.f ? v : 0.1f * v;
             xreg[i] = v;
         }
@@ -76,7 +86,7 @@ __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep)
         for (int i = 0; i < A_PER; ++i) {
             int idx = tid + i * NTHR;
             if (idx < A_F4) {
-                int kk = idx / (BM / 4), c4 = idx - kk * (BM / 4);
+                int kk = idx / (BMV / 4), c4 = idx - kk * (BMV / 4);
                 int cil = kk / 3, tap = kk - 3 * cil;
                 *reinterpret_cast<float4*>(&As[buf][(tap * KC + cil) * BM + c4 * 4]) = areg[i];
             }
@@ -86,13 +96,13 @@ __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep)
             if (xg[i] >= 0) Xs[buf][xl[i]] = xreg[i];
     };
 
-    f32x4v acc[3][TN];
+    f32x4v acc[MT][TN];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    const int nslab = a.Cin / KC;
+    const int nslab = (a.Cin + KC - 1) / KC;
     load_slab(0);
     store_slab(0);
     __syncthreads();
@@ -105,13 +115,13 @@ __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep)
         for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
             for (int c4 = 0; c4 < KC; c4 += 4) {
-                float av[3], bv[TN];
+                float av[MT], bv[TN];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) av[i] = as[(tap * KC + c4) * BM + i * 16];
+                for (int i = 0; i < MT; ++i) av[i] = as[(tap * KC + c4) * BM + i * 16];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bv[j] = xs[c4 * XROW + tap * dil + j * 16];
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
@@ -121,14 +131,14 @@ __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep)
     }
 
     if constexpr (FILM) {
-        f32x4v asc[3][TN], ash[3][TN];
+        f32x4v asc[MT][TN], ash[MT][TN];
         constexpr int FK = 8, FROW = TL::FROW;
-        constexpr int FA_F4 = FK * BM / 4, FA_PER = (FA_F4 + NTHR - 1) / NTHR;
+        constexpr int FA_F4 = FK * BMV / 4, FA_PER = (FA_F4 + NTHR - 1) / NTHR;
         constexpr int FB_PER = (FK * BN + NTHR - 1) / NTHR;
         const float* cb = a.cond + (long)b * a.Ccond * len;
-        auto film_phase = [&](const float* Wt, f32x4v (&out)[3][TN]) {
+        auto film_phase = [&](const float* Wt, f32x4v (&out)[MT][TN]) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) out[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
             float4 fa[FA_PER];
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep)
                 for (int i = 0; i < FA_PER; ++i) {
                     int idx = tid + i * NTHR;
                     if (idx < FA_F4) {
-                        int kk = idx / (BM / 4), c4 = idx - kk * (BM / 4);
+                        int kk = idx / (BMV / 4), c4 = idx - kk * (BMV / 4);
                         fa[i] = *reinterpret_cast<const float4*>(Wt + (long)(c0 + kk) * a.Mpad + c4 * 4);
                     }
                 }
@@ -155,7 +165,10 @@ __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep)
 #pragma unroll
                 for (int i = 0; i < FA_PER; ++i) {
                     int idx = tid + i * NTHR;
-                    if (idx < FA_F4) *reinterpret_cast<float4*>(&As[buf][idx * 4]) = fa[i];
+                    if (idx < FA_F4) {
+                        int kk = idx / (BMV / 4), c4 = idx - kk * (BMV / 4);
+                        *reinterpret_cast<float4*>(&As[buf][kk * BM + c4 * 4]) = fa[i];
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < FB_PER; ++i) {
@@ -175,13 +188,13 @@ __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep)
                 const float* bs = Xs[cur] + lq * FROW + ncol0 + l15;
 #pragma unroll
                 for (int c4 = 0; c4 < FK; c4 += 4) {
-                    float av[3], bv[TN];
+                    float av[MT], bv[TN];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) av[i] = as[c4 * BM + i * 16];
+                    for (int i = 0; i < MT; ++i) av[i] = as[c4 * BM + i * 16];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bv[j] = bs[c4 * FROW + j * 16];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
                             out[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], out[i][j], 0, 0, 0);
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep)
         film_phase(a.sc_At, asc);
         film_phase(a.sh_At, ash);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int t = t0 + ncol0 + j * 16 + l15;
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep)
             }
     } else {
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int t = t0 + ncol0 + j * 16 + l15;
@@ -220,21 +233,22 @@ __global__ __launch_bounds__(TL::NTHR) void conv3m48_kernel(Conv3Args a, Epi ep)
     }
 }
 
-// Launch for M == 48 (Mpad == 64 weights: only the first 48 columns of each At row are read).
-template <bool LRELU, class Epi, bool FILM = false>
-inline void conv3m48_launch(hipStream_t s, const float* At, int Mpad, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
-                            const FilmOps& f = FilmOps()) {
+// Launch for M <= 48 (MT = 3) or M <= 32 (MT = 2); only the first MT*16 columns of each At row are read.
+// `x2` (optional): channels [split, Cin) come from a second tensor [B][Cin - split][len] (downs[0]'s cat).
+template <int MT, bool LRELU, class Epi, bool FILM = false>
+inline void conv3mt_launch(hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
+                           const FilmOps& f = FilmOps(), const float* x2 = nullptr, int split = 0) {
 #ifndef TVC_C48_NW
 #define TVC_C48_NW 8
 #endif
 #ifndef TVC_C48_TN
 #define TVC_C48_TN 1     // 8 waves x 16 columns = 128-sample tiles: measured best (1.40 ms vs 1.51 for TN = 2 on ups.3)
 #endif
-    using TL = C48Tile<TVC_C48_NW, TVC_C48_TN>;
+    using TL = C48Tile<TVC_C48_NW, TVC_C48_TN, MT>;
     Conv3Args a;
-    a.At = At;
+    a.At = w.At;
     a.x = x;
-    a.Mpad = Mpad;
+    a.Mpad = w.Mpad;
     a.Cin = Cin;
     a.len = len;
     a.dil = dil;
@@ -243,8 +257,17 @@ inline void conv3m48_launch(hipStream_t s, const float* At, int Mpad, const floa
     a.sh_At = f.sh_At;
     a.cond = f.cond;
     a.Ccond = f.Ccond;
+    a.x2 = x2;
+    a.split = x2 ? split : Cin;
+    a.Krows = w.Kpad;
     dim3 g((unsigned)(a.tiles_per_utt * B));
     hipLaunchKernelGGL((conv3m48_kernel<TL, LRELU, Epi, FILM>), g, dim3(TL::NTHR), 0, s, a, ep);
+}
+
+template <bool LRELU, class Epi, bool FILM = false>
+inline void conv3m48_launch(hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
+                            const FilmOps& f = FilmOps()) {
+    conv3mt_launch<3, LRELU, Epi, FILM>(s, w, x, B, Cin, len, dil, ep, f);
 }
 
 }  // namespace tvc

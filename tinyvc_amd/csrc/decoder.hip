@@ -254,7 +254,11 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         LoadPlain ld{content, kSslDim, T, (long)kSslDim * T};
         EpiSumCond ep{x, ctx->flt_content_in.bias, nullptr, f0, nullptr, nullptr, ctx->flt_f_w, ctx->flt_f_b, ch[0], T, B * T};
         igemm_launch(s, ctx->flt_content_in.At, ctx->flt_content_in.Mpad, ctx->flt_content_in.Kpad, B * T, T, ld, ep);
-        TVC_CHECK(run_down0(ctx, s, ctx->flt_down0, source, energy, skip[0], B, (int)L));
+        if (TVC_USE_C48)   // downs[0]: k3 conv over cat[source (16 ch), energy (1 ch)], read from the two tensors in place
+            conv3mt_launch<2, false>(s, ctx->flt_down0, source, B, 17, (int)L, 1, C3EpiBias<false>{skip[0], ctx->flt_down0.bias, nullptr, 24, (int)L},
+                                     FilmOps(), energy, 16);
+        else
+            TVC_CHECK(run_down0(ctx, s, ctx->flt_down0, source, energy, skip[0], B, (int)L));
     }
     // down path
     for (int i = 1; i <= 4; ++i) {
@@ -277,15 +281,18 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 EpiBias<ACT_NONE, false> ep{res, d.res.bias, nullptr, d.cout, len, nc, (long)d.cout * len, 0};
                 igemm_launch(s, d.res.At, d.res.Mpad, d.res.Kpad, nc, len, ld, ep);
             }
-            if (d.cin == 48 && TVC_USE_C48) {   // 48 = 3 x 16: the 16x16x4 kernel has no row padding
-                conv3m48_launch<true>(s, d.c1.At, d.c1.Mpad, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
-                conv3m48_launch<true>(s, d.c2.At, d.c2.Mpad, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
+            if (d.cin == 24 && TVC_USE_C48) {   // 24 output channels = two 16-row tiles, many small waves
+                conv3mt_launch<2, true>(s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
+                conv3mt_launch<2, true>(s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
+            } else if (d.cin == 48 && TVC_USE_C48) {   // 48 = 3 x 16: the 16x16x4 kernel has no row padding
+                conv3m48_launch<true>(s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
+                conv3m48_launch<true>(s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
             } else {
                 conv3_launch<true>(s, d.c1.At, d.c1.Mpad, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
                 conv3_launch<true>(s, d.c2.At, d.c2.Mpad, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
             }
             if (d.cout == 48 && TVC_USE_C48)
-                conv3m48_launch<true>(s, d.c3.At, d.c3.Mpad, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
+                conv3m48_launch<true>(s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
             else
                 conv3_launch<true>(s, d.c3.At, d.c3.Mpad, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
         }
@@ -334,8 +341,8 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 const PackedW& wsh = half ? u.sh2 : u.sh1;
                 if (C == 48 && TVC_USE_C48) {
                     // 48-channel level on 16x16x4 tiles (no row padding), FiLM and residual fused
-                    conv3m48_launch<true>(s, ca.At, ca.Mpad, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo});
-                    conv3m48_launch<true, C3EpiFilmFused, true>(s, cb.At, cb.Mpad, h, B, C, lo, db,
+                    conv3m48_launch<true>(s, ca, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo});
+                    conv3m48_launch<true, C3EpiFilmFused, true>(s, cb, h, B, C, lo, db,
                                                                 C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
                                                                 FilmOps{wsc.At, wsh.At, cond, C});
                     continue;
