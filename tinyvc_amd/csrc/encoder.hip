@@ -159,30 +159,54 @@ struct EpiSplit {
 };
 
 // PitchEstimator.decode (encoder.py:61-67): top-4 logits (ties -> lower class id), softmax over
-// them, expectation of the class frequencies, <= 20 Hz -> 0.   One thread per (b, t) column.
-static __global__ void pitch_decode_kernel(const float* __restrict__ logits, const float* __restrict__ freq,
-                                           float* __restrict__ f0, int B, int T) {
-    long n = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (n >= (long)B * T) return;
-    int b = (int)(n / T), t = (int)(n - (long)b * T);
-    const float* p = logits + (long)b * kPitchClasses * T + t;
-    float v0 = -INFINITY, v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
-    int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
-    for (int c = 0; c < kPitchClasses; ++c) {
-        float v = p[(long)c * T];
-        if (v > v3) {
-            if (v > v0) { v3 = v2; i3 = i2; v2 = v1; i2 = i1; v1 = v0; i1 = i0; v0 = v; i0 = c; }
-            else if (v > v1) { v3 = v2; i3 = i2; v2 = v1; i2 = i1; v1 = v; i1 = c; }
-            else if (v > v2) { v3 = v2; i3 = i2; v2 = v; i2 = c; }
-            else { v3 = v; i3 = c; }
-        }
+// them, expectation of the class frequencies, <= 20 Hz -> 0.
+// One workgroup = 64 consecutive columns: each of the 4 waves scans a quarter of the 512 classes with
+// lanes along time (coalesced), keeps a per-lane top-4, and the four partial lists merge through LDS.
+struct PTop4 {
+    float v[4];
+    int i[4];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = -INFINITY; i[j] = 0x7fffffff; }
     }
-    float e0 = 1.f, e1 = expf(v1 - v0), e2 = expf(v2 - v0), e3 = expf(v3 - v0);
+    __device__ __forceinline__ static bool better(float a, int ia, float b, int ib) { return a > b || (a == b && ia < ib); }
+    __device__ __forceinline__ void insert(float x, int ix) {
+        if (!better(x, ix, v[3], i[3])) return;
+        if (better(x, ix, v[0], i[0])) { v[3] = v[2]; i[3] = i[2]; v[2] = v[1]; i[2] = i[1]; v[1] = v[0]; i[1] = i[0]; v[0] = x; i[0] = ix; }
+        else if (better(x, ix, v[1], i[1])) { v[3] = v[2]; i[3] = i[2]; v[2] = v[1]; i[2] = i[1]; v[1] = x; i[1] = ix; }
+        else if (better(x, ix, v[2], i[2])) { v[3] = v[2]; i[3] = i[2]; v[2] = x; i[2] = ix; }
+        else { v[3] = x; i[3] = ix; }
+    }
+};
+
+static __global__ __launch_bounds__(256) void pitch_decode_kernel(const float* __restrict__ logits, const float* __restrict__ freq,
+                                                                  float* __restrict__ f0, int B, int T) {
+    __shared__ float sv[4][64][4];
+    __shared__ int si[4][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long ncols = (long)B * T;
+    const long n = blockIdx.x * 64L + lane;
+    const bool ok = n < ncols;
+    const long nn = ok ? n : ncols - 1;
+    const int b = (int)(nn / T), t = (int)(nn - (long)b * T);
+    const float* p = logits + (long)b * kPitchClasses * T + t;
+    PTop4 top;
+    top.init();
+    for (int c = wave * (kPitchClasses / 4); c < (wave + 1) * (kPitchClasses / 4); ++c) top.insert(p[(long)c * T], c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sv[wave][lane][e] = top.v[e]; si[wave][lane][e] = top.i[e]; }
+    __syncthreads();
+    if (wave != 0 || !ok) return;
+    for (int w = 1; w < 4; ++w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) top.insert(sv[w][lane][e], si[w][lane][e]);
+    const float v0 = top.v[0];
+    float e0 = 1.f, e1 = expf(top.v[1] - v0), e2 = expf(top.v[2] - v0), e3 = expf(top.v[3] - v0);
     float den = ((e0 + e1) + e2) + e3;
-    float acc = __fmul_rn(e0 / den, freq[i0]);
-    acc = __fadd_rn(acc, __fmul_rn(e1 / den, freq[i1]));
-    acc = __fadd_rn(acc, __fmul_rn(e2 / den, freq[i2]));
-    acc = __fadd_rn(acc, __fmul_rn(e3 / den, freq[i3]));
+    float acc = __fmul_rn(e0 / den, freq[top.i[0]]);
+    acc = __fadd_rn(acc, __fmul_rn(e1 / den, freq[top.i[1]]));
+    acc = __fadd_rn(acc, __fmul_rn(e2 / den, freq[top.i[2]]));
+    acc = __fadd_rn(acc, __fmul_rn(e3 / den, freq[top.i[3]]));
     f0[n] = acc <= 20.f ? 0.f : acc;
 }
 
@@ -212,7 +236,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
         EpiBias<ACT_NONE, false> ep{lg, ctx->pit_out.bias, nullptr, kPitchClasses, T, ncols, (long)kPitchClasses * T, 0};
         igemm_launch(s, ctx->pit_out.At, ctx->pit_out.Mpad, ctx->pit_out.Kpad, ncols, T, ld, ep);
     }
-    hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 255) / 256), dim3(256), 0, s, lg, ctx->pitch_freq, f0, B, T);
+    hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, lg, ctx->pitch_freq, f0, B, T);
     return launch_check(ctx, "encoder");
 }
 

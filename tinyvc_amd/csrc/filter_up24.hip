@@ -107,9 +107,8 @@ struct Up24Cfg {
     // weight image offsets (floats)
     static constexpr int O_WA = 0, O_WB = O_WA + 72 * 32, O_SC = O_WB + 72 * 32, O_SH = O_SC + 24 * 32,
                          O_W5 = O_SH + 24 * 32, O_W7 = O_W5 + 24 * 32, WFLOATS = O_W7 + 24 * 8;
-    static constexpr int LDS_FLOATS = 2 * C * XS + C * XS + WFLOATS + 5 * 32;
+    static constexpr int LDS_FLOATS = C * XS + C * XS + WFLOATS + 5 * 32;
     static_assert(XS >= XW && XS >= HWr && XS >= W2r, "row stride");
-    static_assert(NT / 8 * 4 >= W, "output conv: 8 lanes per 4 outputs");
 };
 
 struct Up24Args {
@@ -136,8 +135,8 @@ template <class CF>
 __global__ __launch_bounds__(CF::NT) void up24_kernel(Up24Args a) {
     constexpr int C = CF::C, W = CF::W, D1 = CF::D1, D2 = CF::D2, H = CF::H, E = CF::E, XS = CF::XS, NT = CF::NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xbuf = smem;                        // 2 x [C][XS] input tile, double buffered
-    float* Hs = smem + 2 * C * XS;             // [C][XS] 1st-conv output; later c5 output (half B)
+    float* Xbuf = smem;                        // [C][XS] input tile (the next one waits in registers until the end of the tile)
+    float* Hs = smem + C * XS;                 // [C][XS] 1st-conv output; later c5 output (half B)
     float* Wi = Hs + C * XS;                   // resident weight images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -224,7 +223,7 @@ __global__ __launch_bounds__(CF::NT) void up24_kernel(Up24Args a) {
 
     int cur = 0;
     for (; tile < a.ntiles; tile += gridDim.x, cur ^= 1) {
-        float* Xs = Xbuf + cur * C * XS;
+        float* Xs = Xbuf;
         const int b = tile / a.tiles_per_utt;
         const int t0 = (tile - b * a.tiles_per_utt) * W;
         const int px0 = t0 - E - H;       // position of Xs column 0
@@ -345,44 +344,48 @@ __global__ __launch_bounds__(CF::NT) void up24_kernel(Up24Args a) {
             // 8 lanes per group of 4 consecutive outputs, 3 channels each: per channel 10 activations
             // and 7 (broadcast) weights feed 28 FMAs; the 8 partial sums meet through three shuffles.
             {
-                const int g = tid >> 3, part = tid & 7;
+                const int part = tid & 7;
                 const int lo = -p20 > 0 ? -p20 : 0;
                 const int hi = (len - 1 - p20) < (CF::W2 - 1) ? (len - 1 - p20) : (CF::W2 - 1);
-                float o4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (UP24_EXP != 1 && 4 * g < W) {
-                    int cols[10];
+                for (int g0 = 0; g0 < (W + 3) / 4; g0 += NT / 8) {      // uniform trip count: the shuffles need every lane
+                    const int g = g0 + (tid >> 3);
+                    float o4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (UP24_EXP != 1 && 4 * g < W) {
+                        int cols[10];
 #pragma unroll
-                    for (int i = 0; i < 10; ++i) {
-                        int c = 4 * g + E - 3 + i;
-                        cols[i] = c < lo ? lo : (c > hi ? hi : c);
+                        for (int i = 0; i < 10; ++i) {
+                            int c = 4 * g + E - 3 + i;
+                            cols[i] = c < lo ? lo : (c > hi ? hi : c);
+                        }
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) {
+                            const int c = part * 3 + cc;
+                            float xv[10], wv[7];
+#pragma unroll
+                            for (int i = 0; i < 10; ++i) xv[i] = Hs[c * XS + cols[i]];
+#pragma unroll
+                            for (int j = 0; j < 7; ++j) wv[j] = Wi[CF::O_W7 + c * 7 + j];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int j = 0; j < 7; ++j) o4[q] = fmaf(wv[j], xv[q + j], o4[q]);
+                        }
                     }
 #pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) {
-                        const int c = part * 3 + cc;
-                        float xv[10], wv[7];
-#pragma unroll
-                        for (int i = 0; i < 10; ++i) xv[i] = Hs[c * XS + cols[i]];
-#pragma unroll
-                        for (int j = 0; j < 7; ++j) wv[j] = Wi[CF::O_W7 + c * 7 + j];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int j = 0; j < 7; ++j) o4[q] = fmaf(wv[j], xv[q + j], o4[q]);
+                    for (int q = 0; q < 4; ++q) {
+                        o4[q] += __shfl_xor(o4[q], 1);
+                        o4[q] += __shfl_xor(o4[q], 2);
+                        o4[q] += __shfl_xor(o4[q], 4);
                     }
+                    const int o = 4 * g + part;                  // lanes 0..3 of a group store outputs 4g..4g+3
+                    const float v = part == 0 ? o4[0] : (part == 1 ? o4[1] : (part == 2 ? o4[2] : o4[3]));
+                    if (part < 4 && o < W && t0 + o < len) a.out[(long)b * len + t0 + o] = v + a.b7[0];
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    o4[q] += __shfl_xor(o4[q], 1);
-                    o4[q] += __shfl_xor(o4[q], 2);
-                    o4[q] += __shfl_xor(o4[q], 4);
-                }
-                const int o = 4 * g + part;                      // lanes 0..3 of a group store outputs 4g..4g+3
-                const float v = part == 0 ? o4[0] : (part == 1 ? o4[1] : (part == 2 ? o4[2] : o4[3]));
-                if (part < 4 && o < W && t0 + o < len) a.out[(long)b * len + t0 + o] = v + a.b7[0];
             }
         }
         // ---- next tile's input: registers -> the other LDS buffer ---------------------------------------
-        if (UP24_EXP != 2 && next < a.ntiles) deposit(Xbuf + (cur ^ 1) * C * XS, next);
+        if (!CF::SECOND && UP24_EXP != 5) __syncthreads();     // half A: S2 still reads the input tile (residual)
+        if (UP24_EXP != 2 && next < a.ntiles) deposit(Xbuf, next);
         if (UP24_EXP != 5) __syncthreads();
     }
 }
@@ -409,8 +412,14 @@ static int launch_up24(tvc_ctx* ctx, hipStream_t s, Up24Args a, int B) {
 // x [B][24][len/f], cond [B][24][len] -> wave [B][len]; x1 is scratch [B][24][len].
 int run_up24_fused(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, const float* cond, float* x1, float* wave,
                    int B, int len, const float* w7, const float* b7) {
-    using CA = Up24Cfg<256, 1, 3, false, 0, UP24_NT>;
-    using CB = Up24Cfg<250, 9, 27, true, 3, UP24_NT>;
+#ifndef UP24_WA
+#define UP24_WA 384
+#endif
+#ifndef UP24_WB
+#define UP24_WB 378
+#endif
+    using CA = Up24Cfg<UP24_WA, 1, 3, false, 0, UP24_NT>;
+    using CB = Up24Cfg<UP24_WB, 9, 27, true, 3, UP24_NT>;
     Up24Args a{};
     a.len = len;
     a.xf = u.factor;

@@ -53,17 +53,27 @@ int run_prepare_index(tvc_ctx* ctx, hipStream_t s, const float* index, float* pr
     return launch_check(ctx, "knn_prepare_index");
 }
 
-// qn[b][k][t] = src[b][k][t] / (||src[b][:][t]|| + 1e-6)
-static __global__ void query_normalize_kernel(const float* __restrict__ src, float* __restrict__ qn, int B, int T) {
-    long n = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (n >= (long)B * T) return;
-    int b = (int)(n / T), t = (int)(n - (long)b * T);
+// qn[b][k][t] = src[b][k][t] / (||src[b][:][t]|| + 1e-6).  One workgroup = 64 consecutive columns;
+// its 4 waves each sum a quarter of the 768 channels (lanes along time, coalesced), partial sums of
+// squares meet in LDS in a fixed order, then every wave rescales its quarter.
+static __global__ __launch_bounds__(256) void query_normalize_kernel(const float* __restrict__ src, float* __restrict__ qn, int B, int T) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long ncols = (long)B * T;
+    const long n = blockIdx.x * 64L + lane;
+    const bool ok = n < ncols;
+    const long nn = ok ? n : ncols - 1;
+    const int b = (int)(nn / T), t = (int)(nn - (long)b * T);
     const float* p = src + (long)b * KD * T + t;
     float* q = qn + (long)b * KD * T + t;
+    const int k0 = wave * (KD / 4), k1 = k0 + KD / 4;
     float s = 0.f;
-    for (int k = 0; k < KD; ++k) s = fmaf(p[(long)k * T], p[(long)k * T], s);
-    float den = sqrtf(s) + 1e-6f;
-    for (int k = 0; k < KD; ++k) q[(long)k * T] = p[(long)k * T] / den;
+    for (int k = k0; k < k1; ++k) s = fmaf(p[(long)k * T], p[(long)k * T], s);
+    part[wave][lane] = s;
+    __syncthreads();
+    const float den = sqrtf(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) + 1e-6f;
+    if (!ok) return;
+    for (int k = k0; k < k1; ++k) q[(long)k * T] = p[(long)k * T] / den;
 }
 
 struct Top4 {
@@ -276,7 +286,7 @@ int run_knn(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, con
     int* ci = ws.get<int>((size_t)nsplit * ncols * 4);
     if (dry) return 0;
     if (N > 0x7fffff00L) return fail(ctx, TVC_ERR_ARG, "index too large");
-    hipLaunchKernelGGL(query_normalize_kernel, dim3((ncols + 255) / 256), dim3(256), 0, s, src, qn, B, T);
+    hipLaunchKernelGGL(query_normalize_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, src, qn, B, T);
     hipLaunchKernelGGL(knn_topk_kernel, dim3((unsigned)(qtiles * nsplit)), dim3(KNN_WAVES * 64), 0, s, prepared, Npad, (int)N, qn,
                        ncols, T, nsplit, tps, cv, ci);
     hipLaunchKernelGGL(knn_merge_gather_kernel, dim3((ncols + 31) / 32), dim3(256), 0, s, cv, ci, nsplit, ncols, T,
