@@ -89,6 +89,7 @@ struct Packer {
         }
         fix.push_back({&pw->At, ab.put(At)});
         fix.push_back({&pw->bias, ab.put(bias)});
+        a6(pw, At);
         if (taps > 1) {   // tap-major copy: row (tap*cin + ci)
             std::vector<float> Att((size_t)pw->Kpad * pw->Mpad, 0.f);
             for (int ci = 0; ci < cin; ++ci)
@@ -99,6 +100,45 @@ struct Packer {
         } else {
             fix.push_back({&pw->At_tap, fix[fix.size() - 2].off});
         }
+    }
+    // bf16x3 split image of At for conv3s.h: [step = slab*taps + tap][m-tile][part][lane][8 bf16],
+    // lane -> row m = 32*mt + (lane & 31), channel ci = 16*slab + 8*(lane >> 5) + j.  x = p1 + p2 + p3 with
+    // round-to-nearest-even parts; both residuals are exact in fp32.
+    void a6(PackedW* pw, const std::vector<float>& At) {
+        auto to_bf16 = [](float f) -> uint16_t {
+            uint32_t u;
+            std::memcpy(&u, &f, 4);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        auto from_bf16 = [](uint16_t h) -> float {
+            uint32_t u = (uint32_t)h << 16;
+            float f;
+            std::memcpy(&f, &u, 4);
+            return f;
+        };
+        const int taps = pw->taps, cin = pw->cin, MT = pw->Mpad / 32, nslab = (cin + 15) / 16;
+        std::vector<float> img((size_t)nslab * taps * MT * 3 * 256, 0.f);
+        uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
+        for (int s = 0; s < nslab; ++s)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int mt = 0; mt < MT; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            int ci = s * 16 + 8 * (lane >> 5) + j, m = mt * 32 + (lane & 31);
+                            float w = (ci < cin && m < pw->M) ? At[(size_t)(ci * taps + tap) * pw->Mpad + m] : 0.f;
+                            uint16_t h1 = to_bf16(w);
+                            float r = w - from_bf16(h1);
+                            uint16_t h2 = to_bf16(r);
+                            float r2 = r - from_bf16(h2);
+                            uint16_t h3 = to_bf16(r2);
+                            size_t base = (((size_t)(s * taps + tap) * MT + mt) * 3 * 64 + lane) * 8 + j;
+                            o[base] = h1;
+                            o[base + 512] = h2;
+                            o[base + 1024] = h3;
+                        }
+        pw->MT6 = MT;
+        fix.push_back({&pw->A6, ab.put(img)});
     }
     void convnext(const std::string& p, ConvNeXtW* w, int C, int dil) {
         w->C = C;
@@ -143,6 +183,7 @@ void build_dft_tables(Packer& pk, tvc_ctx* ctx) {
         std::vector<float> bias(pw.Mpad, 0.f);
         pk.fix.push_back({&pw.At, pk.ab.put(At)});
         pk.fix.push_back({&pw.bias, pk.ab.put(bias)});
+        pk.a6(&pw, At);
     };
     auto ang = [&](long f, long n) { return two_pi * (double)((f * n) % N) / N; };
     {   // forward real part: rows k = n-1 (n = 1..960), columns f = 0..960

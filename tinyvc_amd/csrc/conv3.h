@@ -41,6 +41,7 @@ struct Conv3Args {
 // Epilogue interface: store(b, t, m, v[4]) for 4 consecutive channels m..m+3 at (b, t); t < len guaranteed.
 template <bool RES>
 struct C3EpiBias {
+    static constexpr bool kRes = RES;
     float* y;
     const float* bias;
     const float* res;

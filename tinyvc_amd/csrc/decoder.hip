@@ -2,6 +2,7 @@
 // iSTFT, and the FilterNet U-Net.
 #include "conv3.h"
 #include "conv3m48.h"
+#include "conv3s.h"
 #include "igemm.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
@@ -239,6 +240,10 @@ static void conv_launch(hipStream_t s, const PackedW& w, const float* x, int cin
     igemm_launch(s, w.At, w.Mpad, w.Kpad, B * len, len, ld, ep);
 }
 
+#ifndef TVC_SPLIT
+#define TVC_SPLIT 1
+#endif
+
 static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
                       const float* energy, const float* source, float* wave, int B, int T) {
     const long L = (long)T * kHop;
@@ -287,12 +292,17 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
             } else if (d.cin == 48 && TVC_USE_C48) {   // 48 = 3 x 16: the 16x16x4 kernel has no row padding
                 conv3m48_launch<true>(s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
                 conv3m48_launch<true>(s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
+            } else if (TVC_SPLIT && d.cin % 96 == 0) {   // bf16x3 split path, 16x the fp32 MFMA rate per part-product
+                TVC_CHECK(conv3s_launch<true>(ctx, s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len}));
+                TVC_CHECK(conv3s_launch<true>(ctx, s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len}));
             } else {
                 conv3_launch<true>(s, d.c1.At, d.c1.Mpad, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
                 conv3_launch<true>(s, d.c2.At, d.c2.Mpad, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
             }
             if (d.cout == 48 && TVC_USE_C48)
                 conv3m48_launch<true>(s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
+            else if (TVC_SPLIT && d.cin % 16 == 0 && d.cout % 96 == 0)
+                TVC_CHECK(conv3s_launch<true>(ctx, s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len}));
             else
                 conv3_launch<true>(s, d.c3.At, d.c3.Mpad, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
         }
@@ -345,6 +355,13 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                     conv3m48_launch<true, C3EpiFilmFused, true>(s, cb, h, B, C, lo, db,
                                                                 C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
                                                                 FilmOps{wsc.At, wsh.At, cond, C});
+                    continue;
+                }
+                if (TVC_SPLIT && C % 96 == 0) {
+                    TVC_CHECK(conv3s_launch<true>(ctx, s, ca, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo}));
+                    TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
+                                                                          C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
+                                                                          &wsc, &wsh, cond, C)));
                     continue;
                 }
                 conv3_launch<true>(s, ca.At, ca.Mpad, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo});
