@@ -243,6 +243,9 @@ static void conv_launch(hipStream_t s, const PackedW& w, const float* x, int cin
 #ifndef TVC_SPLIT
 #define TVC_SPLIT 1
 #endif
+#ifndef TVC_SPLIT48
+#define TVC_SPLIT48 0   // 1: 48-channel levels on the split path too (2: also downs.1's 24 -> 48 conv); measured 10 % slower than the exact 16x16x4 fp32 tiles (row padding 48 -> 64, HBM-heavier level)
+#endif
 
 static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
                       const float* energy, const float* source, float* wave, int B, int T) {
@@ -289,6 +292,9 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
             if (d.cin == 24 && TVC_USE_C48) {   // 24 output channels = two 16-row tiles, many small waves
                 conv3mt_launch<2, true>(s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
                 conv3mt_launch<2, true>(s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
+            } else if (d.cin == 48 && TVC_SPLIT48) {
+                TVC_CHECK(conv3s_launch<true>(ctx, s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len}));
+                TVC_CHECK(conv3s_launch<true>(ctx, s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len}));
             } else if (d.cin == 48 && TVC_USE_C48) {   // 48 = 3 x 16: the 16x16x4 kernel has no row padding
                 conv3m48_launch<true>(s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
                 conv3m48_launch<true>(s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
@@ -299,7 +305,9 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 conv3_launch<true>(s, d.c1.At, d.c1.Mpad, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
                 conv3_launch<true>(s, d.c2.At, d.c2.Mpad, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
             }
-            if (d.cout == 48 && TVC_USE_C48)
+            if (d.cout == 48 && TVC_SPLIT48 >= 2)   // 24 -> 48: the second K slab is half empty
+                TVC_CHECK(conv3s_launch<true>(ctx, s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len}));
+            else if (d.cout == 48 && TVC_USE_C48)
                 conv3m48_launch<true>(s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
             else if (TVC_SPLIT && d.cin % 16 == 0 && d.cout % 96 == 0)
                 TVC_CHECK(conv3s_launch<true>(ctx, s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len}));
@@ -327,7 +335,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         const float* cond = skip[4 - i];
         size_t mk = ws.mark();
         float* xu = ws.get<float>((size_t)B * C * lo);
-        float* film = (C < 96 && C != 24 && !(C == 48 && TVC_USE_C48)) ? ws.get<float>((size_t)B * 2 * C * lo) : nullptr;
+        float* film = (C < 96 && C != 24 && !(C == 48 && (TVC_USE_C48 || TVC_SPLIT48))) ? ws.get<float>((size_t)B * 2 * C * lo) : nullptr;
         float* h = ws.get<float>((size_t)B * C * lo);
         float* x1 = ws.get<float>((size_t)B * C * lo);
         if (!dry && C == 24) {
@@ -349,6 +357,13 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 float* xout = half ? xu : x1;  // 2nd half writes over xu (its input and residual are x1)
                 const PackedW& wsc = half ? u.sc2 : u.sc1;
                 const PackedW& wsh = half ? u.sh2 : u.sh1;
+                if (C == 48 && TVC_SPLIT48) {
+                    TVC_CHECK(conv3s_launch<true>(ctx, s, ca, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo}));
+                    TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
+                                                                          C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
+                                                                          &wsc, &wsh, cond, C)));
+                    continue;
+                }
                 if (C == 48 && TVC_USE_C48) {
                     // 48-channel level on 16x16x4 tiles (no row padding), FiLM and residual fused
                     conv3m48_launch<true>(s, ca, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo});
