@@ -37,25 +37,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef S_WPE_F
 #define S_WPE_F 3
 #endif
+#ifndef S_BPC
+#define S_BPC 1     // persistent workgroups per CU
+#endif
 #ifndef S_FB
 #define S_FB 2   // fragment register sets: 2 = next tap's LDS reads under this tap's MFMAs, 1 = read, then multiply
+#endif
+#ifndef S_FB_F
+#define S_FB_F 1   // FiLM-fused kernels: two accumulator sets live, single fragment set keeps the slab loops spill-free
 #endif
 #ifndef S_ABL
 #define S_ABL 0   // timing ablations (wrong results): 1 no MFMA, 2 no weight loads, 4 no input loads, 8 no input split/stores, 16 no output stores
 #endif
 
-#ifndef S_DBG
-#define S_DBG 0   // 1: workgroup 300 wave 0 records s_memtime stamps and the launcher prints them
-#endif
-#if S_DBG
-__device__ unsigned long long g_sdbg[64];
-#define S_STAMP(k)                                                                                               \
-    do {                                                                                                         \
-        if (blockIdx.x == 300 && threadIdx.x == 0 && (k) < 64) g_sdbg[k] = __builtin_amdgcn_s_memtime();         \
-    } while (0)
-#else
-#define S_STAMP(k)
-#endif
 
 template <int MTB_, int WM_, int NWV_, int WN_ = 1>
 struct SplitTile {
@@ -67,14 +61,22 @@ struct SplitTile {
     static constexpr int X_U4 = 3 * 2 * XROW;
     static constexpr int X_PER = (2 * XROW + NTHR - 1) / NTHR;                  // staging items per thread
     static constexpr int a_u4(int taps) { return taps * MTB * 3 * 64; }
-    static constexpr int lds_bytes(int taps) { return (a_u4(taps) + X_U4) * 16; }
+    static constexpr int OS = BN + 4;                                           // row stride (floats) of the output tile parked in LDS
+    static constexpr int lds_bytes(int taps) {
+        const int stage = (a_u4(taps) + X_U4) * 16, out = BM * OS * 4;
+        return (stage > out ? stage : out) + 3 * BM * 4;      // + bias / FiLM-bias rows of this workgroup
+    }
+    static constexpr int bias_off(int taps) {                  // float offset of that area
+        const int stage = (a_u4(taps) + X_U4) * 16, out = BM * OS * 4;
+        return (stage > out ? stage : out) / 4;
+    }
 };
 
 struct ConvSArgs {
     const uint4* A6;     // split weight image
     int MT;              // m-tiles in the image
     const float* x;      // [B][Cin][len]
-    int Cin, len, dil, tiles_per_utt;
+    int Cin, len, dil, tiles_per_utt, ntiles;
     const uint4* sc6 = nullptr;   // FiLM scale / shift images (1x1 over cond), FILM kernels only
     const uint4* sh6 = nullptr;
     const float* cond = nullptr;
@@ -104,101 +106,111 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& p1, uint4& p2
 // workgroup barrier that drains this wave's LDS traffic but not its global loads
 __device__ __forceinline__ void slab_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// acc += W (.) x over all slabs of one input tensor
-template <class TL, int TAPS, int A_U4, bool LRELU>
-__device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], const uint4* __restrict__ A6, int MT, int mt0,
-                                            const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs) {
-    constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, NTHR = TL::NTHR, XROW = TL::XROW, BN = TL::BN, X_PER = TL::X_PER;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave / NWV, wn = wave - wm * NWV;
-    const int xw = BN + 2 * dil;
-
-    // staging map of this thread, fixed across slabs: item -> (channel group g, staged column c)
-    unsigned xo[X_PER];                                      // utterance-relative element offset of (channel 8 g, position p)
-    int xdst[X_PER], xg8[X_PER];
-    float xr[X_PER][8];
+// Staging registers of one thread (one slab in flight) and its share of the halo tile.
+template <class TL>
+struct SlabRegs {
+    static constexpr int A_MAX = (3 * TL::MTB * 3 + TL::NW - 1) / TL::NW;
+    u32x4 ar[A_MAX];
+    float xr[TL::X_PER][8];
+};
+template <class TL>
+struct SlabMap {
+    unsigned xo[TL::X_PER];    // utterance-relative element offset of (channel 8 g, position p)
+    int xdst[TL::X_PER];       // LDS row of the item, -1 = idle
+};
+template <class TL>
+__device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t0) {
+    const int xw = TL::BN + 2 * dil;
 #pragma unroll
-    for (int i = 0; i < X_PER; ++i) {
-        int idx = tid + i * NTHR;
+    for (int i = 0; i < TL::X_PER; ++i) {
+        int idx = threadIdx.x + i * TL::NTHR;
         int g = idx / xw, c = idx - g * xw;
         int p = t0 - dil + c;
         p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
-        xdst[i] = g < 2 ? g * XROW + c : -1;
+        m.xdst[i] = g < 2 ? g * TL::XROW + c : -1;
         g = g < 2 ? g : 1;                                   // idle items still load (valid address), never store
-        xg8[i] = 8 * g;
-        xo[i] = (unsigned)(8 * g * len + p);
+        m.xo[i] = (unsigned)(8 * g * len + p);
     }
+}
+// global -> registers only (no use of the values here: the loads stay in flight behind the MFMAs)
+template <class TL, int TAPS>
+__device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ A6, int MT, int mt0,
+                                          const float* __restrict__ xb, int Cin, int len, int s) {
+    constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER;
     constexpr int PIECES = TAPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
-    const uint4* a_src = A6 + (long)mt0 * 192;
-    u32x4 ar[A_PER];
-    // global -> registers only (no use of the values here: the loads stay in flight behind the MFMAs)
-    auto gload = [&](int s) __attribute__((always_inline)) {
-        const int ci0 = s * 16;
-        if (!(S_ABL & 2)) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ci0 = s * 16;
+    if (!(S_ABL & 2)) {
+        const uint4* a_src = A6 + (long)mt0 * 192;
 #pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-                int q = wave + i * NW;
-                q = q < PIECES ? q : PIECES - 1;
-                const int tap = q / (MTB * 3), rem = q - tap * (MTB * 3);
-                ar[i] = *reinterpret_cast<const u32x4*>(a_src + ((long)(s * TAPS + tap) * MT * 192 + rem * 64) + lane);
-            }
+        for (int i = 0; i < A_PER; ++i) {
+            int q = wave + i * NW;
+            q = q < PIECES ? q : PIECES - 1;
+            const int tap = q / (MTB * 3), rem = q - tap * (MTB * 3);
+            r.ar[i] = *reinterpret_cast<const u32x4*>(a_src + ((long)(s * TAPS + tap) * MT * 192 + rem * 64) + lane);
         }
-        if (S_ABL & 4) return;
-        const float* xc = xb + (long)ci0 * len;              // uniform base, 32-bit lane offsets
-        if (ci0 + 16 <= Cin) {
+    }
+    if (S_ABL & 4) return;
+    const float* xc = xb + (long)ci0 * len;              // uniform base, 32-bit lane offsets
+    // Cin % 16 == 0 is a launch precondition (every level routed here has 48/96/192/384 channels): no ragged slab
 #pragma unroll
-            for (int i = 0; i < X_PER; ++i)
+    for (int i = 0; i < X_PER; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xr[i][j] = xc[xo[i] + (unsigned)(j * len)];
-        } else {   // ragged last slab: channels >= Cin read as zero
-#pragma unroll
-            for (int i = 0; i < X_PER; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int cj = ci0 + xg8[i] + j;
-                    float v = xc[xo[i] + (unsigned)((cj < Cin ? j : 0) * len)];
-                    xr[i][j] = cj < Cin ? v : 0.f;
-                }
-        }
-    };
+        for (int j = 0; j < 8; ++j) r.xr[i][j] = xc[m.xo[i] + (unsigned)(j * len)];
+}
+// slab 0 of a phase, issued by whoever runs before it (previous phase / previous tile / kernel entry)
+template <class TL, int TAPS>
+__device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0, const float* __restrict__ xb,
+                                           int Cin, int len, int dil, int t0) {
+    SlabMap<TL> m;
+    make_map<TL>(m, len, dil, t0);
+    slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, 0);
+}
+
+// acc += W (.) x over all slabs of one input tensor.  Slab 0 is already in flight in `r` (first_load); `next()`
+// is called in its place behind the last slab, so the following phase or tile starts without a cold load.
+template <class TL, int TAPS, int A_U4, bool LRELU, int FB, class Next>
+__device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
+                                            const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next) {
+    constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / NWV, wn = wave - wm * NWV;
+    SlabMap<TL> m;
+    make_map<TL>(m, len, dil, t0);
+    constexpr int PIECES = TAPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
     auto lstore = [&]() __attribute__((always_inline)) {
         if (!(S_ABL & 2)) {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 const int q = wave + i * NW;
-                if (q < PIECES) *reinterpret_cast<u32x4*>(As + q * 64 + lane) = ar[i];
+                if (q < PIECES) *reinterpret_cast<u32x4*>(As + q * 64 + lane) = r.ar[i];
             }
         }
 #pragma unroll
         for (int i = 0; i < X_PER; ++i)
-            if (xdst[i] >= 0 && !(S_ABL & 8)) {
+            if (m.xdst[i] >= 0 && !(S_ABL & 8)) {
                 if (LRELU) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xr[i][j] = fmaxf(xr[i][j], 0.1f * xr[i][j]);   // = leaky_relu(x, 0.1)
+                    for (int j = 0; j < 8; ++j) r.xr[i][j] = fmaxf(r.xr[i][j], 0.1f * r.xr[i][j]);   // = leaky_relu(x, 0.1)
                 }
                 uint4 p1, p2, p3;
-                split8(xr[i], p1, p2, p3);
-                Xs[xdst[i]] = p1;
-                Xs[2 * XROW + xdst[i]] = p2;
-                Xs[4 * XROW + xdst[i]] = p3;
+                split8(r.xr[i], p1, p2, p3);
+                Xs[m.xdst[i]] = p1;
+                Xs[2 * XROW + m.xdst[i]] = p2;
+                Xs[4 * XROW + m.xdst[i]] = p3;
             }
     };
 
     const int nslab = (Cin + 15) / 16;
     const uint4* as = As + wm * WM * 192 + lane;
     const uint4* xs = Xs + lh * XROW + wn * WN * 32 + l31;
-    S_STAMP(1);
-    gload(0);
     for (int s = 0; s < nslab; ++s) {
-        if (TAPS == 3) S_STAMP(2 + 4 * s);
         slab_barrier();                            // every wave is done reading the previous slab
-        if (TAPS == 3) S_STAMP(3 + 4 * s);
         lstore();                                  // slab s: registers -> LDS
-        if (s + 1 < nslab) gload(s + 1);           // slab s+1 flies across this slab's MFMAs
-        if (TAPS == 3) S_STAMP(4 + 4 * s);
+        if (s + 1 < nslab) slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, s + 1);   // flies across this slab's MFMAs
+        else next();
         slab_barrier();
-        if (TAPS == 3) S_STAMP(5 + 4 * s);
         // fragments of tap t+1 are read while the MFMAs of tap t run
         bf16x8 af[2][WM][3], bf[2][WN][3];
         auto frags = [&](int tap, int fb) __attribute__((always_inline)) {
@@ -211,11 +223,11 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], const
 #pragma unroll
                 for (int p = 0; p < 3; ++p) af[fb][i][p] = __builtin_bit_cast(bf16x8, as[(tap * MTB * 3 + i * 3 + p) * 64]);
         };
-        if (S_FB == 2) frags(0, 0);
+        if (FB == 2) frags(0, 0);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            const int fb = S_FB == 2 ? tap & 1 : 0;
-            if (S_FB == 2) {
+            const int fb = FB == 2 ? tap & 1 : 0;
+            if (FB == 2) {
                 if (tap + 1 < TAPS) frags(tap + 1, fb ^ 1);
                 __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler sinks them to just-in-time otherwise)
             } else {
@@ -231,10 +243,52 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], const
                     for (int j = 0; j < WN; ++j)
                         if (!(S_ABL & 1) || q == 0)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][i][PA[q]], bf[fb][j][PB[q]], acc[i][j], 0, 0, 0);
-            if (S_FB == 2) __builtin_amdgcn_sched_barrier(0);
-#if S_DBG
-            if (TAPS == 3 && s == 2) { S_STAMP(41 + tap); __builtin_amdgcn_sched_barrier(0); }
-#endif
+            if (FB == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// Output tile -> HBM through LDS: the accumulator layout gives a lane one sample of 16 different rows (4-byte
+// stores, 128 B per row and instruction); parked as Ot[row][sample] the tile leaves as 16-byte stores (and the
+// residual arrives as 16-byte loads) along time.  v already holds everything but the residual.
+template <class TL, bool RES>
+__device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][TL::WN], float* __restrict__ y, const float* __restrict__ res,
+                                           int b, int M, int len, int mt0, int t0) {
+    constexpr int WM = TL::WM, WN = TL::WN, BM = TL::BM, BN = TL::BN, OS = TL::OS, NTHR = TL::NTHR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / TL::NWV, wn = wave - wm * TL::NWV;
+    slab_barrier();                                // every wave is done with the staging buffers
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ot[((wm * WM + i) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)) * OS + (wn * WN + j) * 32 + l31] = v[i][j][r];
+    slab_barrier();
+    float* yb = y + ((long)b * M + mt0 * 32) * len + t0;      // offsets inside the tile's rows fit 32 bits
+    const float* rb = RES ? res + ((long)b * M + mt0 * 32) * len + t0 : nullptr;
+    const int rows = M - mt0 * 32 < BM ? M - mt0 * 32 : BM;
+    const bool vec = (len & 3) == 0;                        // rows start 16-byte aligned (t0 is a multiple of 32)
+#pragma unroll 2
+    for (int idx = tid; idx < BM * (BN / 4); idx += NTHR) {
+        const int row = idx / (BN / 4), c = (idx - row * (BN / 4)) * 4;
+        if (row >= rows || t0 + c >= len) continue;
+        const float4 o = *reinterpret_cast<const float4*>(Ot + row * OS + c);
+        const int off = row * len + c;
+        if (vec && t0 + c + 3 < len) {
+            float4 w = o;
+            if (RES) {
+                const float4 q = *reinterpret_cast<const float4*>(rb + off);
+                w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w;
+            }
+            *reinterpret_cast<float4*>(yb + off) = w;
+        } else {
+            const float e[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t0 + c + u < len) yb[off + u] = RES ? e[u] + rb[off + u] : e[u];
         }
     }
 }
@@ -247,99 +301,119 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     uint4* Xs = smem_s + A_U4;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave / TL::NWV, wn = wave - wm * TL::NWV;
+    const int lh = lane >> 5;
+    const int wm = wave / TL::NWV;
     const int mblocks = a.MT / MTB;
-    const int mt0 = (blockIdx.x % mblocks) * MTB;
-    const int nt_id = blockIdx.x / mblocks;
-    const int b = nt_id / a.tiles_per_utt;
-    const int t0 = (nt_id - b * a.tiles_per_utt) * TL::BN;
     const int len = a.len;
-    S_STAMP(0);
+    const int ntiles = a.ntiles;
 
-    f32x16 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    split_phase<TL, TAPS, A_U4, LRELU>(acc, a.A6, a.MT, mt0, a.x + (long)b * a.Cin * len, a.Cin, len, a.dil, t0, As, Xs);
-    const int tw = t0 + wn * WN * 32 + l31;        // column of n-tile 0 of this wave
-
-    if constexpr (FILM) {
-        // conv -> FiLM -> + residual (decoder.py:94-97,181-182): scale and shift are two more 1x1 phases over
-        // cond on the same tiles; the conv result is folded with the scale before the shift phase runs, so
-        // at most two accumulator sets are live.
-        const float* cb = a.cond + (long)b * a.Ccond * len;
-        f32x16 a2[WM][WN];
-        auto zero2 = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) a2[i][j][r] = 0.f;
+    // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the first slab of every phase - including the
+    // first phase of the NEXT tile - is loaded behind the last slab of the one before it, so only the very first
+    // load of a workgroup is cold and the output stores of a tile overlap the next tile's input loads
+    auto coords = [&](int tile, int& mt0, int& b, int& t0) __attribute__((always_inline)) {
+        mt0 = (tile % mblocks) * MTB;
+        const int nt_id = tile / mblocks;
+        b = nt_id / a.tiles_per_utt;
+        t0 = (nt_id - b * a.tiles_per_utt) * TL::BN;
+    };
+    SlabRegs<TL> regs;
+    int tile = blockIdx.x, mt0, b, t0;
+    coords(tile, mt0, b, t0);
+    first_load<TL, TAPS>(regs, a.A6, a.MT, mt0, a.x + (long)b * a.Cin * len, a.Cin, len, a.dil, t0);
+    while (tile < ntiles) {
+        const int nxt = tile + gridDim.x;
+        auto load_next_tile = [&]() __attribute__((always_inline)) {
+            if (nxt < ntiles) {
+                int mt0n, bn, t0n;
+                coords(nxt, mt0n, bn, t0n);
+                first_load<TL, TAPS>(regs, a.A6, a.MT, mt0n, a.x + (long)bn * a.Cin * len, a.Cin, len, a.dil, t0n);
+            }
         };
-        zero2();
-        split_phase<TL, 1, A_U4, false>(a2, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs);
-        const int mb = (mt0 + wm * WM) * 32 + 4 * lh;              // row of accumulator register r of m-tile i: mb + 32 i + (r & 3) + 8 (r >> 2)
+        const float* xb = a.x + (long)b * a.Cin * len;
+        // this tile's bias rows -> LDS: read back with ds_read (lgkmcnt), so the epilogue math never waits on vmcnt
+        // while the next phase's prefetch is in flight (a global bias load would drag that whole prefetch with it)
+        float* Bs = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS);
+        if (tile == (int)blockIdx.x || mblocks > 1) {
+            for (int i = threadIdx.x; i < TL::BM; i += TL::NTHR) {
+                int m = mt0 * 32 + i;
+                m = m < ep.M ? m : ep.M - 1;
+                Bs[i] = ep.bias[m];
+                if constexpr (FILM) {
+                    Bs[TL::BM + i] = ep.bsc[m];
+                    Bs[2 * TL::BM + i] = ep.bsh[m];
+                }
+            }
+        }
+        const int rl = wm * WM * 32 + 4 * lh;                     // local row of accumulator register r of m-tile i: rl + 32 i + (r & 3) + 8 (r >> 2)
+        f32x16 acc[WM][WN];
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
-                m = m < ep.M ? m : ep.M - 1;
-                const float bm = ep.bias[m], bs = ep.bsc[m];
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j][r] = __fmul_rn(acc[i][j][r] + bm, a2[i][j][r] + bs);
-            }
-        zero2();
-        split_phase<TL, 1, A_U4, false>(a2, a.sh6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs);
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int t = tw + j * 32;
-            if (t < len) {
-                float* yb = ep.y + (long)b * ep.M * len + t;          // offsets within one utterance fit 32 bits
-                const float* rb = ep.res + (long)b * ep.M * len + t;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        if constexpr (FILM) {
+            // conv -> FiLM -> + residual (decoder.py:94-97,181-182): scale and shift are two more 1x1 phases over
+            // cond on the same tiles; the conv result is folded with the scale before the shift phase runs, so
+            // at most two accumulator sets are live.
+            const float* cb = a.cond + (long)b * a.Ccond * len;
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+                                               [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0); });
+            f32x16 a2[WM][WN];
+            auto zero2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
-                        if (m < ep.M) yb[m * len] = __fadd_rn(__fadd_rn(acc[i][j][r], a2[i][j][r] + ep.bsh[m]), rb[m * len]);
-                    }
-            }
+                    for (int j = 0; j < WN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) a2[i][j][r] = 0.f;
+            };
+            zero2();
+            split_phase<TL, 1, A_U4, false, FILM ? S_FB_F : S_FB>(a2, regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs,
+                                            [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sh6, a.MT, mt0, cb, a.Ccond, len, 0, t0); });
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rl + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const float bm = Bs[row], bs = Bs[TL::BM + row];
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j][r] = __fmul_rn(acc[i][j][r] + bm, a2[i][j][r] + bs);
+                }
+            zero2();
+            split_phase<TL, 1, A_U4, false, FILM ? S_FB_F : S_FB>(a2, regs, a.sh6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile);
+            // out = ((h + b)(sc + b_sc)) + (sh + b_sh), + residual in the vector pass
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float bh = Bs[2 * TL::BM + rl + i * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j][r] = __fadd_rn(acc[i][j][r], a2[i][j][r] + bh);
+                }
+            tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
+        } else {
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float bm = Bs[rl + i * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j][r] += bm;
+                }
+            if (!(S_ABL & 16)) tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
         }
-    } else {
-        const int mb = (mt0 + wm * WM) * 32 + 4 * lh;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int t = tw + j * 32;
-            if (t < len && !(S_ABL & 16)) {
-                float* yb = ep.y + (long)b * ep.M * len + t;          // offsets within one utterance fit 32 bits
-                const float* rb = nullptr;
-                if constexpr (Epi::kRes) rb = ep.res + (long)b * ep.M * len + t;
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
-                        if (m < ep.M) {
-                            float o = acc[i][j][r] + ep.bias[m];
-                            if constexpr (Epi::kRes) o += rb[m * len];
-                            yb[m * len] = o;
-                        }
-                    }
-            }
-        }
-        S_STAMP(40);
+        tile = nxt;
+        if (tile < ntiles) coords(tile, mt0, b, t0);
     }
 }
 
 template <class TL, int TAPS, bool LRELU, class Epi, bool FILM>
 inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
                            const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond) {
+    if (Cin % 16 != 0 || (FILM && Ccond % 16 != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of 16");
     static bool ready = false;
     constexpr int lds = TL::lds_bytes(TAPS);
     if (!ready) {
@@ -362,24 +436,16 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
         a.cond = cond;
         a.Ccond = Ccond;
     }
-    dim3 g((unsigned)((a.MT / TL::MTB) * a.tiles_per_utt * B));
-    hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM>), g, dim3(TL::NTHR), lds, s, a, ep);
-#if S_DBG
-    if (!FILM && g.x > 300) {
-        static int shown = 0;
-        if (shown++ == 40) {
-            unsigned long long h[64];
-            hipDeviceSynchronize();
-            hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sdbg), sizeof(h));
-            const int ns = (Cin + 15) / 16;
-            fprintf(stderr, "[sdbg] grid %u Cin %d len %d: start->phase %llu;", g.x, Cin, len, h[1] - h[0]);
-            for (int k = 0; k < ns; ++k)
-                fprintf(stderr, " [slab %d: top %llu bar %llu stage %llu bar %llu]", k, h[2 + 4 * k] - h[0], h[3 + 4 * k] - h[2 + 4 * k],
-                        h[4 + 4 * k] - h[3 + 4 * k], h[5 + 4 * k] - h[4 + 4 * k]);
-            fprintf(stderr, " end %llu; slab2 after bar->tap0 %llu tap1 %llu tap2 %llu\n", h[40] - h[0], h[41] - h[13], h[42] - h[41], h[43] - h[42]);
-        }
+    a.ntiles = (a.MT / TL::MTB) * a.tiles_per_utt * B;
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv3s: device properties");
+        ncu = prop.multiProcessorCount;
     }
-#endif
+    const int slots = ncu * S_BPC;                 // persistent: one resident workgroup per slot walks the tiles
+    dim3 g((unsigned)(a.ntiles < slots ? a.ntiles : slots));
+    hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM>), g, dim3(TL::NTHR), lds, s, a, ep);
     return 0;
 }
 

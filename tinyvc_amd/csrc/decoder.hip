@@ -305,7 +305,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 conv3_launch<true>(s, d.c1.At, d.c1.Mpad, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
                 conv3_launch<true>(s, d.c2.At, d.c2.Mpad, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
             }
-            if (d.cout == 48 && TVC_SPLIT48 >= 2)   // 24 -> 48: the second K slab is half empty
+            if (d.cout == 48 && d.cin % 16 == 0 && TVC_SPLIT48 >= 2)
                 TVC_CHECK(conv3s_launch<true>(ctx, s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len}));
             else if (d.cout == 48 && TVC_USE_C48)
                 conv3m48_launch<true>(s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
@@ -335,7 +335,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         const float* cond = skip[4 - i];
         size_t mk = ws.mark();
         float* xu = ws.get<float>((size_t)B * C * lo);
-        float* film = (C < 96 && C != 24 && !(C == 48 && (TVC_USE_C48 || TVC_SPLIT48))) ? ws.get<float>((size_t)B * 2 * C * lo) : nullptr;
+        float* film = (C < 96 && C != 24 && !(C == 48 && (TVC_USE_C48 + TVC_SPLIT48 > 0))) ? ws.get<float>((size_t)B * 2 * C * lo) : nullptr;
         float* h = ws.get<float>((size_t)B * C * lo);
         float* x1 = ws.get<float>((size_t)B * C * lo);
         if (!dry && C == 24) {
