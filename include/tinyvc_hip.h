@@ -80,8 +80,9 @@ int tvc_encoder_f32(tvc_ctx* ctx, void* stream, const float* spec, float* ssl, f
 /* Prepare an index for matching, once per index: index [768, N] (the [1,768,N] tensor of index.pt,
  * reference extract_index.py:58 / infer.py:49, or Generator.encode's output) -> `prepared`, a blob of
  * tvc_knn_prepared_elems(N) floats holding the columns scaled by 1/(||r||+1e-6)
- * (feature_retrieval.py:25 recomputes that on every call) and the raw vectors row-major for the
- * final gather. */
+ * (feature_retrieval.py:25 recomputes that on every call), the raw vectors row-major for the
+ * final gather, and the same normalised columns split into three bf16 parts per value in MFMA lane
+ * order (the similarity GEMM's operand). The layout is private to the library. */
 int64_t tvc_knn_prepared_elems(int64_t N);
 int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, float* prepared,
                               int64_t N);

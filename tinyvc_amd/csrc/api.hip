@@ -492,7 +492,8 @@ int tvc_encoder_f32(tvc_ctx* ctx, void* stream, const float* spec, float* ssl, f
 int64_t tvc_knn_prepared_elems(int64_t N) {
     if (N <= 0) return 0;
     int64_t npad = (N + 127) / 128 * 128;
-    return (int64_t)kSslDim * npad + N * (int64_t)kSslDim;
+    // normalised columns [768][Npad] + raw rows [N][768] + split-precision image (3 bf16 per value = 1.5 floats)
+    return (int64_t)kSslDim * npad + N * (int64_t)kSslDim + (int64_t)kSslDim * npad * 3 / 2;
 }
 
 int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, float* prepared, int64_t N) {

@@ -8,6 +8,7 @@
 // per-split candidates, emits int64 indices and gathers + averages the 4 raw index vectors.
 //
 // Tie-break: equal similarities -> lower index first (torch.topk leaves it unspecified).
+#include "conv3s.h"
 #include "igemm.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
@@ -17,6 +18,9 @@ namespace tvc {
 constexpr int KD = kSslDim;  // 768
 #ifndef KNN_BK
 #define KNN_BK 16      // K-slab depth of the similarity GEMM (deeper slabs cost occupancy: measured slower)
+#endif
+#ifndef KNN_SPLIT
+#define KNN_SPLIT 1    // similarity GEMM on the split-precision bf16 path (0: exact-fp32 MFMA kernel)
 #endif
 #ifndef KNN_WAVES
 #define KNN_WAVES 8    // waves per workgroup: 8 -> each wave owns 64 x 32 (32 accumulator registers)
@@ -46,10 +50,36 @@ static __global__ void index_prepare_kernel(const float* __restrict__ index, flo
     }
 }
 
+// Split-precision image of the normalised index for knn_topk_split_kernel: every value as three bf16 parts
+// (v = p1 + p2 + p3, residuals exact), laid out [128-vector tile][K16 step][m-tile][part][lane][8] so that a
+// (tile, step) is 12 contiguous 1 KiB pieces already in MFMA lane order (row = lane & 31, k = 8 (lane >> 5) + j).
+static __global__ void index_split_kernel(const float* __restrict__ normT, unsigned short* __restrict__ img, long Npad) {
+    long n = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (n >= Npad) return;
+    const long tile = n >> 7;
+    const int mt = (int)(n & 127) >> 5, l31 = (int)(n & 31);
+    for (int k = 0; k < KD; ++k) {
+        float v = normT[(long)k * Npad + n];
+        __bf16 h1 = (__bf16)v;
+        float r = v - (float)h1;
+        __bf16 h2 = (__bf16)r;
+        float r2 = r - (float)h2;
+        __bf16 h3 = (__bf16)r2;
+        const int step = k >> 4, lh = (k >> 3) & 1, j = k & 7;
+        long base = ((((tile * (KD / 16) + step) * 4 + mt) * 3) * 64 + (lh * 32 + l31)) * 8 + j;
+        img[base] = __builtin_bit_cast(unsigned short, h1);
+        img[base + 512] = __builtin_bit_cast(unsigned short, h2);
+        img[base + 1024] = __builtin_bit_cast(unsigned short, h3);
+    }
+}
+
+// prepared blob: [768][Npad] normalised columns | [N][768] raw rows | split image (Npad * 768 * 3 bf16)
 int run_prepare_index(tvc_ctx* ctx, hipStream_t s, const float* index, float* prepared, int64_t N) {
     long Npad = npad128(N);
     hipLaunchKernelGGL(index_prepare_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, s, index, prepared,
                        prepared + (size_t)KD * Npad, (long)N, Npad);
+    unsigned short* img = reinterpret_cast<unsigned short*>(prepared + (size_t)KD * Npad + (size_t)N * KD);
+    hipLaunchKernelGGL(index_split_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, s, prepared, img, Npad);
     return launch_check(ctx, "knn_prepare_index");
 }
 
@@ -215,6 +245,150 @@ static __global__ __launch_bounds__(KNN_WAVES * 64) void knn_topk_kernel(const f
     }
 }
 
+// Same search on the split-precision path (conv3s.h): sims from six bf16 part-products per K16 block, fp32
+// accumulation, error below the fp32 MFMA chain's (so the top-4 decisions are at least as faithful).
+// 8 waves of 64 (index) x 32 (queries); the (tile, step) sequence is one flat pipeline: registers hold step g+1,
+// LDS is double-buffered, one raw barrier per step.
+static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const uint4* __restrict__ img, long Npad, int N,
+                                                                    const float* __restrict__ qn, int ncols, int T,
+                                                                    int nsplit, int tiles_per_split,
+                                                                    float* __restrict__ cand_v, int* __restrict__ cand_i) {
+    constexpr int STEPS = KD / 16;                       // 48
+    constexpr int A_U4 = 12 * 64, X_U4 = 3 * 2 * 128;    // one buffer each: 12 KiB + 12 KiB
+    __shared__ __attribute__((aligned(16))) uint4 smem[2 * (A_U4 + X_U4)];
+    __shared__ float mv[128][16];
+    __shared__ int mi[128][16];
+    uint4* As = smem;
+    uint4* Xs = smem + 2 * A_U4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int split = blockIdx.x % nsplit;
+    const int qtile = blockIdx.x / nsplit;
+    const int n0 = qtile * 128;
+    const int mtiles = (int)(Npad >> 7);
+    const int mt_lo = split * tiles_per_split;
+    const int mt_hi = min(mtiles, mt_lo + tiles_per_split);
+    const int G = (mt_hi - mt_lo) * STEPS;               // flat (tile, step) sequence
+
+    // staging roles: threads 0..255 own one query item (8 channels of one column) + weight piece tid / 64;
+    // threads 256..511 own weight pieces 4.. (two each)
+    const bool xrole = tid < 256;
+    const float* qp = qn;
+    int xdst = 0;
+    if (xrole) {
+        const int g = tid >> 7, pos = tid & 127;
+        int n = n0 + pos;
+        n = n < ncols ? n : ncols - 1;
+        const int b = n / T, t = n - b * T;
+        qp = qn + ((long)b * KD + 8 * g) * T + t;
+        xdst = g * 128 + pos;
+    }
+    const int pa = xrole ? wave : 4 + 2 * (wave - 4);    // first weight piece of this thread
+    float xr[8];
+    u32x4 ar[2];
+    auto gload = [&](int g) __attribute__((always_inline)) {
+        const int mt = mt_lo + g / STEPS, st = g - (g / STEPS) * STEPS;
+        const uint4* src = img + ((long)mt * STEPS + st) * (12 * 64) + lane;
+        ar[0] = *reinterpret_cast<const u32x4*>(src + pa * 64);
+        if (!xrole) ar[1] = *reinterpret_cast<const u32x4*>(src + (pa + 1) * 64);
+        if (xrole) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[j] = qp[(long)(st * 16 + j) * T];
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+        uint4* ab = As + buf * A_U4;
+        *reinterpret_cast<u32x4*>(ab + pa * 64 + lane) = ar[0];
+        if (!xrole) *reinterpret_cast<u32x4*>(ab + (pa + 1) * 64 + lane) = ar[1];
+        if (xrole) {
+            uint4 p1, p2, p3;
+            split8(xr, p1, p2, p3);
+            uint4* xb = Xs + buf * X_U4;
+            xb[xdst] = p1;
+            xb[256 + xdst] = p2;
+            xb[512 + xdst] = p3;
+        }
+    };
+
+    Top4 top;
+    top.init();
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    if (G > 0) {
+        gload(0);
+        lstore(0);
+        if (G > 1) gload(1);
+        slab_barrier();
+    }
+    for (int g = 0; g < G; ++g) {
+        const int cur = g & 1;
+        if (g + 1 < G) {
+            lstore(cur ^ 1);                        // step g+1 (its buffer was last read in step g-1, behind the barrier)
+            if (g + 2 < G) gload(g + 2);            // flies across this step's MFMAs and the next barrier
+        }
+        const uint4* as = As + cur * A_U4 + wm * (6 * 64) + lane;
+        const uint4* xs = Xs + cur * X_U4 + lh * 128 + wn * 32 + l31;
+        bf16x8 af[2][3], bf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(bf16x8, xs[p * 256]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = __builtin_bit_cast(bf16x8, as[(i * 3 + p) * 64]);
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[PB[q]], acc[i], 0, 0, 0);
+        const int st = g - (g / STEPS) * STEPS;
+        if (st == STEPS - 1) {
+            // running top-4: this lane's 16 registers are 16 index vectors against its own query
+            const int m0 = (mt_lo + g / STEPS) * 128;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < N) top.insert(acc[i][r], row);
+                    acc[i][r] = 0.f;
+                }
+        }
+        slab_barrier();
+    }
+
+    // merge the 4 partial lists (wm in {0,1} x lh in {0,1}) of every query through LDS
+    {
+        int q = wn * 32 + l31;
+        int slot = (wm * 2 + lh) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mv[q][slot + e] = top.v[e];
+            mi[q][slot + e] = top.i[e];
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        Top4 t4;
+        t4.init();
+        for (int e = 0; e < 16; ++e) t4.insert(mv[tid][e], mi[tid][e]);
+        int n = n0 + tid;
+        if (n < ncols) {
+            long o = ((long)split * ncols + n) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cand_v[o + e] = t4.v[e];
+                cand_i[o + e] = t4.i[e];
+            }
+        }
+    }
+}
+
 // One workgroup = 32 consecutive query columns: merge split candidates -> top-4, write indices,
 // gather the 4 raw rows per query (coalesced along the feature axis), average, and write
 // out[b][k][t] through an LDS transpose so stores run along t.
@@ -287,8 +461,14 @@ int run_knn(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, con
     if (dry) return 0;
     if (N > 0x7fffff00L) return fail(ctx, TVC_ERR_ARG, "index too large");
     hipLaunchKernelGGL(query_normalize_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, src, qn, B, T);
-    hipLaunchKernelGGL(knn_topk_kernel, dim3((unsigned)(qtiles * nsplit)), dim3(KNN_WAVES * 64), 0, s, prepared, Npad, (int)N, qn,
-                       ncols, T, nsplit, tps, cv, ci);
+    if (KNN_SPLIT) {
+        const uint4* img = reinterpret_cast<const uint4*>(prepared + (size_t)KD * Npad + (size_t)N * KD);
+        hipLaunchKernelGGL(knn_topk_split_kernel, dim3((unsigned)(qtiles * nsplit)), dim3(512), 0, s, img, Npad, (int)N, qn, ncols, T,
+                           nsplit, tps, cv, ci);
+    } else {
+        hipLaunchKernelGGL(knn_topk_kernel, dim3((unsigned)(qtiles * nsplit)), dim3(KNN_WAVES * 64), 0, s, prepared, Npad, (int)N, qn,
+                           ncols, T, nsplit, tps, cv, ci);
+    }
     hipLaunchKernelGGL(knn_merge_gather_kernel, dim3((ncols + 31) / 32), dim3(256), 0, s, cv, ci, nsplit, ncols, T,
                        prepared + (size_t)KD * Npad, out, idx_out);
     return launch_check(ctx, "knn_match");
