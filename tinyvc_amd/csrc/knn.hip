@@ -22,6 +22,9 @@ constexpr int KD = kSslDim;  // 768
 #ifndef KNN_SPLIT
 #define KNN_SPLIT 1    // similarity GEMM on the split-precision bf16 path (0: exact-fp32 MFMA kernel)
 #endif
+#ifndef KNN_PIN
+#define KNN_PIN 0
+#endif
 #ifndef KNN_WAVES
 #define KNN_WAVES 8    // waves per workgroup: 8 -> each wave owns 64 x 32 (32 accumulator registers)
 #endif
@@ -341,6 +344,9 @@ static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const uint4*
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int p = 0; p < 3; ++p) af[i][p] = __builtin_bit_cast(bf16x8, as[(i * 3 + p) * 64]);
+#if KNN_PIN
+        __builtin_amdgcn_sched_barrier(0);          // all nine reads, then the twelve MFMAs
+#endif
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
         for (int q = 0; q < 6; ++q)
