@@ -42,6 +42,7 @@ struct Conv3Args {
 template <bool RES>
 struct C3EpiBias {
     static constexpr bool kRes = RES;
+    static constexpr bool kIgemm = false;
     float* y;
     const float* bias;
     const float* res;
@@ -80,6 +81,7 @@ struct C3EpiFilm {
 
 // conv -> FiLM -> + residual with scale/shift computed in-kernel: store(b, t, m, h[4], sc[4], sh[4])
 struct C3EpiFilmFused {
+    static constexpr bool kIgemm = false;
     float* y;
     const float* bias;
     const float* bsc;

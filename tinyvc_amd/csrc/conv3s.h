@@ -75,7 +75,8 @@ struct SplitTile {
 struct ConvSArgs {
     const uint4* A6;     // split weight image
     int MT;              // m-tiles in the image
-    const float* x;      // [B][Cin][len]
+    const float* x;      // [B][Cin][len], utterance b at x + b * xstride
+    long xstride;
     int Cin, len, dil, tiles_per_utt, ntiles;
     const uint4* sc6 = nullptr;   // FiLM scale / shift images (1x1 over cond), FILM kernels only
     const uint4* sh6 = nullptr;
@@ -319,21 +320,21 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     SlabRegs<TL> regs;
     int tile = blockIdx.x, mt0, b, t0;
     coords(tile, mt0, b, t0);
-    first_load<TL, TAPS>(regs, a.A6, a.MT, mt0, a.x + (long)b * a.Cin * len, a.Cin, len, a.dil, t0);
+    first_load<TL, TAPS>(regs, a.A6, a.MT, mt0, a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0);
     while (tile < ntiles) {
         const int nxt = tile + gridDim.x;
         auto load_next_tile = [&]() __attribute__((always_inline)) {
             if (nxt < ntiles) {
                 int mt0n, bn, t0n;
                 coords(nxt, mt0n, bn, t0n);
-                first_load<TL, TAPS>(regs, a.A6, a.MT, mt0n, a.x + (long)bn * a.Cin * len, a.Cin, len, a.dil, t0n);
+                first_load<TL, TAPS>(regs, a.A6, a.MT, mt0n, a.x + (long)bn * a.xstride, a.Cin, len, a.dil, t0n);
             }
         };
-        const float* xb = a.x + (long)b * a.Cin * len;
+        const float* xb = a.x + (long)b * a.xstride;
         // this tile's bias rows -> LDS: read back with ds_read (lgkmcnt), so the epilogue math never waits on vmcnt
         // while the next phase's prefetch is in flight (a global bias load would drag that whole prefetch with it)
         float* Bs = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS);
-        if (tile == (int)blockIdx.x || mblocks > 1) {
+        if constexpr (!Epi::kIgemm) if (tile == (int)blockIdx.x || mblocks > 1) {
             for (int i = threadIdx.x; i < TL::BM; i += TL::NTHR) {
                 int m = mt0 * 32 + i;
                 m = m < ep.M ? m : ep.M - 1;
@@ -395,6 +396,26 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
         } else {
             split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile);
+            if constexpr (Epi::kIgemm) {
+                // plain GEMM use (B = 1, len = all columns): the igemm epilogue functors finish the element
+                const int l31 = lane & 31, wn = wave - wm * TL::NWV;
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        const int n = b * len + t0 + (wn * WN + j) * 32 + l31;
+                        if (t0 + (wn * WN + j) * 32 + l31 < len) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                                ep.store(n, (mt0 + wm * WM + i) * 32 + 8 * q + 4 * lh, v);
+                            }
+                        }
+                    }
+                tile = nxt;
+                if (tile < ntiles) coords(tile, mt0, b, t0);
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -403,7 +424,8 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
 #pragma unroll
                     for (int j = 0; j < WN; ++j) acc[i][j][r] += bm;
                 }
-            if (!(S_ABL & 16)) tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
+            if constexpr (!Epi::kIgemm)
+                if (!(S_ABL & 16)) tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
         }
         tile = nxt;
         if (tile < ntiles) coords(tile, mt0, b, t0);
@@ -412,7 +434,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
 
 template <class TL, int TAPS, bool LRELU, class Epi, bool FILM>
 inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
-                           const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond) {
+                           const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond, long xstride = 0, int bpc = S_BPC) {
     if (Cin % 16 != 0 || (FILM && Ccond % 16 != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of 16");
     static bool ready = false;
     constexpr int lds = TL::lds_bytes(TAPS);
@@ -426,6 +448,7 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     a.A6 = reinterpret_cast<const uint4*>(w.A6);
     a.MT = w.MT6;
     a.x = x;
+    a.xstride = xstride ? xstride : (long)Cin * len;
     a.Cin = Cin;
     a.len = len;
     a.dil = dil;
@@ -443,7 +466,7 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
         if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv3s: device properties");
         ncu = prop.multiProcessorCount;
     }
-    const int slots = ncu * S_BPC;                 // persistent: one resident workgroup per slot walks the tiles
+    const int slots = ncu * bpc;                 // persistent: one resident workgroup per slot walks the tiles
     dim3 g((unsigned)(a.ntiles < slots ? a.ntiles : slots));
     hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM>), g, dim3(TL::NTHR), lds, s, a, ep);
     return 0;
@@ -488,6 +511,14 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
         return conv3s_launch_t<SplitTile<3, TVC_SF_WM, TVC_SF_NWV, TVC_SF_WN>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond);
     else
         return conv3s_launch_t<SplitTile<3, TVC_S_WM, TVC_S_NWV, TVC_S_WN>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond);
+}
+
+// Plain GEMM on the split path: out(m, n) = sum_k W[m][k] x[b][k][t], n = b * len + t, finished by an igemm epilogue
+// functor (store(n, m, v[4])).  Cin must be a multiple of 16 and rows [K, Cin) must be readable (weights there are 0).
+template <int MTB, int NWV, int BPC, class Epi>
+inline int gemm_s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep) {
+    if (w.MT6 % MTB != 0) return fail(ctx, TVC_ERR_ARG, "gemm_s: row tiles do not divide");
+    return conv3s_launch_t<SplitTile<MTB, 1, NWV, 1>, 1, false, Epi, false>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride, BPC);
 }
 
 }  // namespace tvc

@@ -9,6 +9,15 @@
 
 namespace tvc {
 
+#ifndef TVC_SPLIT_IDFT
+#define TVC_SPLIT_IDFT 1   // inverse DFT GEMMs of the noise branch on the split-precision path
+#endif
+#ifndef IDFT_MTB
+#define IDFT_MTB 2
+#define IDFT_NWV 4
+#define IDFT_BPC 2
+#endif
+
 #ifndef TVC_USE_C48
 #define TVC_USE_C48 1
 #endif
@@ -217,12 +226,19 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
     }
     hipLaunchKernelGGL(noise_spec_kernel, dim3(grid_for((long)B * kBins * T)), dim3(256), 0, s, kern, angle, yri, (long)kBins * T, B);
     {   // even part from the real halves (rows 0..960 of yri), then odd part from the imaginary halves of bins 1..959
+#if TVC_SPLIT_IDFT
+        // split-precision path: K rows beyond 961 / 959 meet zero weights and stay inside yri (its imaginary half follows)
+        TVC_CHECK((gemm_s_launch<IDFT_MTB, IDFT_NWV, IDFT_BPC>(ctx, s, ctx->istft_e, yri, B, 976, T, (long)2 * kBins * T, EpiFramesPart<false>{frames, ncols})));
+        TVC_CHECK((gemm_s_launch<IDFT_MTB, IDFT_NWV, IDFT_BPC>(ctx, s, ctx->istft_o, yri + (long)(kBins + 1) * T, B, 960, T, (long)2 * kBins * T,
+                                                               EpiFramesPart<true>{frames, ncols})));
+#else
         LoadPlain le{yri, kBins, T, (long)2 * kBins * T};
         EpiFramesPart<false> ee{frames, ncols};
         igemm_launch(s, ctx->istft_e.At, ctx->istft_e.Mpad, ctx->istft_e.Kpad, ncols, T, le, ee);
         LoadPlain lo{yri + (long)(kBins + 1) * T, kBins - 2, T, (long)2 * kBins * T};
         EpiFramesPart<true> eo{frames, ncols};
         igemm_launch(s, ctx->istft_o.At, ctx->istft_o.Mpad, ctx->istft_o.Kpad, ncols, T, lo, eo);
+#endif
     }
     hipLaunchKernelGGL(noise_ola_kernel, dim3(grid_for((long)B * L)), dim3(256), 0, s, frames, source, B, T);
     return launch_check(ctx, "dsp");

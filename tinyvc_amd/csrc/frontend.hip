@@ -1,10 +1,20 @@
 // Front end: |STFT| (spectrogram.py:8-15), energy envelope (energy_estimation.py:9-14),
 // semitone shift (pitch_shift.py:5-15).
+#include "conv3s.h"
 #include "igemm.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
 
 namespace tvc {
+
+#ifndef DFT_MTB   // workgroup of the DFT GEMMs: DFT_MTB x DFT_NWV waves of 32 x 32, DFT_BPC persistent workgroups per CU
+#define DFT_MTB 2
+#define DFT_NWV 4
+#define DFT_BPC 2   // measured best of {4x4x1, 2x4x2, 2x4x1, 4x2x2, 2x8x1, 4x3x1}
+#endif
+#ifndef TVC_SPLIT_DFT
+#define TVC_SPLIT_DFT 1   // forward / inverse DFT GEMMs on the split-precision bf16 path
+#endif
 
 // ---- |STFT| as two half-size windowed real-DFT contractions on the fp32 matrix pipe ---------------
 // spec[b][f][t] = | sum_n hann[n] x_b[(t+1)*480 + n - 960 (reflected)] e^{-2 pi i f n / 1920} |
@@ -55,6 +65,11 @@ int run_stft(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, fl
     float* fo = ws.get<float>((size_t)960 * ncols);
     if (dry) return 0;
     hipLaunchKernelGGL(stft_fold_kernel, dim3(15, (ncols + 31) / 32), dim3(256), 0, s, wav, fe, fo, (int)L, T, ncols);
+#if TVC_SPLIT_DFT
+    // both half-size DFT GEMMs on the split-precision path: fe/fo [960][ncols] are one "utterance" of ncols samples
+    TVC_CHECK((gemm_s_launch<DFT_MTB, DFT_NWV, DFT_BPC>(ctx, s, ctx->stft_re, fe, 1, 960, ncols, 0, EpiStftPart<false>{spec, T, ncols})));
+    TVC_CHECK((gemm_s_launch<DFT_MTB, DFT_NWV, DFT_BPC>(ctx, s, ctx->stft_im, fo, 1, 960, ncols, 0, EpiStftPart<true>{spec, T, ncols})));
+#else
     {
         LoadMatrix ld{fe, 960, ncols};
         EpiStftPart<false> ep{spec, T, ncols};
@@ -65,6 +80,7 @@ int run_stft(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, fl
         EpiStftPart<true> ep{spec, T, ncols};
         igemm_launch(s, ctx->stft_im.At, ctx->stft_im.Mpad, ctx->stft_im.Kpad, ncols, T, ld, ep);
     }
+#endif
     return launch_check(ctx, "stft");
 }
 

@@ -266,6 +266,7 @@ struct EpiSumCond {
 // overwrites spec with sqrt(re^2 + im^2).  Rows are bins.
 template <bool FINAL>
 struct EpiStftPart {
+    static constexpr bool kIgemm = true;   // store(n, m, v[4]) interface (also usable from the split-precision kernel)
     float* spec;
     int T, ncols;
     __device__ __forceinline__ void store(int n, int m, const float v[4]) const {
@@ -289,6 +290,7 @@ struct EpiStftPart {
 // pass 2 holds O[n] (rows m = n-1, n = 1..959) and finishes x[n] = E - O, x[1920-n] = E + O in place.
 template <bool FINAL>
 struct EpiFramesPart {
+    static constexpr bool kIgemm = true;
     float* frames;
     int ncols;
     __device__ __forceinline__ void store(int n, int m, const float v[4]) const {
