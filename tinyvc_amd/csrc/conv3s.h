@@ -61,10 +61,11 @@ struct SplitTile {
     static constexpr int X_U4 = 3 * 2 * XROW;
     static constexpr int X_PER = (2 * XROW + NTHR - 1) / NTHR;                  // staging items per thread
     static constexpr int a_u4(int taps) { return taps * MTB * 3 * 64; }
+    static constexpr int KS_MAX = 768;                                          // input channels of a SCALED launch
     static constexpr int OS = BN + 4;                                           // row stride (floats) of the output tile parked in LDS
     static constexpr int lds_bytes(int taps) {
         const int stage = (a_u4(taps) + X_U4) * 16, out = BM * OS * 4;
-        return (stage > out ? stage : out) + 3 * BM * 4;      // + bias / FiLM-bias rows of this workgroup
+        return (stage > out ? stage : out) + 3 * BM * 4 + KS_MAX * 4;      // + bias / FiLM-bias rows of this workgroup + input-channel factors
     }
     static constexpr int bias_off(int taps) {                  // float offset of that area
         const int stage = (a_u4(taps) + X_U4) * 16, out = BM * OS * 4;
@@ -78,6 +79,7 @@ struct ConvSArgs {
     const float* x;      // [B][Cin][len], utterance b at x + b * xstride
     long xstride;
     int Cin, len, dil, tiles_per_utt, ntiles;
+    const float* kscale = nullptr;   // optional per-(utterance, input channel) factor applied while staging (SCALED kernels), [B][Cin]
     const uint4* sc6 = nullptr;   // FiLM scale / shift images (1x1 over cond), FILM kernels only
     const uint4* sh6 = nullptr;
     const float* cond = nullptr;
@@ -118,6 +120,7 @@ template <class TL>
 struct SlabMap {
     unsigned xo[TL::X_PER];    // utterance-relative element offset of (channel 8 g, position p)
     int xdst[TL::X_PER];       // LDS row of the item, -1 = idle
+    int xg8[TL::X_PER];        // first channel of the item inside the slab (0 or 8)
 };
 template <class TL>
 __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t0) {
@@ -130,6 +133,7 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
         p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
         m.xdst[i] = g < 2 ? g * TL::XROW + c : -1;
         g = g < 2 ? g : 1;                                   // idle items still load (valid address), never store
+        m.xg8[i] = 8 * g;
         m.xo[i] = (unsigned)(8 * g * len + p);
     }
 }
@@ -170,9 +174,10 @@ __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restr
 
 // acc += W (.) x over all slabs of one input tensor.  Slab 0 is already in flight in `r` (first_load); `next()`
 // is called in its place behind the last slab, so the following phase or tile starts without a cold load.
-template <class TL, int TAPS, int A_U4, bool LRELU, int FB, class Next>
+template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, class Next>
 __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
-                                            const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next) {
+                                            const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next,
+                                            const float* Ks = nullptr) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -180,7 +185,7 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     SlabMap<TL> m;
     make_map<TL>(m, len, dil, t0);
     constexpr int PIECES = TAPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
-    auto lstore = [&]() __attribute__((always_inline)) {
+    auto lstore = [&](int sl) __attribute__((always_inline)) {
         if (!(S_ABL & 2)) {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
@@ -195,6 +200,12 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
 #pragma unroll
                     for (int j = 0; j < 8; ++j) r.xr[i][j] = fmaxf(r.xr[i][j], 0.1f * r.xr[i][j]);   // = leaky_relu(x, 0.1)
                 }
+                if (SCALED) {
+                    const float4 k0 = *reinterpret_cast<const float4*>(Ks + sl * 16 + m.xg8[i]);
+                    const float4 k1 = *reinterpret_cast<const float4*>(Ks + sl * 16 + m.xg8[i] + 4);
+                    r.xr[i][0] *= k0.x; r.xr[i][1] *= k0.y; r.xr[i][2] *= k0.z; r.xr[i][3] *= k0.w;
+                    r.xr[i][4] *= k1.x; r.xr[i][5] *= k1.y; r.xr[i][6] *= k1.z; r.xr[i][7] *= k1.w;
+                }
                 uint4 p1, p2, p3;
                 split8(r.xr[i], p1, p2, p3);
                 Xs[m.xdst[i]] = p1;
@@ -208,7 +219,7 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     const uint4* xs = Xs + lh * XROW + wn * WN * 32 + l31;
     for (int s = 0; s < nslab; ++s) {
         slab_barrier();                            // every wave is done reading the previous slab
-        lstore();                                  // slab s: registers -> LDS
+        lstore(s);                                 // slab s: registers -> LDS
         if (s + 1 < nslab) slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, s + 1);   // flies across this slab's MFMAs
         else next();
         slab_barrier();
@@ -294,7 +305,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     }
 }
 
-template <class TL, int TAPS, bool LRELU, class Epi, bool FILM>
+template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false>
 __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ? S_WPE_F : S_WPE))) void conv3s_kernel(ConvSArgs a, Epi ep) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, A_U4 = TL::a_u4(TAPS);
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s[];
@@ -344,6 +355,11 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                     Bs[2 * TL::BM + i] = ep.bsh[m];
                 }
             }
+        }
+        float* Ks = Bs + 3 * TL::BM;
+        if constexpr (SCALED) {
+            // first use is behind the first slab's barrier; the previous tile's last use is behind its last one
+            for (int i = threadIdx.x; i < a.Cin; i += TL::NTHR) Ks[i] = a.kscale[(long)b * a.Cin + i];
         }
         const int rl = wm * WM * 32 + 4 * lh;                     // local row of accumulator register r of m-tile i: rl + 32 i + (r & 3) + 8 (r >> 2)
         f32x16 acc[WM][WN];
@@ -395,7 +411,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 }
             tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
         } else {
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile);
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB, SCALED>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile, Ks);
             if constexpr (Epi::kIgemm) {
                 // plain GEMM use (B = 1, len = all columns): the igemm epilogue functors finish the element
                 const int l31 = lane & 31, wn = wave - wm * TL::NWV;
@@ -432,14 +448,15 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     }
 }
 
-template <class TL, int TAPS, bool LRELU, class Epi, bool FILM>
+template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false>
 inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
-                           const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond, long xstride = 0, int bpc = S_BPC) {
+                           const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond, long xstride = 0, int bpc = S_BPC,
+                           const float* kscale = nullptr) {
     if (Cin % 16 != 0 || (FILM && Ccond % 16 != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of 16");
     static bool ready = false;
     constexpr int lds = TL::lds_bytes(TAPS);
     if (!ready) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3s_kernel<TL, TAPS, LRELU, Epi, FILM>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv3s setup: %s", hipGetErrorString(e));
         ready = true;
@@ -447,6 +464,8 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     ConvSArgs a;
     a.A6 = reinterpret_cast<const uint4*>(w.A6);
     a.MT = w.MT6;
+    if (SCALED && (!kscale || Cin > TL::KS_MAX)) return fail(ctx, TVC_ERR_ARG, "conv3s: scaled launch needs factors for <= 768 channels");
+    a.kscale = kscale;
     a.x = x;
     a.xstride = xstride ? xstride : (long)Cin * len;
     a.Cin = Cin;
@@ -468,7 +487,7 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     }
     const int slots = ncu * bpc;                 // persistent: one resident workgroup per slot walks the tiles
     dim3 g((unsigned)(a.ntiles < slots ? a.ntiles : slots));
-    hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM>), g, dim3(TL::NTHR), lds, s, a, ep);
+    hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED>), g, dim3(TL::NTHR), lds, s, a, ep);
     return 0;
 }
 
@@ -515,10 +534,12 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
 
 // Plain GEMM on the split path: out(m, n) = sum_k W[m][k] x[b][k][t], n = b * len + t, finished by an igemm epilogue
 // functor (store(n, m, v[4])).  Cin must be a multiple of 16 and rows [K, Cin) must be readable (weights there are 0).
-template <int MTB, int NWV, int BPC, class Epi>
-inline int gemm_s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep) {
+template <int MTB, int NWV, int BPC, class Epi, bool SCALED = false>
+inline int gemm_s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
+                         const float* kscale = nullptr) {
     if (w.MT6 % MTB != 0) return fail(ctx, TVC_ERR_ARG, "gemm_s: row tiles do not divide");
-    return conv3s_launch_t<SplitTile<MTB, 1, NWV, 1>, 1, false, Epi, false>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride, BPC);
+    return conv3s_launch_t<SplitTile<MTB, 1, NWV, 1>, 1, false, Epi, false, SCALED>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride,
+                                                                                   BPC, kscale);
 }
 
 }  // namespace tvc

@@ -1,9 +1,18 @@
 // Encoder (encoder.py:75-116) and the ConvNeXt-v2 layer shared with SourceNet (convnext.py:7-58).
+#include "conv3s.h"
 #include "igemm.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
 
 namespace tvc {
+
+#ifndef TVC_SPLIT_ENC
+#define TVC_SPLIT_ENC 1   // ConvNeXt 1x1 contractions and the output projections on the split-precision bf16 path
+#endif
+#ifndef ENC_NWV
+#define ENC_NWV 4
+#define ENC_BPC 2
+#endif
 
 // -------------------------------------------------------------------------------------------------
 // [depthwise k7 dilated replicate-padded conv] + LayerNorm over channels, per time column.
@@ -121,18 +130,26 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
         hipLaunchKernelGGL((dwconv_ln_kernel<true>), dim3((T + 63) / 64, B), dim3(1024), 0, s, x, y, w.dw_w, w.dw_b, w.ln_g, w.ln_b, C, T, w.dilation);
     }
     {
-        LoadPlain ld{y, C, T, (long)C * T};
         EpiBias<ACT_GELU, false> ep{h, w.c2.bias, nullptr, C2, T, ncols, (long)C2 * T, 0};
-        igemm_launch(s, w.c2.At, w.c2.Mpad, w.c2.Kpad, ncols, T, ld, ep);
+        if (TVC_SPLIT_ENC && C % 16 == 0 && w.c2.MT6 % 2 == 0) {
+            TVC_CHECK((gemm_s_launch<2, ENC_NWV, ENC_BPC>(ctx, s, w.c2, y, B, C, T, 0, ep)));
+        } else {
+            LoadPlain ld{y, C, T, (long)C * T};
+            igemm_launch(s, w.c2.At, w.c2.Mpad, w.c2.Kpad, ncols, T, ld, ep);
+        }
     }
     {
         hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)B * C2 * 64)), dim3(256), 0, s, h, gx, (long)B * C2, T);
         hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, s, gx, w.grn_g, nx, C2);
     }
     {
-        LoadScaled ld{h, nx, C2, T};
         EpiBias<ACT_NONE, true> ep{x, w.c3_bias_grn, x, C, T, ncols, (long)C * T, (long)C * T};
-        igemm_launch(s, w.c3.At, w.c3.Mpad, w.c3.Kpad, ncols, T, ld, ep);
+        if (TVC_SPLIT_ENC && C2 % 16 == 0 && C2 <= 768 && w.c3.MT6 % 2 == 0) {
+            TVC_CHECK((gemm_s_launch<2, ENC_NWV, ENC_BPC, EpiBias<ACT_NONE, true>, true>(ctx, s, w.c3, h, B, C2, T, 0, ep, nx)));
+        } else {
+            LoadScaled ld{h, nx, C2, T};
+            igemm_launch(s, w.c3.At, w.c3.Mpad, w.c3.Kpad, ncols, T, ld, ep);
+        }
     }
     return launch_check(ctx, "convnext");
 }
@@ -227,14 +244,22 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     for (int i = 0; i < 4; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->pit_mid[i], xp, B, T));
     if (dry) return 0;
     {
-        LoadPlain ld{xs, kSslCh, T, (long)kSslCh * T};
         EpiBias<ACT_NONE, false> ep{ssl, ctx->ssl_out.bias, nullptr, kSslDim, T, ncols, (long)kSslDim * T, 0};
-        igemm_launch(s, ctx->ssl_out.At, ctx->ssl_out.Mpad, ctx->ssl_out.Kpad, ncols, T, ld, ep);
+        if (TVC_SPLIT_ENC) {
+            TVC_CHECK((gemm_s_launch<2, ENC_NWV, ENC_BPC>(ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep)));
+        } else {
+            LoadPlain ld{xs, kSslCh, T, (long)kSslCh * T};
+            igemm_launch(s, ctx->ssl_out.At, ctx->ssl_out.Mpad, ctx->ssl_out.Kpad, ncols, T, ld, ep);
+        }
     }
     {
-        LoadPlain ld{xp, kPitchCh, T, (long)kPitchCh * T};
         EpiBias<ACT_NONE, false> ep{lg, ctx->pit_out.bias, nullptr, kPitchClasses, T, ncols, (long)kPitchClasses * T, 0};
-        igemm_launch(s, ctx->pit_out.At, ctx->pit_out.Mpad, ctx->pit_out.Kpad, ncols, T, ld, ep);
+        if (TVC_SPLIT_ENC) {
+            TVC_CHECK((gemm_s_launch<2, ENC_NWV, ENC_BPC>(ctx, s, ctx->pit_out, xp, B, kPitchCh, T, 0, ep)));
+        } else {
+            LoadPlain ld{xp, kPitchCh, T, (long)kPitchCh * T};
+            igemm_launch(s, ctx->pit_out.At, ctx->pit_out.Mpad, ctx->pit_out.Kpad, ncols, T, ld, ep);
+        }
     }
     hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, lg, ctx->pitch_freq, f0, B, T);
     return launch_check(ctx, "encoder");

@@ -190,6 +190,7 @@ __device__ __forceinline__ float act_apply(float o, int act) {
 
 template <int ACT, bool RES>
 struct EpiBias {
+    static constexpr bool kIgemm = true;   // store(n, m, v[4]) interface (also usable from the split-precision kernel)
     float* y;
     const float* bias;
     const float* res;
