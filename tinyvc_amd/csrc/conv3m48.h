@@ -241,10 +241,13 @@ inline void conv3mt_launch(hipStream_t s, const PackedW& w, const float* x, int 
 #ifndef TVC_C48_NW
 #define TVC_C48_NW 8
 #endif
+#ifndef TVC_C24_TN
+#define TVC_C24_TN 2     // column tiles per wave of the 24-row (two m-tile) launches: downs.0 / downs.1 (0.605 -> 0.57 ms)
+#endif
 #ifndef TVC_C48_TN
 #define TVC_C48_TN 1     // 8 waves x 16 columns = 128-sample tiles: measured best (1.40 ms vs 1.51 for TN = 2 on ups.3)
 #endif
-    using TL = C48Tile<TVC_C48_NW, TVC_C48_TN, MT>;
+    using TL = C48Tile<TVC_C48_NW, MT == 2 ? TVC_C24_TN : TVC_C48_TN, MT>;
     Conv3Args a;
     a.At = w.At;
     a.x = x;

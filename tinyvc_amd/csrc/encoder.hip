@@ -10,6 +10,7 @@ namespace tvc {
 #define TVC_SPLIT_ENC 1   // ConvNeXt 1x1 contractions and the output projections on the split-precision bf16 path
 #endif
 #ifndef ENC_NWV
+#define ENC_MTB 2
 #define ENC_NWV 4
 #define ENC_BPC 2
 #endif
@@ -131,8 +132,8 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     }
     {
         EpiBias<ACT_GELU, false> ep{h, w.c2.bias, nullptr, C2, T, ncols, (long)C2 * T, 0};
-        if (TVC_SPLIT_ENC && C % 16 == 0 && w.c2.MT6 % 2 == 0) {
-            TVC_CHECK((gemm_s_launch<2, ENC_NWV, ENC_BPC>(ctx, s, w.c2, y, B, C, T, 0, ep)));
+        if (TVC_SPLIT_ENC && C % 16 == 0 && w.c2.MT6 % ENC_MTB == 0) {
+            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, w.c2, y, B, C, T, 0, ep)));
         } else {
             LoadPlain ld{y, C, T, (long)C * T};
             igemm_launch(s, w.c2.At, w.c2.Mpad, w.c2.Kpad, ncols, T, ld, ep);
@@ -144,8 +145,8 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     }
     {
         EpiBias<ACT_NONE, true> ep{x, w.c3_bias_grn, x, C, T, ncols, (long)C * T, (long)C * T};
-        if (TVC_SPLIT_ENC && C2 % 16 == 0 && C2 <= 768 && w.c3.MT6 % 2 == 0) {
-            TVC_CHECK((gemm_s_launch<2, ENC_NWV, ENC_BPC, EpiBias<ACT_NONE, true>, true>(ctx, s, w.c3, h, B, C2, T, 0, ep, nx)));
+        if (TVC_SPLIT_ENC && C2 % 16 == 0 && C2 <= 768 && w.c3.MT6 % ENC_MTB == 0) {
+            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC, EpiBias<ACT_NONE, true>, true>(ctx, s, w.c3, h, B, C2, T, 0, ep, nx)));
         } else {
             LoadScaled ld{h, nx, C2, T};
             igemm_launch(s, w.c3.At, w.c3.Mpad, w.c3.Kpad, ncols, T, ld, ep);
@@ -246,7 +247,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     {
         EpiBias<ACT_NONE, false> ep{ssl, ctx->ssl_out.bias, nullptr, kSslDim, T, ncols, (long)kSslDim * T, 0};
         if (TVC_SPLIT_ENC) {
-            TVC_CHECK((gemm_s_launch<2, ENC_NWV, ENC_BPC>(ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep)));
+            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep)));
         } else {
             LoadPlain ld{xs, kSslCh, T, (long)kSslCh * T};
             igemm_launch(s, ctx->ssl_out.At, ctx->ssl_out.Mpad, ctx->ssl_out.Kpad, ncols, T, ld, ep);
@@ -255,7 +256,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     {
         EpiBias<ACT_NONE, false> ep{lg, ctx->pit_out.bias, nullptr, kPitchClasses, T, ncols, (long)kPitchClasses * T, 0};
         if (TVC_SPLIT_ENC) {
-            TVC_CHECK((gemm_s_launch<2, ENC_NWV, ENC_BPC>(ctx, s, ctx->pit_out, xp, B, kPitchCh, T, 0, ep)));
+            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->pit_out, xp, B, kPitchCh, T, 0, ep)));
         } else {
             LoadPlain ld{xp, kPitchCh, T, (long)kPitchCh * T};
             igemm_launch(s, ctx->pit_out.At, ctx->pit_out.Mpad, ctx->pit_out.Kpad, ncols, T, ld, ep);
