@@ -80,7 +80,7 @@ struct ConvSArgs {
     long xstride;
     int Cin, len, dil, tiles_per_utt, ntiles;
     const float* kscale = nullptr;   // optional per-(utterance, input channel) factor applied while staging (SCALED kernels), [B][Cin]
-    const uint4* sc6 = nullptr;   // FiLM scale / shift images (1x1 over cond), FILM kernels only
+    const uint4* sc6 = nullptr;   // stacked FiLM [to_scale ; to_shift] image (1x1 over cond), FILM kernels only
     const uint4* sh6 = nullptr;
     const float* cond = nullptr;
     int Ccond = 0;
@@ -260,6 +260,100 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     }
 }
 
+// FiLM scale and shift in ONE 1x1 phase over the cond tile: the stacked [to_scale ; to_shift] weight image supplies two
+// m-tile groups (rows mt0.. and mtoff + mt0..) that share every staged input slab and every B fragment, so the cond
+// tile is loaded, split and written once instead of twice and a slab carries 12 MFMAs per wave instead of 6.
+template <class TL>
+__device__ __forceinline__ void film_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ F6, int MT, int mt0, int mtoff,
+                                          const float* __restrict__ xb, int len, int s) {
+    constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER;
+    constexpr int PIECES = 2 * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
+    static_assert(A_PER <= SlabRegs<TL>::A_MAX, "FiLM weight pieces must fit the staging registers");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (!(S_ABL & 2)) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int q = wave + i * NW;
+            q = q < PIECES ? q : PIECES - 1;
+            const int grp = q / (MTB * 3), rem = q - grp * (MTB * 3);
+            r.ar[i] = *reinterpret_cast<const u32x4*>(F6 + (((long)s * MT + mt0 + grp * mtoff) * 192 + rem * 64) + lane);
+        }
+    }
+    if (S_ABL & 4) return;
+    const float* xc = xb + (long)s * 16 * len;
+#pragma unroll
+    for (int i = 0; i < X_PER; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.xr[i][j] = xc[m.xo[i] + (unsigned)(j * len)];
+}
+template <class TL>
+__device__ __forceinline__ void film_first_load(SlabRegs<TL>& r, const uint4* __restrict__ F6, int MT, int mt0, int mtoff,
+                                                const float* __restrict__ xb, int len, int t0) {
+    SlabMap<TL> m;
+    make_map<TL>(m, len, 0, t0);
+    film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, 0);
+}
+template <class TL, class Next>
+__device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16 (&ash)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ F6,
+                                           int MT, int mt0, int mtoff, const float* __restrict__ xb, int Cin, int len, int t0, uint4* As, uint4* Xs,
+                                           Next next) {
+    constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
+    constexpr int PIECES = 2 * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / NWV, wn = wave - wm * NWV;
+    SlabMap<TL> m;
+    make_map<TL>(m, len, 0, t0);
+    const int nslab = Cin / 16;
+    const uint4* as = As + wm * WM * 192 + lane;
+    const uint4* xs = Xs + lh * XROW + wn * WN * 32 + l31;
+    for (int s = 0; s < nslab; ++s) {
+        slab_barrier();
+        if (!(S_ABL & 2)) {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int q = wave + i * NW;
+                if (q < PIECES) *reinterpret_cast<u32x4*>(As + q * 64 + lane) = r.ar[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < X_PER; ++i)
+            if (m.xdst[i] >= 0 && !(S_ABL & 8)) {
+                uint4 p1, p2, p3;
+                split8(r.xr[i], p1, p2, p3);
+                Xs[m.xdst[i]] = p1;
+                Xs[2 * XROW + m.xdst[i]] = p2;
+                Xs[4 * XROW + m.xdst[i]] = p3;
+            }
+        if (s + 1 < nslab) film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, s + 1);
+        else next();
+        slab_barrier();
+        bf16x8 fc[WM][3], fh[WM][3], bf[WN][3];
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[j][p] = __builtin_bit_cast(bf16x8, xs[2 * p * XROW + j * 32]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                fc[i][p] = __builtin_bit_cast(bf16x8, as[(i * 3 + p) * 64]);
+                fh[i][p] = __builtin_bit_cast(bf16x8, as[(MTB * 3 + i * 3 + p) * 64]);
+            }
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    if (!(S_ABL & 1) || q == 0) {
+                        asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[i][PA[q]], bf[j][PB[q]], asc[i][j], 0, 0, 0);
+                        ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i][PA[q]], bf[j][PB[q]], ash[i][j], 0, 0, 0);
+                    }
+    }
+}
+
 // Output tile -> HBM through LDS: the accumulator layout gives a lane one sample of 16 different rows (4-byte
 // stores, 128 B per row and instruction); parked as Ot[row][sample] the tile leaves as 16-byte stores (and the
 // residual arrives as 16-byte loads) along time.  v already holds everything but the residual.
@@ -371,43 +465,30 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         if constexpr (FILM) {
-            // conv -> FiLM -> + residual (decoder.py:94-97,181-182): scale and shift are two more 1x1 phases over
-            // cond on the same tiles; the conv result is folded with the scale before the shift phase runs, so
-            // at most two accumulator sets are live.
+            // conv -> FiLM -> + residual (decoder.py:94-97,181-182): scale and shift come from one more 1x1 phase over
+            // the cond tile on the same output tiles; (conv, scale, shift) combine in registers.
             const float* cb = a.cond + (long)b * a.Ccond * len;
+            const int mtoff = a.MT;                                   // the stacked FiLM image has 2 * a.MT m-tiles: scale rows, then shift rows
             split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
-                                               [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0); });
-            f32x16 a2[WM][WN];
-            auto zero2 = [&]() __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) a2[i][j][r] = 0.f;
-            };
-            zero2();
-            split_phase<TL, 1, A_U4, false, FILM ? S_FB_F : S_FB>(a2, regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs,
-                                            [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sh6, a.MT, mt0, cb, a.Ccond, len, 0, t0); });
+                                               [&]() __attribute__((always_inline)) { film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, len, t0); });
+            f32x16 asc[WM][WN], ash[WM][WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rl + i * 32 + (r & 3) + 8 * (r >> 2);
-                    const float bm = Bs[row], bs = Bs[TL::BM + row];
+                for (int j = 0; j < WN; ++j)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) acc[i][j][r] = __fmul_rn(acc[i][j][r] + bm, a2[i][j][r] + bs);
-                }
-            zero2();
-            split_phase<TL, 1, A_U4, false, FILM ? S_FB_F : S_FB>(a2, regs, a.sh6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile);
+                    for (int r = 0; r < 16; ++r) asc[i][j][r] = ash[i][j][r] = 0.f;
+            film_phase<TL>(asc, ash, regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, a.Ccond, len, t0, As, Xs, load_next_tile);
             // out = ((h + b)(sc + b_sc)) + (sh + b_sh), + residual in the vector pass
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float bh = Bs[2 * TL::BM + rl + i * 32 + (r & 3) + 8 * (r >> 2)];
+                    const int row = rl + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const float bm = Bs[row], bs = Bs[TL::BM + row], bh = Bs[2 * TL::BM + row];
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) acc[i][j][r] = __fadd_rn(acc[i][j][r], a2[i][j][r] + bh);
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j][r] = __fadd_rn(__fmul_rn(acc[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
                 }
             tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
         } else {
@@ -473,8 +554,9 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     a.dil = dil;
     a.tiles_per_utt = (len + TL::BN - 1) / TL::BN;
     if (FILM) {
-        a.sc6 = reinterpret_cast<const uint4*>(wsc->A6);
-        a.sh6 = reinterpret_cast<const uint4*>(wsh->A6);
+        if (wsc->MT6 != 2 * w.MT6) return fail(ctx, TVC_ERR_ARG, "conv3s: FiLM image must stack scale and shift rows");
+        a.sc6 = reinterpret_cast<const uint4*>(wsc->A6);   // stacked [to_scale ; to_shift] image (wsh unused)
+        a.sh6 = nullptr;
         a.cond = cond;
         a.Ccond = Ccond;
     }

@@ -390,9 +390,10 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 }
                 if (TVC_SPLIT && C % 96 == 0) {
                     TVC_CHECK(conv3s_launch<true>(ctx, s, ca, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo}));
+                    const PackedW& fw = half ? u.film2 : u.film1;      // stacked [to_scale ; to_shift] rows
                     TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
                                                                           C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
-                                                                          &wsc, &wsh, cond, C)));
+                                                                          &fw, &fw, cond, C)));
                     continue;
                 }
                 conv3_launch<true>(s, ca.At, ca.Mpad, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo});
