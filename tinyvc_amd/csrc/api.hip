@@ -89,7 +89,9 @@ struct Packer {
         }
         fix.push_back({&pw->At, ab.put(At)});
         fix.push_back({&pw->bias, ab.put(bias)});
-        a6(pw, At);
+        bool equal_groups = ws.size() > 1;
+        for (auto* w : ws) equal_groups = equal_groups && w->shape[0] == ws[0]->shape[0];
+        a6(pw, At, equal_groups ? (int)ws[0]->shape[0] : 0);
         if (taps > 1) {   // tap-major copy: row (tap*cin + ci)
             std::vector<float> Att((size_t)pw->Kpad * pw->Mpad, 0.f);
             for (int ci = 0; ci < cin; ++ci)
@@ -104,7 +106,8 @@ struct Packer {
     // bf16x3 split image of At for conv3s.h: [step = slab*taps + tap][m-tile][part][lane][8 bf16],
     // lane -> row m = 32*mt + (lane & 31), channel ci = 16*slab + 8*(lane >> 5) + j.  x = p1 + p2 + p3 with
     // round-to-nearest-even parts; both residuals are exact in fp32.
-    void a6(PackedW* pw, const std::vector<float>& At) {
+    // group_rows > 0: the M rows are `M / group_rows` stacked groups (FiLM scale ; shift), each padded to whole 32-row tiles
+    void a6(PackedW* pw, const std::vector<float>& At, int group_rows = 0) {
         auto to_bf16 = [](float f) -> uint16_t {
             uint32_t u;
             std::memcpy(&u, &f, 4);
@@ -117,7 +120,9 @@ struct Packer {
             std::memcpy(&f, &u, 4);
             return f;
         };
-        const int taps = pw->taps, cin = pw->cin, MT = pw->Mpad / 32, nslab = (cin + 15) / 16;
+        const int taps = pw->taps, cin = pw->cin, nslab = (cin + 15) / 16;
+        const int gp = group_rows > 0 ? (group_rows + 31) / 32 * 32 : 0;
+        const int MT = group_rows > 0 ? (pw->M / group_rows) * gp / 32 : pw->Mpad / 32;
         std::vector<float> img((size_t)nslab * taps * MT * 3 * 256, 0.f);
         uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
         for (int s = 0; s < nslab; ++s)
@@ -126,6 +131,10 @@ struct Packer {
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 8; ++j) {
                             int ci = s * 16 + 8 * (lane >> 5) + j, m = mt * 32 + (lane & 31);
+                            if (group_rows > 0) {
+                                const int g = m / gp, mi = m - g * gp;
+                                m = mi < group_rows ? g * group_rows + mi : pw->M;   // padding row
+                            }
                             float w = (ci < cin && m < pw->M) ? At[(size_t)(ci * taps + tap) * pw->Mpad + m] : 0.f;
                             uint16_t h1 = to_bf16(w);
                             float r = w - from_bf16(h1);

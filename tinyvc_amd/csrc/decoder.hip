@@ -260,7 +260,7 @@ static void conv_launch(hipStream_t s, const PackedW& w, const float* x, int cin
 #define TVC_SPLIT 1
 #endif
 #ifndef TVC_SPLIT48
-#define TVC_SPLIT48 0   // 1: 48-channel levels on the split path too (2: also downs.1's 24 -> 48 conv); measured 10 % slower than the exact 16x16x4 fp32 tiles (row padding 48 -> 64, HBM-heavier level)
+#define TVC_SPLIT48 1   // 48-channel levels on the split path too (rows padded 48 -> 64; with the stacked FiLM phase ups.3 1.49 -> 1.25 ms)
 #endif
 
 static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
@@ -297,8 +297,10 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
             static const char* names[4] = {"filter.down1", "filter.down2", "filter.down3", "filter.down4"};
             ProfScope ps(ctx, s, dry, names[i - 1]);
             // F.interpolate(scale_factor=1/f): ATen uses scale = 1/(1/f) = f
-            hipLaunchKernelGGL(lerp_resize_kernel, dim3(grid_for((long)B * d.cin * len)), dim3(256), 0, s, skip[i - 1], xi,
-                               (long)B * d.cin, lin, len, (float)d.factor);
+            {
+                const LerpLaunch ll = lerp_launch((long)B * d.cin, len);
+                hipLaunchKernelGGL(lerp_resize_kernel, ll.grid, dim3(256), 0, s, skip[i - 1], xi, (long)B * d.cin, lin, len, (float)d.factor, ll.tx);
+            }
             const int nc = B * len;
             {
                 LoadPlain ld{xi, d.cin, len, (long)d.cin * len};
@@ -363,8 +365,10 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
             static const char* names[5] = {"filter.up0", "filter.up1", "filter.up2", "filter.up3", "filter.up4"};
             ProfScope ps(ctx, s, dry, names[i]);
             // F.interpolate(scale_factor=f): ATen uses scale = float(1/f)
-            hipLaunchKernelGGL(lerp_resize_kernel, dim3(grid_for((long)B * C * lo)), dim3(256), 0, s, x, xu, (long)B * C, lin, lo,
-                               (float)(1.0 / (double)u.factor));
+            {
+                const LerpLaunch ll = lerp_launch((long)B * C, lo);
+                hipLaunchKernelGGL(lerp_resize_kernel, ll.grid, dim3(256), 0, s, x, xu, (long)B * C, lin, lo, (float)(1.0 / (double)u.factor), ll.tx);
+            }
             for (int half = 0; half < 2; ++half) {
                 const PackedW& ca = half ? u.c3 : u.c1;
                 const PackedW& cb = half ? u.c4 : u.c2;
@@ -375,9 +379,10 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 const PackedW& wsh = half ? u.sh2 : u.sh1;
                 if (C == 48 && TVC_SPLIT48) {
                     TVC_CHECK(conv3s_launch<true>(ctx, s, ca, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo}));
+                    const PackedW& fw48 = half ? u.film2 : u.film1;    // stacked, each group padded to whole 32-row tiles
                     TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
                                                                           C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
-                                                                          &wsc, &wsh, cond, C)));
+                                                                          &fw48, &fw48, cond, C)));
                     continue;
                 }
                 if (C == 48 && TVC_USE_C48) {

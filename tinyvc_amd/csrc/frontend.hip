@@ -113,7 +113,10 @@ int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, 
     hipLaunchKernelGGL(energy_pool_kernel, dim3(grid_for((long)B * ne * 64)), dim3(256), 0, s, wav, e, B, (int)L, ne);
     // F.interpolate(e, L): `size` given -> scale = float(in) / float(out)
     float scale = (float)ne / (float)L;
-    hipLaunchKernelGGL(lerp_resize_kernel, dim3(grid_for((long)B * L)), dim3(256), 0, s, e, energy, (long)B, ne, (int)L, scale);
+    {
+        const LerpLaunch ll = lerp_launch((long)B, (int)L);
+        hipLaunchKernelGGL(lerp_resize_kernel, ll.grid, dim3(256), 0, s, e, energy, (long)B, ne, (int)L, scale, ll.tx);
+    }
     return launch_check(ctx, "energy");
 }
 

@@ -30,16 +30,47 @@ __device__ __forceinline__ float lerp_eval(const Lerp& c, float x0, float x1) {
 }
 
 // y[row][d] = lerp(x[row][:]) — F.interpolate(mode='linear') on `rows` independent rows.
-static __global__ void lerp_resize_kernel(const float* __restrict__ x, float* __restrict__ y, long rows,
-                                          int n_in, int n_out, float scale) {
-    long total = rows * (long)n_out;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long row = i / n_out;
-        int d = (int)(i - row * n_out);
-        Lerp c = lerp_coord(d, scale, n_in);
+// A thread owns 4 consecutive outputs: their source coordinates depend on d only, so they are computed once and
+// reused for every row the thread walks (blockIdx.y strides the rows); outputs leave as one 16-byte store.
+static __global__ __launch_bounds__(256) void lerp_resize_kernel(const float* __restrict__ x, float* __restrict__ y, long rows,
+                                                                 int n_in, int n_out, float scale, int tx) {
+    // tx (power of two <= 256) threads span a row's 4-output groups, the other 256 / tx thread rows take different rows
+    const int sx = threadIdx.x & (tx - 1), sy = threadIdx.x / tx, ny = 256 / tx;
+    const int d0 = (blockIdx.x * tx + sx) * 4;
+    if (d0 >= n_out) return;
+    Lerp c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = lerp_coord(d0 + u < n_out ? d0 + u : n_out - 1, scale, n_in);
+    const bool vec = (n_out & 3) == 0;                 // rows stay 16-byte aligned
+    for (long row = (long)blockIdx.y * ny + sy; row < rows; row += (long)gridDim.y * ny) {
         const float* xr = x + row * n_in;
-        y[i] = lerp_eval(c, xr[c.i0], xr[c.i1]);
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = lerp_eval(c[u], xr[c[u].i0], xr[c[u].i1]);
+        float* yr = y + row * n_out + d0;
+        if (vec) {
+            *reinterpret_cast<float4*>(yr) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (d0 + u < n_out) yr[u] = o[u];
+        }
     }
+}
+struct LerpLaunch {
+    dim3 grid;
+    int tx;
+};
+inline LerpLaunch lerp_launch(long rows, int n_out) {
+    const int groups = (n_out + 3) / 4;
+    int tx = 256;
+    while (tx > 16 && tx / 2 >= groups) tx /= 2;
+    const unsigned gx = (unsigned)((groups + tx - 1) / tx);
+    const int ny = 256 / tx;
+    long gy = (rows + ny - 1) / ny;
+    const long want = 256L * 16 / (gx ? gx : 1);       // ~16 workgroups per CU in flight
+    if (gy > want) gy = want < 1 ? 1 : want;
+    return {dim3(gx, (unsigned)gy), tx};
 }
 
 // max over consecutive windows: y[row][j] = max_{i<win} x[row][j*win + i]   (F.max_pool1d(k=win, s=win))
