@@ -9,6 +9,9 @@
 
 namespace tvc {
 
+#ifndef TVC_SPLIT_1X1
+#define TVC_SPLIT_1X1 0    // 1: FilterNet's 1x1 convs (Downsample.res, Upsample.c5) on the split-precision path too (measured time-neutral)
+#endif
 #ifndef TVC_SPLIT_IDFT
 #define TVC_SPLIT_IDFT 1   // inverse DFT GEMMs of the noise branch on the split-precision path
 #endif
@@ -303,9 +306,13 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
             }
             const int nc = B * len;
             {
-                LoadPlain ld{xi, d.cin, len, (long)d.cin * len};
                 EpiBias<ACT_NONE, false> ep{res, d.res.bias, nullptr, d.cout, len, nc, (long)d.cout * len, 0};
-                igemm_launch(s, d.res.At, d.res.Mpad, d.res.Kpad, nc, len, ld, ep);
+                if (TVC_SPLIT_1X1 && d.cin % 16 == 0 && d.res.MT6 % 3 == 0) {
+                    TVC_CHECK((gemm_s_launch<3, 4, 1>(ctx, s, d.res, xi, B, d.cin, len, 0, ep)));
+                } else {
+                    LoadPlain ld{xi, d.cin, len, (long)d.cin * len};
+                    igemm_launch(s, d.res.At, d.res.Mpad, d.res.Kpad, nc, len, ld, ep);
+                }
             }
             if (d.cin == 24 && TVC_USE_C48) {   // 24 output channels = two 16-row tiles, many small waves
                 conv3mt_launch<2, true>(s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
@@ -417,9 +424,15 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                     conv3_launch<true>(s, cb.At, cb.Mpad, h, B, C, lo, db, C3EpiFilm{xout, cb.bias, film, xin, C, lo});
                 }
             }
-            LoadPlain ld{xu, C, lo, (long)C * lo};
             EpiBias<ACT_NONE, false> ep{xlev[i], u.c5.bias, nullptr, u.cout, lo, nc, (long)u.cout * lo, 0};
-            igemm_launch(s, u.c5.At, u.c5.Mpad, u.c5.Kpad, nc, lo, ld, ep);
+            if (TVC_SPLIT_1X1 && C % 16 == 0 && u.c5.MT6 % 3 == 0) {
+                TVC_CHECK((gemm_s_launch<3, 4, 1>(ctx, s, u.c5, xu, B, C, lo, 0, ep)));
+            } else if (TVC_SPLIT_1X1 && C % 16 == 0 && u.c5.MT6 % 2 == 0) {
+                TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, u.c5, xu, B, C, lo, 0, ep)));
+            } else {
+                LoadPlain ld{xu, C, lo, (long)C * lo};
+                igemm_launch(s, u.c5.At, u.c5.Mpad, u.c5.Kpad, nc, lo, ld, ep);
+            }
         }
         ws.release(mk);
         x = xlev[i];
