@@ -40,7 +40,8 @@ def test_ctypes_table_matches_header(lib):
 
 def test_version_and_null_safety(lib):
     assert lib.tvc_version() == 1
-    assert lib.tvc_knn_prepared_elems(1000) == 768 * 1024 + 1000 * 768
+    # normalised columns [768][Npad] + raw rows [N][768] + the bf16x3 image of the normalised columns (1.5 floats per value)
+    assert lib.tvc_knn_prepared_elems(1000) == 768 * 1024 + 1000 * 768 + 768 * 1024 * 3 // 2
     assert lib.tvc_knn_prepared_elems(0) == 0
     # argument validation happens before any device work
     assert lib.tvc_finalize_weights(None) == -1
