@@ -37,6 +37,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef S_WPE_F
 #define S_WPE_F 3
 #endif
+#ifndef TVC_S_FLAT
+#define TVC_S_FLAT 1   // GEMM launches tile the flattened B * T column axis instead of every utterance separately
+#endif
 #ifndef S_BPC
 #define S_BPC 1     // persistent workgroups per CU
 #endif
@@ -61,7 +64,7 @@ struct SplitTile {
     static constexpr int X_U4 = 3 * 2 * XROW;
     static constexpr int X_PER = (2 * XROW + NTHR - 1) / NTHR;                  // staging items per thread
     static constexpr int a_u4(int taps) { return taps * MTB * 3 * 64; }
-    static constexpr int KS_MAX = 768;                                          // input channels of a SCALED launch
+    static constexpr int KS_MAX = 2 * 768;                                      // SCALED launch: factors of <= 768 input channels for the <= 2 utterances a tile touches
     static constexpr int OS = BN + 4;                                           // row stride (floats) of the output tile parked in LDS
     static constexpr int lds_bytes(int taps) {
         const int stage = (a_u4(taps) + X_U4) * 16, out = BM * OS * 4;
@@ -79,6 +82,7 @@ struct ConvSArgs {
     const float* x;      // [B][Cin][len], utterance b at x + b * xstride
     long xstride;
     int Cin, len, dil, tiles_per_utt, ntiles;
+    int flatT = 0;       // > 0: flat GEMM tiles over the B * flatT columns (len = B * flatT, B = 1 for the tile walk)
     const float* kscale = nullptr;   // optional per-(utterance, input channel) factor applied while staging (SCALED kernels), [B][Cin]
     const uint4* sc6 = nullptr;   // stacked FiLM [to_scale ; to_shift] image (1x1 over cond), FILM kernels only
     const uint4* sh6 = nullptr;
@@ -121,9 +125,12 @@ struct SlabMap {
     unsigned xo[TL::X_PER];    // utterance-relative element offset of (channel 8 g, position p)
     int xdst[TL::X_PER];       // LDS row of the item, -1 = idle
     int xg8[TL::X_PER];        // first channel of the item inside the slab (0 or 8)
+    int xk[TL::X_PER];         // flat GEMM tiles: factor-row offset of the item's utterance inside the staged Ks
 };
+// fT > 0 = flat GEMM tiles: the tile's columns are positions n = b * fT + t of the flattened [B * fT] axis (len = B * fT),
+// utterance b starts at element b * fstride, channels are fT apart; a tile may straddle utterances.
 template <class TL>
-__device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t0) {
+__device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t0, int fT = 0, unsigned fstride = 0, int kcin = 0) {
     const int xw = TL::BN + 2 * dil;
 #pragma unroll
     for (int i = 0; i < TL::X_PER; ++i) {
@@ -134,14 +141,22 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
         m.xdst[i] = g < 2 ? g * TL::XROW + c : -1;
         g = g < 2 ? g : 1;                                   // idle items still load (valid address), never store
         m.xg8[i] = 8 * g;
-        m.xo[i] = (unsigned)(8 * g * len + p);
+        if (fT > 0) {
+            const int b = p / fT, t = p - b * fT;
+            m.xo[i] = (unsigned)b * fstride + (unsigned)(8 * g * fT + t);
+            m.xk[i] = (b - t0 / fT) * kcin;
+        } else {
+            m.xo[i] = (unsigned)(8 * g * len + p);
+            m.xk[i] = 0;
+        }
     }
 }
 // global -> registers only (no use of the values here: the loads stay in flight behind the MFMAs)
 template <class TL, int TAPS>
 __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ A6, int MT, int mt0,
-                                          const float* __restrict__ xb, int Cin, int len, int s) {
+                                          const float* __restrict__ xb, int Cin, int len, int s, int fT = 0) {
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER;
+    const int cs = fT > 0 ? fT : len;                    // channel stride
     constexpr int PIECES = TAPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ci0 = s * 16;
@@ -156,20 +171,20 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
         }
     }
     if (S_ABL & 4) return;
-    const float* xc = xb + (long)ci0 * len;              // uniform base, 32-bit lane offsets
+    const float* xc = xb + (long)ci0 * cs;               // uniform base, 32-bit lane offsets
     // Cin % 16 == 0 is a launch precondition (every level routed here has 48/96/192/384 channels): no ragged slab
 #pragma unroll
     for (int i = 0; i < X_PER; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.xr[i][j] = xc[m.xo[i] + (unsigned)(j * len)];
+        for (int j = 0; j < 8; ++j) r.xr[i][j] = xc[m.xo[i] + (unsigned)(j * cs)];
 }
 // slab 0 of a phase, issued by whoever runs before it (previous phase / previous tile / kernel entry)
 template <class TL, int TAPS>
 __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0, const float* __restrict__ xb,
-                                           int Cin, int len, int dil, int t0) {
+                                           int Cin, int len, int dil, int t0, int fT = 0, unsigned fstride = 0) {
     SlabMap<TL> m;
-    make_map<TL>(m, len, dil, t0);
-    slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, 0);
+    make_map<TL>(m, len, dil, t0, fT, fstride);
+    slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT);
 }
 
 // acc += W (.) x over all slabs of one input tensor.  Slab 0 is already in flight in `r` (first_load); `next()`
@@ -177,13 +192,13 @@ __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restr
 template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, class Next>
 __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
                                             const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next,
-                                            const float* Ks = nullptr) {
+                                            const float* Ks = nullptr, int fT = 0, unsigned fstride = 0) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NWV, wn = wave - wm * NWV;
     SlabMap<TL> m;
-    make_map<TL>(m, len, dil, t0);
+    make_map<TL>(m, len, dil, t0, fT, fstride, Cin);
     constexpr int PIECES = TAPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
     auto lstore = [&](int sl) __attribute__((always_inline)) {
         if (!(S_ABL & 2)) {
@@ -201,8 +216,8 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
                     for (int j = 0; j < 8; ++j) r.xr[i][j] = fmaxf(r.xr[i][j], 0.1f * r.xr[i][j]);   // = leaky_relu(x, 0.1)
                 }
                 if (SCALED) {
-                    const float4 k0 = *reinterpret_cast<const float4*>(Ks + sl * 16 + m.xg8[i]);
-                    const float4 k1 = *reinterpret_cast<const float4*>(Ks + sl * 16 + m.xg8[i] + 4);
+                    const float4 k0 = *reinterpret_cast<const float4*>(Ks + m.xk[i] + sl * 16 + m.xg8[i]);
+                    const float4 k1 = *reinterpret_cast<const float4*>(Ks + m.xk[i] + sl * 16 + m.xg8[i] + 4);
                     r.xr[i][0] *= k0.x; r.xr[i][1] *= k0.y; r.xr[i][2] *= k0.z; r.xr[i][3] *= k0.w;
                     r.xr[i][4] *= k1.x; r.xr[i][5] *= k1.y; r.xr[i][6] *= k1.z; r.xr[i][7] *= k1.w;
                 }
@@ -220,7 +235,7 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     for (int s = 0; s < nslab; ++s) {
         slab_barrier();                            // every wave is done reading the previous slab
         lstore(s);                                 // slab s: registers -> LDS
-        if (s + 1 < nslab) slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, s + 1);   // flies across this slab's MFMAs
+        if (s + 1 < nslab) slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT);   // flies across this slab's MFMAs
         else next();
         slab_barrier();
         // fragments of tap t+1 are read while the MFMAs of tap t run
@@ -425,17 +440,19 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     SlabRegs<TL> regs;
     int tile = blockIdx.x, mt0, b, t0;
     coords(tile, mt0, b, t0);
-    first_load<TL, TAPS>(regs, a.A6, a.MT, mt0, a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0);
+    const int fT = a.flatT;
+    const unsigned fstride = (unsigned)a.xstride;
+    first_load<TL, TAPS>(regs, a.A6, a.MT, mt0, fT ? a.x : a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0, fT, fstride);
     while (tile < ntiles) {
         const int nxt = tile + gridDim.x;
         auto load_next_tile = [&]() __attribute__((always_inline)) {
             if (nxt < ntiles) {
                 int mt0n, bn, t0n;
                 coords(nxt, mt0n, bn, t0n);
-                first_load<TL, TAPS>(regs, a.A6, a.MT, mt0n, a.x + (long)bn * a.xstride, a.Cin, len, a.dil, t0n);
+                first_load<TL, TAPS>(regs, a.A6, a.MT, mt0n, fT ? a.x : a.x + (long)bn * a.xstride, a.Cin, len, a.dil, t0n, fT, fstride);
             }
         };
-        const float* xb = a.x + (long)b * a.xstride;
+        const float* xb = fT ? a.x : a.x + (long)b * a.xstride;
         // this tile's bias rows -> LDS: read back with ds_read (lgkmcnt), so the epilogue math never waits on vmcnt
         // while the next phase's prefetch is in flight (a global bias load would drag that whole prefetch with it)
         float* Bs = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS);
@@ -453,7 +470,9 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         float* Ks = Bs + 3 * TL::BM;
         if constexpr (SCALED) {
             // first use is behind the first slab's barrier; the previous tile's last use is behind its last one
-            for (int i = threadIdx.x; i < a.Cin; i += TL::NTHR) Ks[i] = a.kscale[(long)b * a.Cin + i];
+            const int b0 = fT ? t0 / fT : b;                      // flat tiles: the (at most two) utterances this tile touches
+            const int nrow = fT ? ((t0 + TL::BN - 1 < len ? t0 + TL::BN - 1 : len - 1) / fT - b0 + 1) * a.Cin : a.Cin;
+            for (int i = threadIdx.x; i < nrow; i += TL::NTHR) Ks[i] = a.kscale[(long)b0 * a.Cin + i];
         }
         const int rl = wm * WM * 32 + 4 * lh;                     // local row of accumulator register r of m-tile i: rl + 32 i + (r & 3) + 8 (r >> 2)
         f32x16 acc[WM][WN];
@@ -492,7 +511,8 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 }
             tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
         } else {
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB, SCALED>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile, Ks);
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB, SCALED>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile, Ks, fT,
+                                                                             fstride);
             if constexpr (Epi::kIgemm) {
                 // plain GEMM use (B = 1, len = all columns): the igemm epilogue functors finish the element
                 const int l31 = lane & 31, wn = wave - wm * TL::NWV;
@@ -532,7 +552,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
 template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false>
 inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
                            const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond, long xstride = 0, int bpc = S_BPC,
-                           const float* kscale = nullptr) {
+                           const float* kscale = nullptr, bool flat = false) {
     if (Cin % 16 != 0 || (FILM && Ccond % 16 != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of 16");
     static bool ready = false;
     constexpr int lds = TL::lds_bytes(TAPS);
@@ -545,14 +565,20 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     ConvSArgs a;
     a.A6 = reinterpret_cast<const uint4*>(w.A6);
     a.MT = w.MT6;
-    if (SCALED && (!kscale || Cin > TL::KS_MAX)) return fail(ctx, TVC_ERR_ARG, "conv3s: scaled launch needs factors for <= 768 channels");
+    if (SCALED && (!kscale || Cin > 768)) return fail(ctx, TVC_ERR_ARG, "conv3s: scaled launch needs factors for <= 768 channels");
     a.kscale = kscale;
     a.x = x;
     a.xstride = xstride ? xstride : (long)Cin * len;
     a.Cin = Cin;
     a.len = len;
     a.dil = dil;
-    a.tiles_per_utt = (len + TL::BN - 1) / TL::BN;
+    if (flat) {   // GEMM over the flattened B * len columns: no partial tile per utterance
+        if (FILM || TAPS != 1 || dil != 0) return fail(ctx, TVC_ERR_ARG, "conv3s: flat tiles are for plain GEMMs");
+        a.flatT = len;
+        a.len = B * len;
+        B = 1;
+    }
+    a.tiles_per_utt = (a.len + TL::BN - 1) / TL::BN;
     if (FILM) {
         if (wsc->MT6 != 2 * w.MT6) return fail(ctx, TVC_ERR_ARG, "conv3s: FiLM image must stack scale and shift rows");
         a.sc6 = reinterpret_cast<const uint4*>(wsc->A6);   // stacked [to_scale ; to_shift] image (wsh unused)
@@ -620,8 +646,12 @@ template <int MTB, int NWV, int BPC, class Epi, bool SCALED = false>
 inline int gemm_s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
                          const float* kscale = nullptr) {
     if (w.MT6 % MTB != 0) return fail(ctx, TVC_ERR_ARG, "gemm_s: row tiles do not divide");
-    return conv3s_launch_t<SplitTile<MTB, 1, NWV, 1>, 1, false, Epi, false, SCALED>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride,
-                                                                                   BPC, kscale);
+    using TL = SplitTile<MTB, 1, NWV, 1>;
+    // flat column tiles unless a tile could touch more than two utterances of a SCALED launch (factors of two are staged)
+    // or the element offsets would not fit 32 bits
+    const long xs = xstride ? xstride : (long)Cin * len;
+    const bool flat = TVC_S_FLAT && B > 1 && xs * B < (1L << 31) && (!SCALED || len >= TL::BN);
+    return conv3s_launch_t<TL, 1, false, Epi, false, SCALED>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride, BPC, kscale, flat);
 }
 
 }  // namespace tvc
