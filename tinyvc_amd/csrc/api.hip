@@ -264,6 +264,12 @@ int tvc_ctx_create(int hip_device, tvc_ctx** out) {
         }
         for (auto& f : pk.fix) *f.slot = c->const_arena + f.off;
     }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        tvc_ctx_destroy(c);
+        return TVC_ERR_HIP;
+    }
     *out = c;
     return TVC_OK;
 }
@@ -276,6 +282,9 @@ void tvc_ctx_destroy(tvc_ctx* ctx) {
         if (r.b) (void)hipEventDestroy(r.b);
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->const_arena) (void)hipFree(ctx->const_arena);
     delete ctx;

@@ -37,6 +37,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef S_WPE_F
 #define S_WPE_F 3
 #endif
+#ifndef TVC_S_MTB2
+#define TVC_S_MTB2 0
+#endif
 #ifndef TVC_S_FLAT
 #define TVC_S_FLAT 1   // GEMM launches tile the flattened B * T column axis instead of every utterance separately
 #endif
@@ -636,6 +639,8 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
     }
     if constexpr (FILM)
         return conv3s_launch_t<SplitTile<3, TVC_SF_WM, TVC_SF_NWV, TVC_SF_WN>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond);
+    else if (TVC_S_MTB2 && w.MT6 % 2 == 0)   // 192 / 384 rows: 8-wave workgroups of two m-tiles, two per CU
+        return conv3s_launch_t<SplitTile<2, 1, 4, 1>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, 2);
     else
         return conv3s_launch_t<SplitTile<3, TVC_S_WM, TVC_S_NWV, TVC_S_WN>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond);
 }

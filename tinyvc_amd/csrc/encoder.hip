@@ -6,6 +6,9 @@
 
 namespace tvc {
 
+#ifndef TVC_ENC_FORK
+#define TVC_ENC_FORK 1    // pitch estimator on the side stream, beside the SSL chain
+#endif
 #ifndef TVC_SPLIT_ENC
 #define TVC_SPLIT_ENC 1   // ConvNeXt 1x1 contractions and the output projections on the split-precision bf16 path
 #endif
@@ -241,8 +244,34 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
         TVC_CHECK(run_layernorm(ctx, s, xs, ctx->ssl_ln_g, ctx->ssl_ln_b, B, kSslCh, T));
         TVC_CHECK(run_layernorm(ctx, s, xp, ctx->pit_ln_g, ctx->pit_ln_b, B, kPitchCh, T));
     }
-    for (int i = 0; i < 6; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->ssl_mid[i], xs, B, T));
-    for (int i = 0; i < 4; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->pit_mid[i], xp, B, T));
+    // The pitch estimator (4 narrow ConvNeXt layers + logits + decode) and the SSL chain are independent after the
+    // stacked input 1x1: fork the pitch chain onto the context's side stream and join before returning, so its
+    // small launches fill the gaps of the SSL chain instead of extending the critical path.  Each chain gets its own
+    // scratch block (the per-layer mark/release scratch would alias otherwise).
+    const size_t ssl_scratch = ((size_t)B * kSslCh * T * 3 + (size_t)B * kSslCh * 4) * sizeof(float) + 4096;
+    char* ssl_blk = ws.get<char>(ssl_scratch);
+    Ws wssl(ssl_blk, ssl_scratch, dry);
+    hipStream_t sp = s;
+    const bool fork = TVC_ENC_FORK && !dry && ctx->side;
+    if (fork) {
+        TVC_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
+        TVC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        sp = ctx->side;
+    }
+    for (int i = 0; i < 4; ++i) TVC_CHECK(run_convnext(ctx, sp, ws, dry, ctx->pit_mid[i], xp, B, T));
+    if (!dry) {
+        EpiBias<ACT_NONE, false> ep{lg, ctx->pit_out.bias, nullptr, kPitchClasses, T, ncols, (long)kPitchClasses * T, 0};
+        if (TVC_SPLIT_ENC) {
+            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep)));
+        } else {
+            LoadPlain ld{xp, kPitchCh, T, (long)kPitchCh * T};
+            igemm_launch(sp, ctx->pit_out.At, ctx->pit_out.Mpad, ctx->pit_out.Kpad, ncols, T, ld, ep);
+        }
+        hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(256), 0, sp, lg, ctx->pitch_freq, f0, B, T);
+    }
+    if (fork) TVC_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+    for (int i = 0; i < 6; ++i) TVC_CHECK(run_convnext(ctx, s, wssl, dry, ctx->ssl_mid[i], xs, B, T));
+    if (!wssl.ok()) return fail(ctx, TVC_ERR_WORKSPACE, "encoder: SSL scratch block too small");
     if (dry) return 0;
     {
         EpiBias<ACT_NONE, false> ep{ssl, ctx->ssl_out.bias, nullptr, kSslDim, T, ncols, (long)kSslDim * T, 0};
@@ -253,16 +282,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
             igemm_launch(s, ctx->ssl_out.At, ctx->ssl_out.Mpad, ctx->ssl_out.Kpad, ncols, T, ld, ep);
         }
     }
-    {
-        EpiBias<ACT_NONE, false> ep{lg, ctx->pit_out.bias, nullptr, kPitchClasses, T, ncols, (long)kPitchClasses * T, 0};
-        if (TVC_SPLIT_ENC) {
-            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->pit_out, xp, B, kPitchCh, T, 0, ep)));
-        } else {
-            LoadPlain ld{xp, kPitchCh, T, (long)kPitchCh * T};
-            igemm_launch(s, ctx->pit_out.At, ctx->pit_out.Mpad, ctx->pit_out.Kpad, ncols, T, ld, ep);
-        }
-    }
-    hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, lg, ctx->pitch_freq, f0, B, T);
+    if (fork) TVC_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     return launch_check(ctx, "encoder");
 }
 

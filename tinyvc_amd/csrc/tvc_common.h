@@ -75,6 +75,8 @@ struct tvc_ctx {
     bool profiling = false;                   // tvc_profile_enable: hipEvent pairs around named regions
     std::vector<tvc_prof_region> regions;
     std::vector<hipEvent_t> event_pool;       // recycled hipEvents: no hipEventCreate on the hot path
+    hipStream_t side = nullptr;               // fork/join stream: the pitch estimator runs beside the SSL chain
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool enc_ready = false, dec_ready = false;  // which checkpoint groups tvc_finalize_weights packed
     char enc_missing[160] = {0}, dec_missing[160] = {0};
     std::map<std::string, tvc::HostTensor> host;  // staged checkpoint tensors
