@@ -9,6 +9,9 @@
 
 namespace tvc {
 
+#ifndef TVC_DSP_FORK
+#define TVC_DSP_FORK 0      // 1: harmonic oscillator on the side stream beside the filtered-noise branch (measured: no gain, both fill the GPU)
+#endif
 #ifndef TVC_SPLIT_1X1
 #define TVC_SPLIT_1X1 0    // 1: FilterNet's 1x1 convs (Downsample.res, Upsample.c5) on the split-precision path too (measured time-neutral)
 #endif
@@ -219,9 +222,18 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
     // harmonics -> source[:, 0:15]
     const float scale_size = (float)T / (float)L;         // F.interpolate(f0, Lw): size given
     const float scale_amp = (float)(1.0 / (double)kHop);  // F.interpolate(amps, scale_factor=480)
-    hipLaunchKernelGGL(harm_frame_sum_kernel, dim3(T, B), dim3(256), 0, s, f0, csum, T, scale_size);
-    hipLaunchKernelGGL(harm_frame_scan_kernel, dim3(kHarm, B), dim3(64), 0, s, csum, T);
-    hipLaunchKernelGGL(harm_synth_kernel, dim3(T, B), dim3(256), 0, s, f0, amps, csum, source, T, scale_size, scale_amp);
+    // (independent of the noise branch below: different inputs, different rows of `source`) -> side stream, joined at the end
+    hipStream_t sh = s;
+    const bool fork = TVC_DSP_FORK && ctx->side;
+    if (fork) {
+        TVC_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
+        TVC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        sh = ctx->side;
+    }
+    hipLaunchKernelGGL(harm_frame_sum_kernel, dim3(T, B), dim3(256), 0, sh, f0, csum, T, scale_size);
+    hipLaunchKernelGGL(harm_frame_scan_kernel, dim3(kHarm, B), dim3(64), 0, sh, csum, T);
+    hipLaunchKernelGGL(harm_synth_kernel, dim3(T, B), dim3(256), 0, sh, f0, amps, csum, source, T, scale_size, scale_amp);
+    if (fork) TVC_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
     // noise -> source[:, 15]
     if (!angle) {
         hipLaunchKernelGGL(angle_fill_kernel, dim3(grid_for((long)B * kBins * T)), dim3(256), 0, s, ang, (long)B * kBins * T, seed);
@@ -244,6 +256,7 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
 #endif
     }
     hipLaunchKernelGGL(noise_ola_kernel, dim3(grid_for((long)B * L)), dim3(256), 0, s, frames, source, B, T);
+    if (fork) TVC_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     return launch_check(ctx, "dsp");
 }
 
