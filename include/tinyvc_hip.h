@@ -11,7 +11,10 @@
  *     (a torch tensor's data_ptr), fp32, contiguous, channels-first [B, C, T] like the reference;
  *     16-byte aligned;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all
- *     work is enqueued asynchronously on it; nothing here synchronises the device;
+ *     work is enqueued asynchronously on it; nothing here synchronises the device.  The encoder
+ *     forks its pitch estimator onto a context-owned side stream and joins it back onto `stream`
+ *     with events before the call returns, so `stream` order is all a caller ever sees (the
+ *     fork/join is capturable: a HIP graph captured on `stream` includes it);
  *   - `ws` is a caller-allocated device scratch buffer of at least tvc_workspace_bytes() bytes;
  *     the library never allocates device memory after tvc_finalize_weights();
  *   - return value: 0 = ok, negative = tvc_status; tvc_last_error() has the message;
