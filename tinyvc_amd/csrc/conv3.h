@@ -39,7 +39,9 @@ struct Conv3Args {
 };
 
 // Epilogue interface: store(b, t, m, v[4]) for 4 consecutive channels m..m+3 at (b, t); t < len guaranteed.
-template <bool RES>
+// F2 = 3 / 5: compile-time decimation factor of the scalar store() path (a runtime division per element costs more than
+// the interpolate pass it replaces); the tile_store path of conv3s.h uses the runtime fields y2 / f2.
+template <bool RES, int F2 = 0>
 struct C3EpiBias {
     static constexpr bool kRes = RES;
     static constexpr bool kIgemm = false;
@@ -47,7 +49,14 @@ struct C3EpiBias {
     const float* bias;
     const float* res;
     int M, len;
+    // optional second output: the F.interpolate(scale_factor = 1/f2) copy the next Downsample block starts from
+    // (decoder.py:148).  For f2 = 3 / 5 ATen's source coordinate f2 * (d + 0.5) - 0.5 is the integer f2*d + f2/2 (weight
+    // exactly 1), for f2 = 4 it is 4d + 1.5 (weights exactly 0.5 / 0.5): the copy is a pick / a two-sample mean of y.
+    float* y2 = nullptr;
+    int f2 = 0;
     __device__ __forceinline__ void store(int b, int t, int m, const float v[4]) const {
+        const int q = F2 > 0 ? t / F2 : 0;
+        const bool pick = F2 > 0 && y2 != nullptr && t - q * F2 == (F2 >> 1);   // f2 = 4 needs two samples: tile_store only
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (m + r < M) {
@@ -55,6 +64,7 @@ struct C3EpiBias {
                 float o = v[r] + bias[m + r];
                 if (RES) o += res[i];
                 y[i] = o;
+                if (pick) y2[((long)b * M + m + r) * (len / F2) + q] = o;
             }
     }
 };

@@ -377,7 +377,7 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
 // residual arrives as 16-byte loads) along time.  v already holds everything but the residual.
 template <class TL, bool RES>
 __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][TL::WN], float* __restrict__ y, const float* __restrict__ res,
-                                           int b, int M, int len, int mt0, int t0) {
+                                           int b, int M, int len, int mt0, int t0, float* __restrict__ y2 = nullptr, int f2 = 0) {
     constexpr int WM = TL::WM, WN = TL::WN, BM = TL::BM, BN = TL::BN, OS = TL::OS, NTHR = TL::NTHR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -395,6 +395,9 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     const float* rb = RES ? res + ((long)b * M + mt0 * 32) * len + t0 : nullptr;
     const int rows = M - mt0 * 32 < BM ? M - mt0 * 32 : BM;
     const bool vec = (len & 3) == 0;                        // rows start 16-byte aligned (t0 is a multiple of 32)
+    // optional 1/f2-rate copy for the next Downsample block (see C3EpiBias): pick for f2 = 3 / 5, two-sample mean for f2 = 4
+    const int len2 = f2 > 0 ? len / f2 : 0;
+    float* y2b = y2 ? y2 + ((long)b * M + mt0 * 32) * len2 : nullptr;
 #pragma unroll 2
     for (int idx = tid; idx < BM * (BN / 4); idx += NTHR) {
         const int row = idx / (BN / 4), c = (idx - row * (BN / 4)) * 4;
@@ -408,11 +411,30 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
                 w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w;
             }
             *reinterpret_cast<float4*>(yb + off) = w;
+            if (y2b) {
+                const float e[4] = {w.x, w.y, w.z, w.w};
+                if (f2 == 4) {
+                    y2b[row * len2 + ((t0 + c) >> 2)] = fmaf(0.5f, e[1], __fmul_rn(0.5f, e[2]));
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = t0 + c + u, q = t / f2;
+                        if (t - q * f2 == (f2 >> 1)) y2b[row * len2 + q] = e[u];
+                    }
+                }
+            }
         } else {
             const float e[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (t0 + c + u < len) yb[off + u] = RES ? e[u] + rb[off + u] : e[u];
+                if (t0 + c + u < len) {
+                    const float ov = RES ? e[u] + rb[off + u] : e[u];
+                    yb[off + u] = ov;
+                    if (y2b && f2 != 4) {
+                        const int t = t0 + c + u, q = t / f2;
+                        if (t - q * f2 == (f2 >> 1)) y2b[row * len2 + q] = ov;
+                    }
+                }
         }
     }
 }
@@ -545,7 +567,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                     for (int j = 0; j < WN; ++j) acc[i][j][r] += bm;
                 }
             if constexpr (!Epi::kIgemm)
-                if (!(S_ABL & 16)) tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
+                if (!(S_ABL & 16)) tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, ep.y2, ep.f2);
         }
         tile = nxt;
         if (tile < ntiles) coords(tile, mt0, b, t0);

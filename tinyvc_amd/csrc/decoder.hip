@@ -9,6 +9,9 @@
 
 namespace tvc {
 
+#ifndef TVC_FUSE_DECIM
+#define TVC_FUSE_DECIM 1    // Downsample's interpolate(1/f) written by the producing conv's epilogue (pick / two-sample mean)
+#endif
 #ifndef TVC_DSP_FORK
 #define TVC_DSP_FORK 0      // 1: harmonic oscillator on the side stream beside the filtered-noise branch (measured: no gain, both fill the GPU)
 #endif
@@ -288,6 +291,20 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
     float* skip[5];
     for (int i = 0; i < 5; ++i) skip[i] = ws.get<float>((size_t)B * ch[4 - i] * len_dn[i]);
     float* x = ws.get<float>((size_t)B * ch[0] * T);
+    // Downsample inputs produced by the previous block's last conv (its epilogue also writes the 1/f-rate copy),
+    // instead of a separate interpolate pass that re-reads the full-rate skip tensor
+    float* xi_pre[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool xi_fused[5] = {false, false, false, false, false};
+    for (int i = 1; i <= 4; ++i) {
+        const DownW& d = ctx->downs[i - 1];
+        const bool producer_ok = i == 1 ? (TVC_USE_C48 != 0)                                     // downs.0 conv (16x16x4 kernel), factor 5: pick
+                                        : (TVC_SPLIT && ctx->downs[i - 2].cin % 16 == 0 && ctx->downs[i - 2].cout % 96 == 0 &&   // conv3s c3 of the block before
+                                           len_dn[i - 1] % 4 == 0);
+        if (TVC_FUSE_DECIM && producer_ok && ((d.factor == 5 && i == 1) || ((d.factor == 3 || d.factor == 4) && i > 1)) && len_dn[i - 1] % d.factor == 0) {
+            xi_pre[i] = ws.get<float>((size_t)B * d.cin * len_dn[i]);
+            xi_fused[i] = true;
+        }
+    }
 
     if (!dry) {
         ProfScope ps(ctx, s, dry, "filter.in+down0");
@@ -295,7 +312,9 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         EpiSumCond ep{x, ctx->flt_content_in.bias, nullptr, f0, nullptr, nullptr, ctx->flt_f_w, ctx->flt_f_b, ch[0], T, B * T};
         igemm_launch(s, ctx->flt_content_in.At, ctx->flt_content_in.Mpad, ctx->flt_content_in.Kpad, B * T, T, ld, ep);
         if (TVC_USE_C48)   // downs[0]: k3 conv over cat[source (16 ch), energy (1 ch)], read from the two tensors in place
-            conv3mt_launch<2, false>(s, ctx->flt_down0, source, B, 17, (int)L, 1, C3EpiBias<false>{skip[0], ctx->flt_down0.bias, nullptr, 24, (int)L},
+            conv3mt_launch<2, false>(s, ctx->flt_down0, source, B, 17, (int)L, 1,
+                                     C3EpiBias<false, 5>{skip[0], ctx->flt_down0.bias, nullptr, 24, (int)L, xi_fused[1] ? xi_pre[1] : nullptr,
+                                                         xi_fused[1] ? 5 : 0},
                                      FilmOps(), energy, 16);
         else
             TVC_CHECK(run_down0(ctx, s, ctx->flt_down0, source, energy, skip[0], B, (int)L));
@@ -305,7 +324,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         const DownW& d = ctx->downs[i - 1];
         const int lin = (int)len_dn[i - 1], len = (int)len_dn[i];
         size_t mk = ws.mark();
-        float* xi = ws.get<float>((size_t)B * d.cin * len);
+        float* xi = xi_fused[i] ? xi_pre[i] : ws.get<float>((size_t)B * d.cin * len);
         float* res = ws.get<float>((size_t)B * d.cout * len);
         float* h1 = ws.get<float>((size_t)B * d.cin * len);
         float* h2 = ws.get<float>((size_t)B * d.cin * len);
@@ -313,7 +332,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
             static const char* names[4] = {"filter.down1", "filter.down2", "filter.down3", "filter.down4"};
             ProfScope ps(ctx, s, dry, names[i - 1]);
             // F.interpolate(scale_factor=1/f): ATen uses scale = 1/(1/f) = f
-            {
+            if (!xi_fused[i]) {
                 const LerpLaunch ll = lerp_launch((long)B * d.cin, len);
                 hipLaunchKernelGGL(lerp_resize_kernel, ll.grid, dim3(256), 0, s, skip[i - 1], xi, (long)B * d.cin, lin, len, (float)d.factor, ll.tx);
             }
@@ -348,7 +367,9 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
             else if (d.cout == 48 && TVC_USE_C48)
                 conv3m48_launch<true>(s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
             else if (TVC_SPLIT && d.cin % 16 == 0 && d.cout % 96 == 0)
-                TVC_CHECK(conv3s_launch<true>(ctx, s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len}));
+                TVC_CHECK(conv3s_launch<true>(ctx, s, d.c3, h2, B, d.cin, len, 4,
+                                              C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len, (i < 4 && xi_fused[i + 1]) ? xi_pre[i + 1] : nullptr,
+                                                              (i < 4 && xi_fused[i + 1]) ? ctx->downs[i].factor : 0}));
             else
                 conv3_launch<true>(s, d.c3.At, d.c3.Mpad, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
         }

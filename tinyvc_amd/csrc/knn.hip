@@ -22,6 +22,9 @@ constexpr int KD = kSslDim;  // 768
 #ifndef KNN_SPLIT
 #define KNN_SPLIT 1    // similarity GEMM on the split-precision bf16 path (0: exact-fp32 MFMA kernel)
 #endif
+#ifndef KNN_BLOCKS
+#define KNN_BLOCKS 1024   // target workgroup count (query tiles x index splits)
+#endif
 #ifndef KNN_PIN
 #define KNN_PIN 0
 #endif
@@ -456,7 +459,7 @@ int run_knn(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, con
     const long Npad = npad128(N);
     const int qtiles = (ncols + 127) / 128;
     const int mtiles = (int)(Npad / 128);
-    int nsplit = (1024 + qtiles - 1) / qtiles;
+    int nsplit = (KNN_BLOCKS + qtiles - 1) / qtiles;
     if (nsplit > mtiles) nsplit = mtiles;
     if (nsplit < 1) nsplit = 1;
     const int tps = (mtiles + nsplit - 1) / nsplit;
