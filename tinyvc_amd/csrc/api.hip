@@ -120,7 +120,7 @@ struct Packer {
             std::memcpy(&f, &u, 4);
             return f;
         };
-        const int taps = pw->taps, cin = pw->cin, nslab = (cin + 15) / 16;
+        const int taps = pw->taps, cin = pw->cin, nslab = ((cin + 15) / 16 + 5) / 6 * 6;   // zero slabs up to a multiple of 6: any slab depth divides
         const int gp = group_rows > 0 ? (group_rows + 31) / 32 * 32 : 0;
         const int MT = group_rows > 0 ? (pw->M / group_rows) * gp / 32 : pw->Mpad / 32;
         std::vector<float> img((size_t)nslab * taps * MT * 3 * 256, 0.f);
@@ -147,6 +147,7 @@ struct Packer {
                             o[base + 1024] = h3;
                         }
         pw->MT6 = MT;
+        pw->S6 = nslab;
         fix.push_back({&pw->A6, ab.put(img)});
     }
     void convnext(const std::string& p, ConvNeXtW* w, int C, int dil) {

@@ -34,11 +34,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef S_WPE
 #define S_WPE 3     // waves per SIMD the register budget is sized for (plain / FiLM-fused kernels): 12-wave workgroups, no spills
 #endif
+#ifndef S_WPE_G
+#define S_WPE_G 4     // 8-wave (GEMM) workgroups: two per CU need <= 128 registers
+#endif
 #ifndef S_WPE_F
 #define S_WPE_F 3
 #endif
 #ifndef TVC_S_MTB2
 #define TVC_S_MTB2 0
+#endif
+#ifndef TVC_S_KG
+#define TVC_S_KG 2     // deepest K slab (in 16-channel groups) the GEMM launches may use (3 spills at the 128-register budget: slower)
 #endif
 #ifndef TVC_S_FLAT
 #define TVC_S_FLAT 1   // GEMM launches tile the flattened B * T column axis instead of every utterance separately
@@ -49,6 +55,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef S_FB
 #define S_FB 2   // fragment register sets: 2 = next tap's LDS reads under this tap's MFMAs, 1 = read, then multiply
 #endif
+#ifndef S_FB_G
+#define S_FB_G 1   // 8-wave (GEMM) workgroups: single fragment set (128-register budget)
+#endif
 #ifndef S_FB_F
 #define S_FB_F 1   // FiLM-fused kernels: two accumulator sets live, single fragment set keeps the slab loops spill-free
 #endif
@@ -57,16 +66,20 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #endif
 
 
-template <int MTB_, int WM_, int NWV_, int WN_ = 1>
+template <int MTB_, int WM_, int NWV_, int WN_ = 1, int KG_ = 1>
 struct SplitTile {
     static constexpr int MTB = MTB_, WM = WM_, NWV = NWV_, WN = WN_;            // m-tiles per workgroup / per wave, waves along time, n-tiles per wave
+    // KG = 16-channel groups staged per slab.  Convs use 1 (the three taps share one halo tile); the plain-GEMM launches
+    // use 2-3: with one group a slab carries only 6 MFMAs per wave, far less than the load -> LDS -> barrier round trip.
+    static constexpr int KG = KG_;
     static constexpr int MW = MTB / WM, NW = MW * NWV, NTHR = NW * 64;
     static_assert(MTB % WM == 0, "wave rows must tile the workgroup");
     static constexpr int BM = MTB * 32, BN = NWV * WN * 32;
-    static constexpr int MAXD = 27, XROW = BN + 2 * MAXD;
-    static constexpr int X_U4 = 3 * 2 * XROW;
-    static constexpr int X_PER = (2 * XROW + NTHR - 1) / NTHR;                  // staging items per thread
-    static constexpr int a_u4(int taps) { return taps * MTB * 3 * 64; }
+    static constexpr int MAXD = KG > 1 ? 0 : 27, XROW = BN + 2 * MAXD;
+    static constexpr int XG_U4 = 3 * 2 * XROW;                                  // one channel group: [part][8-channel half][position]
+    static constexpr int X_U4 = KG * XG_U4;
+    static constexpr int X_PER = (KG * 2 * XROW + NTHR - 1) / NTHR;             // staging items per thread
+    static constexpr int a_u4(int taps) { return taps * KG * MTB * 3 * 64; }
     static constexpr int KS_MAX = 2 * 768;                                      // SCALED launch: factors of <= 768 input channels for the <= 2 utterances a tile touches
     static constexpr int OS = BN + 4;                                           // row stride (floats) of the output tile parked in LDS
     static constexpr int lds_bytes(int taps) {
@@ -119,7 +132,7 @@ __device__ __forceinline__ void slab_barrier() { asm volatile("s_waitcnt lgkmcnt
 // Staging registers of one thread (one slab in flight) and its share of the halo tile.
 template <class TL>
 struct SlabRegs {
-    static constexpr int A_MAX = (3 * TL::MTB * 3 + TL::NW - 1) / TL::NW;
+    static constexpr int A_MAX = ((TL::KG > 3 ? TL::KG : 3) * TL::MTB * 3 + TL::NW - 1) / TL::NW;
     u32x4 ar[A_MAX];
     float xr[TL::X_PER][8];
 };
@@ -138,18 +151,20 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
 #pragma unroll
     for (int i = 0; i < TL::X_PER; ++i) {
         int idx = threadIdx.x + i * TL::NTHR;
-        int g = idx / xw, c = idx - g * xw;
+        int gk = idx / xw, c = idx - gk * xw;                // gk = 2 * (channel group) + (8-channel half)
         int p = t0 - dil + c;
         p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
-        m.xdst[i] = g < 2 ? g * TL::XROW + c : -1;
-        g = g < 2 ? g : 1;                                   // idle items still load (valid address), never store
-        m.xg8[i] = 8 * g;
+        const bool live = gk < 2 * TL::KG;
+        gk = live ? gk : 2 * TL::KG - 1;                     // idle items still load (valid address), never store
+        const int ks = gk >> 1, g = gk & 1;
+        m.xdst[i] = live ? ks * TL::XG_U4 + g * TL::XROW + c : -1;
+        m.xg8[i] = ks * 16 + 8 * g;
         if (fT > 0) {
             const int b = p / fT, t = p - b * fT;
-            m.xo[i] = (unsigned)b * fstride + (unsigned)(8 * g * fT + t);
+            m.xo[i] = (unsigned)b * fstride + (unsigned)(m.xg8[i] * fT + t);
             m.xk[i] = (b - t0 / fT) * kcin;
         } else {
-            m.xo[i] = (unsigned)(8 * g * len + p);
+            m.xo[i] = (unsigned)(m.xg8[i] * len + p);
             m.xk[i] = 0;
         }
     }
@@ -158,11 +173,11 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
 template <class TL, int TAPS>
 __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ A6, int MT, int mt0,
                                           const float* __restrict__ xb, int Cin, int len, int s, int fT = 0) {
-    constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER;
+    constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER, STEPS = TAPS * TL::KG;
     const int cs = fT > 0 ? fT : len;                    // channel stride
-    constexpr int PIECES = TAPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
+    constexpr int PIECES = STEPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ci0 = s * 16;
+    const int ci0 = s * 16 * TL::KG;
     if (!(S_ABL & 2)) {
         const uint4* a_src = A6 + (long)mt0 * 192;
 #pragma unroll
@@ -170,7 +185,7 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
             int q = wave + i * NW;
             q = q < PIECES ? q : PIECES - 1;
             const int tap = q / (MTB * 3), rem = q - tap * (MTB * 3);
-            r.ar[i] = *reinterpret_cast<const u32x4*>(a_src + ((long)(s * TAPS + tap) * MT * 192 + rem * 64) + lane);
+            r.ar[i] = *reinterpret_cast<const u32x4*>(a_src + ((long)(s * STEPS + tap) * MT * 192 + rem * 64) + lane);
         }
     }
     if (S_ABL & 4) return;
@@ -202,7 +217,8 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     const int wm = wave / NWV, wn = wave - wm * NWV;
     SlabMap<TL> m;
     make_map<TL>(m, len, dil, t0, fT, fstride, Cin);
-    constexpr int PIECES = TAPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
+    constexpr int STEPS = TAPS * TL::KG;               // K16 steps per slab: (channel group, tap)
+    constexpr int PIECES = STEPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
     auto lstore = [&](int sl) __attribute__((always_inline)) {
         if (!(S_ABL & 2)) {
 #pragma unroll
@@ -219,8 +235,8 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
                     for (int j = 0; j < 8; ++j) r.xr[i][j] = fmaxf(r.xr[i][j], 0.1f * r.xr[i][j]);   // = leaky_relu(x, 0.1)
                 }
                 if (SCALED) {
-                    const float4 k0 = *reinterpret_cast<const float4*>(Ks + m.xk[i] + sl * 16 + m.xg8[i]);
-                    const float4 k1 = *reinterpret_cast<const float4*>(Ks + m.xk[i] + sl * 16 + m.xg8[i] + 4);
+                    const float4 k0 = *reinterpret_cast<const float4*>(Ks + m.xk[i] + sl * 16 * TL::KG + m.xg8[i]);
+                    const float4 k1 = *reinterpret_cast<const float4*>(Ks + m.xk[i] + sl * 16 * TL::KG + m.xg8[i] + 4);
                     r.xr[i][0] *= k0.x; r.xr[i][1] *= k0.y; r.xr[i][2] *= k0.z; r.xr[i][3] *= k0.w;
                     r.xr[i][4] *= k1.x; r.xr[i][5] *= k1.y; r.xr[i][6] *= k1.z; r.xr[i][7] *= k1.w;
                 }
@@ -232,7 +248,7 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
             }
     };
 
-    const int nslab = (Cin + 15) / 16;
+    const int nslab = Cin / (16 * TL::KG);
     const uint4* as = As + wm * WM * 192 + lane;
     const uint4* xs = Xs + lh * XROW + wn * WN * 32 + l31;
     for (int s = 0; s < nslab; ++s) {
@@ -247,7 +263,8 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bf[fb][j][p] = __builtin_bit_cast(bf16x8, xs[2 * p * XROW + j * 32 + tap * dil]);
+                for (int p = 0; p < 3; ++p)
+                    bf[fb][j][p] = __builtin_bit_cast(bf16x8, xs[(tap / TAPS) * TL::XG_U4 + 2 * p * XROW + j * 32 + (tap % TAPS) * dil]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -255,10 +272,10 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
         };
         if (FB == 2) frags(0, 0);
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
+        for (int tap = 0; tap < STEPS; ++tap) {        // tap = step index (channel group * TAPS + tap)
             const int fb = FB == 2 ? tap & 1 : 0;
             if (FB == 2) {
-                if (tap + 1 < TAPS) frags(tap + 1, fb ^ 1);
+                if (tap + 1 < STEPS) frags(tap + 1, fb ^ 1);
                 __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler sinks them to just-in-time otherwise)
             } else {
                 frags(tap, 0);
@@ -286,7 +303,7 @@ __device__ __forceinline__ void film_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
                                           const float* __restrict__ xb, int len, int s) {
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER;
     constexpr int PIECES = 2 * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
-    static_assert(A_PER <= SlabRegs<TL>::A_MAX, "FiLM weight pieces must fit the staging registers");
+    static_assert(A_PER <= SlabRegs<TL>::A_MAX && TL::KG == 1, "FiLM weight pieces must fit the staging registers; FiLM kernels stage one channel group");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (!(S_ABL & 2)) {
 #pragma unroll
@@ -440,7 +457,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
 }
 
 template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false>
-__global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ? S_WPE_F : S_WPE))) void conv3s_kernel(ConvSArgs a, Epi ep) {
+__global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ? S_WPE_F : (TL::NW <= 8 ? S_WPE_G : S_WPE)))) void conv3s_kernel(ConvSArgs a, Epi ep) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, A_U4 = TL::a_u4(TAPS);
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s[];
     uint4* As = smem_s;
@@ -536,7 +553,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 }
             tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
         } else {
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB, SCALED>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile, Ks, fT,
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (TL::NW <= 8 ? S_FB_G : S_FB), SCALED>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile, Ks, fT,
                                                                              fstride);
             if constexpr (Epi::kIgemm) {
                 // plain GEMM use (B = 1, len = all columns): the igemm epilogue functors finish the element
@@ -578,7 +595,8 @@ template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = fa
 inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
                            const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond, long xstride = 0, int bpc = S_BPC,
                            const float* kscale = nullptr, bool flat = false) {
-    if (Cin % 16 != 0 || (FILM && Ccond % 16 != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of 16");
+    if (Cin % (16 * TL::KG) != 0 || (FILM && Ccond % 16 != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of the slab depth");
+    if (Cin / 16 > w.S6) return fail(ctx, TVC_ERR_ARG, "conv3s: weight image has fewer K16 steps than the launch walks");
     static bool ready = false;
     constexpr int lds = TL::lds_bytes(TAPS);
     if (!ready) {
@@ -669,16 +687,24 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
 
 // Plain GEMM on the split path: out(m, n) = sum_k W[m][k] x[b][k][t], n = b * len + t, finished by an igemm epilogue
 // functor (store(n, m, v[4])).  Cin must be a multiple of 16 and rows [K, Cin) must be readable (weights there are 0).
-template <int MTB, int NWV, int BPC, class Epi, bool SCALED = false>
-inline int gemm_s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
-                         const float* kscale = nullptr) {
-    if (w.MT6 % MTB != 0) return fail(ctx, TVC_ERR_ARG, "gemm_s: row tiles do not divide");
-    using TL = SplitTile<MTB, 1, NWV, 1>;
+template <int MTB, int NWV, int BPC, int KG, class Epi, bool SCALED>
+inline int gemm_s_launch_k(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
+                           const float* kscale) {
+    using TL = SplitTile<MTB, 1, NWV, 1, KG>;
     // flat column tiles unless a tile could touch more than two utterances of a SCALED launch (factors of two are staged)
     // or the element offsets would not fit 32 bits
     const long xs = xstride ? xstride : (long)Cin * len;
     const bool flat = TVC_S_FLAT && B > 1 && xs * B < (1L << 31) && (!SCALED || len >= TL::BN);
     return conv3s_launch_t<TL, 1, false, Epi, false, SCALED>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride, BPC, kscale, flat);
+}
+template <int MTB, int NWV, int BPC, class Epi, bool SCALED = false>
+inline int gemm_s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
+                         const float* kscale = nullptr) {
+    if (w.MT6 % MTB != 0) return fail(ctx, TVC_ERR_ARG, "gemm_s: row tiles do not divide");
+    // deepest slab the channel count allows: 48, 32 or 16 input channels per load -> LDS -> barrier round trip
+    if (TVC_S_KG >= 3 && Cin % 48 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 3, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale);
+    if (TVC_S_KG >= 2 && Cin % 32 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 2, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale);
+    return gemm_s_launch_k<MTB, NWV, BPC, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale);
 }
 
 }  // namespace tvc

@@ -245,8 +245,9 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
     hipLaunchKernelGGL(noise_spec_kernel, dim3(grid_for((long)B * kBins * T)), dim3(256), 0, s, kern, angle, yri, (long)kBins * T, B);
     {   // even part from the real halves (rows 0..960 of yri), then odd part from the imaginary halves of bins 1..959
 #if TVC_SPLIT_IDFT
-        // split-precision path: K rows beyond 961 / 959 meet zero weights and stay inside yri (its imaginary half follows)
-        TVC_CHECK((gemm_s_launch<IDFT_MTB, IDFT_NWV, IDFT_BPC>(ctx, s, ctx->istft_e, yri, B, 976, T, (long)2 * kBins * T, EpiFramesPart<false>{frames, ncols})));
+        // split-precision path: K rows beyond 961 / 959 (up to 992 / 960, whole 32-channel slabs) meet zero weights and
+        // stay inside yri (its imaginary half follows the real one)
+        TVC_CHECK((gemm_s_launch<IDFT_MTB, IDFT_NWV, IDFT_BPC>(ctx, s, ctx->istft_e, yri, B, 992, T, (long)2 * kBins * T, EpiFramesPart<false>{frames, ncols})));
         TVC_CHECK((gemm_s_launch<IDFT_MTB, IDFT_NWV, IDFT_BPC>(ctx, s, ctx->istft_o, yri + (long)(kBins + 1) * T, B, 960, T, (long)2 * kBins * T,
                                                                EpiFramesPart<true>{frames, ncols})));
 #else

@@ -33,7 +33,7 @@ struct PackedW {
     const float* At_tap = nullptr;  // same weight with k = tap*cin + ci (tap-major), for the LDS-tiled conv kernels
     const float* bias = nullptr;
     const float* A6 = nullptr;      // bf16x3 split image for the split-precision MFMA kernels (conv3s.h), MT6 = Mpad / 32 m-tiles
-    int M = 0, K = 0, Mpad = 0, Kpad = 0, cin = 0, taps = 1, MT6 = 0;
+    int M = 0, K = 0, Mpad = 0, Kpad = 0, cin = 0, taps = 1, MT6 = 0, S6 = 0;   // S6 = 16-channel slabs in A6 (zero-padded to a multiple of 6)
 };
 
 struct ConvNeXtW {
