@@ -40,6 +40,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef S_WPE_F
 #define S_WPE_F 3
 #endif
+#ifndef TVC_S_CKG
+#define TVC_S_CKG 1     // 2: two channel groups per slab for the plain conv launches with Cin % 32 == 0 (measured: no gain)
+#endif
 #ifndef TVC_S_MTB2
 #define TVC_S_MTB2 0
 #endif
@@ -66,7 +69,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #endif
 
 
-template <int MTB_, int WM_, int NWV_, int WN_ = 1, int KG_ = 1>
+template <int MTB_, int WM_, int NWV_, int WN_ = 1, int KG_ = 1, int MAXD_ = 27>
 struct SplitTile {
     static constexpr int MTB = MTB_, WM = WM_, NWV = NWV_, WN = WN_;            // m-tiles per workgroup / per wave, waves along time, n-tiles per wave
     // KG = 16-channel groups staged per slab.  Convs use 1 (the three taps share one halo tile); the plain-GEMM launches
@@ -75,7 +78,7 @@ struct SplitTile {
     static constexpr int MW = MTB / WM, NW = MW * NWV, NTHR = NW * 64;
     static_assert(MTB % WM == 0, "wave rows must tile the workgroup");
     static constexpr int BM = MTB * 32, BN = NWV * WN * 32;
-    static constexpr int MAXD = KG > 1 ? 0 : 27, XROW = BN + 2 * MAXD;
+    static constexpr int MAXD = MAXD_, XROW = BN + 2 * MAXD;                    // largest dilation the halo tile must hold (0 for plain GEMMs)
     static constexpr int XG_U4 = 3 * 2 * XROW;                                  // one channel group: [part][8-channel half][position]
     static constexpr int X_U4 = KG * XG_U4;
     static constexpr int X_PER = (KG * 2 * XROW + NTHR - 1) / NTHR;             // staging items per thread
@@ -132,7 +135,7 @@ __device__ __forceinline__ void slab_barrier() { asm volatile("s_waitcnt lgkmcnt
 // Staging registers of one thread (one slab in flight) and its share of the halo tile.
 template <class TL>
 struct SlabRegs {
-    static constexpr int A_MAX = ((TL::KG > 3 ? TL::KG : 3) * TL::MTB * 3 + TL::NW - 1) / TL::NW;
+    static constexpr int A_MAX = (3 * TL::KG * TL::MTB * 3 + TL::NW - 1) / TL::NW;   // up to 3 taps x KG channel groups of weight pieces
     u32x4 ar[A_MAX];
     float xr[TL::X_PER][8];
 };
@@ -176,6 +179,7 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER, STEPS = TAPS * TL::KG;
     const int cs = fT > 0 ? fT : len;                    // channel stride
     constexpr int PIECES = STEPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
+    static_assert(A_PER <= SlabRegs<TL>::A_MAX, "weight pieces must fit the staging registers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ci0 = s * 16 * TL::KG;
     if (!(S_ABL & 2)) {
@@ -679,6 +683,8 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
     }
     if constexpr (FILM)
         return conv3s_launch_t<SplitTile<3, TVC_SF_WM, TVC_SF_NWV, TVC_SF_WN>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond);
+    else if (TVC_S_CKG == 2 && Cin % 32 == 0)   // two 16-channel groups per slab: 36 MFMAs per wave between barriers instead of 18
+        return conv3s_launch_t<SplitTile<3, TVC_S_WM, TVC_S_NWV, TVC_S_WN, 2>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond);
     else if (TVC_S_MTB2 && w.MT6 % 2 == 0)   // 192 / 384 rows: 8-wave workgroups of two m-tiles, two per CU
         return conv3s_launch_t<SplitTile<2, 1, 4, 1>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, 2);
     else
@@ -690,7 +696,7 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
 template <int MTB, int NWV, int BPC, int KG, class Epi, bool SCALED>
 inline int gemm_s_launch_k(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
                            const float* kscale) {
-    using TL = SplitTile<MTB, 1, NWV, 1, KG>;
+    using TL = SplitTile<MTB, 1, NWV, 1, KG, 0>;
     // flat column tiles unless a tile could touch more than two utterances of a SCALED launch (factors of two are staged)
     // or the element offsets would not fit 32 bits
     const long xs = xstride ? xstride : (long)Cin * len;
