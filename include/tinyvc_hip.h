@@ -96,6 +96,21 @@ int tvc_knn_match_f32(tvc_ctx* ctx, void* stream, const float* src, const float*
                       float* out, int64_t* idx_out, int B, int T, void* ws, size_t ws_bytes);
 
 /* pitch shift ----------------------------------------------------------------------------- */
+/* Index-sharded variant of the match (a very large speaker index split over the GPUs of a node):
+ * every rank holds a prepared shard and
+ *   1. tvc_knn_topk_f32: this shard's top-4 per query: sims_out [B,T,4] (cosine similarity, descending, ties ->
+ *      lower index first) and idx_out [B,T,4] (LOCAL indices into the shard);
+ *   2. the host all-gathers (sim, global index) and keeps the global top-4 per query (tinyvc_amd/parallel.py);
+ *   3. tvc_knn_gather_slots_f32: slots [nslots,768] <- this shard's raw rows for idx[nslots] (local index, or a
+ *      negative value where the row lives on another rank -> zeros); summed over ranks every slot has exactly one
+ *      contributor, so the all-reduce is exact;
+ *   4. tvc_knn_finish_f32: out [B,768,T] = mean of the 4 slots of each query in the single-GPU order. */
+int tvc_knn_topk_f32(tvc_ctx* ctx, void* stream, const float* src, const float* prepared, int64_t N,
+                     float* sims_out, int64_t* idx_out, int B, int T, void* ws, size_t ws_bytes);
+int tvc_knn_gather_slots_f32(tvc_ctx* ctx, void* stream, const float* prepared, int64_t N,
+                             const int64_t* idx, float* slots, int64_t nslots);
+int tvc_knn_finish_f32(tvc_ctx* ctx, void* stream, const float* slots, float* out, int B, int T);
+
 /* module.utils.shift_frequency (reference module/utils/pitch_shift.py:5-15), n elements. */
 int tvc_shift_frequency_f32(tvc_ctx* ctx, void* stream, const float* f0, float* out, int64_t n,
                             float semitones);

@@ -260,3 +260,38 @@ def test_cpu_tensor_to_gpu_model_and_errors(models):
         Encoder().infer(torch.zeros(1, 961, 4))          # model on CPU: loud failure, no fallback
     with pytest.raises(RuntimeError):
         gen.convert(wf, synth.synth_index(3, seed=1), 0.0)   # k=4 > N=3, as torch.topk raises
+
+
+@pytest.mark.gpu
+def test_index_sharded_topk_slots_finish_equal_single_call():
+    """The three C-ABI calls of the index-sharded match, driven for two shards on ONE GPU (no process group: the
+    exchange is emulated by concatenation / addition), must reproduce tvc_knn_match_f32 on the whole index bit for bit."""
+    import torch
+    from tinyvc_amd import parallel, synth
+    from tinyvc_amd.engine import default_engine
+    eng = default_engine(torch.device("cuda:0"))
+    N = 1001
+    index = synth.synth_index(N, seed=11).to("cuda:0")
+    if index.dim() == 3:
+        index = index[0]
+    src = torch.randn(2, 768, 37, generator=torch.Generator().manual_seed(5)).to("cuda:0")
+    blob, n = eng.knn_prepare(index)
+    want, want_idx = eng.knn_match(src, blob, n, want_indices=True)
+    cut = 417
+    shards = [(0, index[:, :cut].contiguous()), (cut, index[:, cut:].contiguous())]
+    prepared = [(lo, *eng.knn_prepare(sh)) for lo, sh in shards]
+    sims, gidx = [], []
+    for lo, b, nl in prepared:
+        s, i = eng.knn_topk(src, b, nl)
+        sims.append(s)
+        gidx.append(i + lo)
+    _, sel = parallel.merge_topk(torch.cat(sims, -1), torch.cat(gidx, -1))
+    assert torch.equal(sel, want_idx)
+    slots = None
+    for lo, b, nl in prepared:
+        local = sel - lo
+        local = torch.where((local >= 0) & (local < nl), local, torch.full_like(local, -1))
+        part = eng.knn_gather_slots(b, nl, local)
+        slots = part if slots is None else slots + part
+    got = eng.knn_finish(slots)
+    assert torch.equal(got, want)

@@ -67,3 +67,78 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- index-sharded match: exchange/merge logic on CPU with the oracle standing in for the per-shard HIP calls ----
+class _OracleShardEngine:
+    """Test stand-in for Engine.knn_topk / knn_gather_slots / knn_finish (those are HIP kernels): the same
+    contracts computed with torch CPU ops, so the all_gather / merge / all_reduce path runs under gloo."""
+
+    def __init__(self, shard):          # shard [768, n_local]
+        self.shard = shard
+
+    def knn_topk(self, src, prepared, n_local):
+        ref = self.shard / (self.shard.norm(dim=0, keepdim=True) + 1e-6)
+        q = src / (src.norm(dim=1, keepdim=True) + 1e-6)
+        sims = torch.einsum("bkt,kn->btn", q, ref)
+        v, i = parallel.merge_topk(sims, torch.arange(n_local).expand_as(sims))
+        return v.contiguous(), i.contiguous()
+
+    def knn_gather_slots(self, prepared, n_local, idx):
+        rows = self.shard.t()                                   # [n_local, 768]
+        out = torch.zeros(*idx.shape, rows.shape[1])
+        ok = idx >= 0
+        out[ok] = rows[idx[ok]]
+        return out
+
+    def knn_finish(self, slots):
+        s = ((slots[..., 0, :] + slots[..., 1, :]) + slots[..., 2, :]) + slots[..., 3, :]
+        return (s * 0.25).permute(0, 2, 1).contiguous()
+
+
+def _knn_worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(3)
+        index = torch.randn(768, n_total, generator=g)
+        index[:, 7] = index[:, 2]                               # an exact tie across (or inside) shards: lower index must win
+        src = torch.randn(2, 768, 9, generator=g)
+        lo, hi = parallel.shard_bounds(n_total, rank, world)
+        eng = _OracleShardEngine(index[:, lo:hi])
+        out, sel = parallel.match_features_sharded(eng, src, None, hi - lo, lo)
+        if rank == 0:
+            q.put((out, sel))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 40), (3, 25)])
+def test_index_sharded_match_equals_unsharded(world, n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_knn_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, sel = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(3)
+    index = torch.randn(768, n_total, generator=g)
+    index[:, 7] = index[:, 2]
+    src = torch.randn(2, 768, 9, generator=g)
+    whole = _OracleShardEngine(index)
+    v, i = whole.knn_topk(src, None, n_total)
+    assert torch.equal(sel, i)
+    assert torch.equal(out, whole.knn_finish(whole.knn_gather_slots(None, n_total, i)))
+
+
+def test_merge_topk_tie_rule():
+    sims = torch.tensor([[0.5, 0.9, 0.9, 0.1, 0.9, 0.3]])
+    idx = torch.tensor([[10, 7, 3, 1, 5, 2]])
+    v, i = parallel.merge_topk(sims, idx)
+    assert i.tolist() == [[3, 5, 7, 10]] and torch.equal(v, torch.tensor([[0.9, 0.9, 0.9, 0.5]]))

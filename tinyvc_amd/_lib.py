@@ -28,6 +28,9 @@ SIGNATURES = {
     "tvc_knn_prepared_elems": (c_int64, [c_int64]),
     "tvc_knn_prepare_index_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "tvc_knn_match_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
+    "tvc_knn_topk_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
+    "tvc_knn_gather_slots_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64]),
+    "tvc_knn_finish_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "tvc_shift_frequency_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float]),
     "tvc_decoder_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_decoder_stages_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),

@@ -533,6 +533,32 @@ int tvc_knn_match_f32(tvc_ctx* ctx, void* stream, const float* src, const float*
             run_knn(ctx, s, ws, false, src, prepared, N, out, idx_out, B, T));
 }
 
+int tvc_knn_topk_f32(tvc_ctx* ctx, void* stream, const float* src, const float* prepared, int64_t N, float* sims_out,
+                     int64_t* idx_out, int B, int T, void* wsp, size_t ws_bytes) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!src || !prepared || !sims_out || !idx_out || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_topk_f32: bad argument");
+    if (N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_knn_topk_f32: an index shard needs at least k=4 vectors");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    TVC_RUN(run_knn_topk(ctx, s, ws, true, src, prepared, N, sims_out, idx_out, B, T),
+            run_knn_topk(ctx, s, ws, false, src, prepared, N, sims_out, idx_out, B, T));
+}
+
+int tvc_knn_gather_slots_f32(tvc_ctx* ctx, void* stream, const float* prepared, int64_t N, const int64_t* idx, float* slots,
+                             int64_t nslots) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!prepared || !idx || !slots || N <= 0 || nslots <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_gather_slots_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_knn_slots(ctx, (hipStream_t)stream, prepared, N, idx, slots, nslots);
+}
+
+int tvc_knn_finish_f32(tvc_ctx* ctx, void* stream, const float* slots, float* out, int B, int T) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!slots || !out || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_finish_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_knn_finish(ctx, (hipStream_t)stream, slots, out, B, T);
+}
+
 int tvc_shift_frequency_f32(tvc_ctx* ctx, void* stream, const float* f0, float* out, int64_t n, float semitones) {
     if (!ctx) return TVC_ERR_ARG;
     if (!f0 || !out || n <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_shift_frequency_f32: bad argument");

@@ -453,6 +453,98 @@ static __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const floa
     }
 }
 
+// ---- index-sharded search (one index shard per GPU): local top-4 with similarities, slot gather, finish ----
+// merge the split candidates of every query -> this shard's top-4 (similarity, local index)
+static __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i, int nsplit, int ncols,
+                                                               float* __restrict__ sims_out, int64_t* __restrict__ idx_out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= ncols) return;
+    Top4 t4;
+    t4.init();
+    for (int sp = 0; sp < nsplit; ++sp) {
+        long o = ((long)sp * ncols + n) * 4;
+        for (int e = 0; e < 4; ++e) t4.insert(cand_v[o + e], cand_i[o + e]);
+    }
+    for (int e = 0; e < 4; ++e) {
+        sims_out[(long)n * 4 + e] = t4.v[e];
+        idx_out[(long)n * 4 + e] = (int64_t)t4.i[e];
+    }
+}
+// slots[n][e][:] = raw row idx[n][e] of this shard, or zeros where idx < 0 (the row lives on another rank)
+static __global__ __launch_bounds__(192) void knn_slot_gather_kernel(const float* __restrict__ rows, const int64_t* __restrict__ idx, long nslots,
+                                                                     long N, float* __restrict__ slots) {
+    const long sl = blockIdx.x;
+    if (sl >= nslots) return;
+    const int64_t i = idx[sl];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i >= 0 && i < N) v = reinterpret_cast<const float4*>(rows + i * KD)[threadIdx.x];
+    reinterpret_cast<float4*>(slots + sl * KD)[threadIdx.x] = v;
+}
+// out[b][k][t] = (((s0 + s1) + s2) + s3) * 0.25 from slots [B*T][4][768] (the same order as the single-GPU gather),
+// transposed through LDS so reads run along k and stores along t
+static __global__ __launch_bounds__(256) void knn_finish_kernel(const float* __restrict__ slots, int ncols, int T, float* __restrict__ out) {
+    __shared__ float tile[32][193];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 32;
+    for (int kc = 0; kc < KD; kc += 192) {
+        for (int q = wave; q < 32; q += 4) {
+            const int n = n0 + q < ncols ? n0 + q : ncols - 1;
+            const float* r0 = slots + ((long)n * 4) * KD + kc;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                int k = lane + 64 * u;
+                float sum = __fadd_rn(__fadd_rn(__fadd_rn(r0[k], r0[KD + k]), r0[2 * KD + k]), r0[3 * KD + k]);
+                tile[q][k] = sum * 0.25f;
+            }
+        }
+        __syncthreads();
+        for (int kk = tid >> 5; kk < 192; kk += 8) {
+            int q = tid & 31;
+            int n = n0 + q;
+            if (n < ncols) {
+                int b = n / T, t = n - b * T;
+                out[((long)b * KD + kc + kk) * T + t] = tile[q][kk];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int run_knn_topk(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, const float* prepared, int64_t N,
+                 float* sims_out, int64_t* idx_out, int B, int T) {
+    const int ncols = B * T;
+    const long Npad = npad128(N);
+    const int qtiles = (ncols + 127) / 128;
+    const int mtiles = (int)(Npad / 128);
+    int nsplit = (KNN_BLOCKS + qtiles - 1) / qtiles;
+    if (nsplit > mtiles) nsplit = mtiles;
+    if (nsplit < 1) nsplit = 1;
+    const int tps = (mtiles + nsplit - 1) / nsplit;
+    nsplit = (mtiles + tps - 1) / tps;
+    float* qn = ws.get<float>((size_t)B * KD * T);
+    float* cv = ws.get<float>((size_t)nsplit * ncols * 4);
+    int* ci = ws.get<int>((size_t)nsplit * ncols * 4);
+    if (dry) return 0;
+    if (N > 0x7fffff00L) return fail(ctx, TVC_ERR_ARG, "index too large");
+    hipLaunchKernelGGL(query_normalize_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, src, qn, B, T);
+    const uint4* img = reinterpret_cast<const uint4*>(prepared + (size_t)KD * Npad + (size_t)N * KD);
+    hipLaunchKernelGGL(knn_topk_split_kernel, dim3((unsigned)(qtiles * nsplit)), dim3(512), 0, s, img, Npad, (int)N, qn, ncols, T, nsplit, tps, cv, ci);
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((ncols + 255) / 256), dim3(256), 0, s, cv, ci, nsplit, ncols, sims_out, idx_out);
+    return launch_check(ctx, "knn_topk");
+}
+
+int run_knn_slots(tvc_ctx* ctx, hipStream_t s, const float* prepared, int64_t N, const int64_t* idx, float* slots, int64_t nslots) {
+    const float* rows = prepared + (size_t)KD * npad128(N);
+    hipLaunchKernelGGL(knn_slot_gather_kernel, dim3((unsigned)nslots), dim3(192), 0, s, rows, idx, (long)nslots, (long)N, slots);
+    return launch_check(ctx, "knn_slots");
+}
+
+int run_knn_finish(tvc_ctx* ctx, hipStream_t s, const float* slots, float* out, int B, int T) {
+    const int ncols = B * T;
+    hipLaunchKernelGGL(knn_finish_kernel, dim3((ncols + 31) / 32), dim3(256), 0, s, slots, ncols, T, out);
+    return launch_check(ctx, "knn_finish");
+}
+
 int run_knn(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, const float* prepared, int64_t N,
             float* out, int64_t* idx_out, int B, int T) {
     const int ncols = B * T;

@@ -201,6 +201,10 @@ int run_encoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* spec, float* 
                 float* logits, int B, int T);
 int run_knn(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* src, const float* prepared, int64_t N,
             float* out, int64_t* idx_out, int B, int T);
+int run_knn_topk(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* src, const float* prepared, int64_t N,
+                 float* sims_out, int64_t* idx_out, int B, int T);
+int run_knn_slots(tvc_ctx*, hipStream_t, const float* prepared, int64_t N, const int64_t* idx, float* slots, int64_t nslots);
+int run_knn_finish(tvc_ctx*, hipStream_t, const float* slots, float* out, int B, int T);
 int run_shift(tvc_ctx*, hipStream_t, const float* f0, float* out, int64_t n, float semitones);
 int run_decoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* content, const float* f0,
                 const float* energy, const float* angle, uint64_t seed, float* wave, float* amps_out,

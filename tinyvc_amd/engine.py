@@ -183,6 +183,34 @@ class Engine:
         self._ok(self.lib.tvc_knn_match_f32(self.ctx, self._stream(), _ptr(src), _ptr(prepared), N, _ptr(out), _ptr(idx), B, T, p, n), "tvc_knn_match_f32")
         return (out, idx) if want_indices else out
 
+    # ---- index-sharded match (one prepared index shard per rank; merged by parallel.match_features_sharded) ----
+    def knn_topk(self, src, prepared, N):
+        """This shard's top-4 per query: (sims [B,T,4] fp32 descending, idx [B,T,4] int64 local indices)."""
+        src = _prep(src, "source", self.device)
+        B, C, T = src.shape
+        if C != spec.SSL_DIM:
+            raise ValueError(f"source must have {spec.SSL_DIM} channels")
+        sims = torch.empty(B, T, 4, dtype=_F32, device=self.device)
+        idx = torch.empty(B, T, 4, dtype=torch.int64, device=self.device)
+        p, n = self._wsargs(B, T * spec.HOP, N)
+        self._ok(self.lib.tvc_knn_topk_f32(self.ctx, self._stream(), _ptr(src), _ptr(prepared), N, _ptr(sims), _ptr(idx), B, T, p, n), "tvc_knn_topk_f32")
+        return sims, idx
+
+    def knn_gather_slots(self, prepared, N, idx):
+        """idx [B,T,4] int64 local indices (negative = not on this shard) -> slots [B,T,4,768] raw rows / zeros."""
+        idx = idx.to(device=self.device, dtype=torch.int64).contiguous()
+        slots = torch.empty(*idx.shape, spec.SSL_DIM, dtype=_F32, device=self.device)
+        self._ok(self.lib.tvc_knn_gather_slots_f32(self.ctx, self._stream(), _ptr(prepared), N, _ptr(idx), _ptr(slots), idx.numel()), "tvc_knn_gather_slots_f32")
+        return slots
+
+    def knn_finish(self, slots):
+        """slots [B,T,4,768] -> [B,768,T]: mean of the four rows in the single-GPU summation order."""
+        slots = _prep(slots, "slots", self.device)
+        B, T = slots.shape[0], slots.shape[1]
+        out = torch.empty(B, spec.SSL_DIM, T, dtype=_F32, device=self.device)
+        self._ok(self.lib.tvc_knn_finish_f32(self.ctx, self._stream(), _ptr(slots), _ptr(out), B, T), "tvc_knn_finish_f32")
+        return out
+
     def shift_frequency(self, f0, semitones):
         f0 = _prep(f0, "f0", self.device)
         out = torch.empty_like(f0)

@@ -40,3 +40,35 @@ def convert_sharded(convert_fn, waves, *args, dst: int = 0, group=None, **kwargs
     lo, hi = shard_bounds(waves.shape[0], rank, world)
     out = convert_fn(waves[lo:hi], *args, **kwargs)
     return gather_waves(out, waves.shape[0], dst=dst, group=group)
+
+
+# ---- a very large speaker index sharded over the GPUs of a node (SURVEY.md 8e variant) --------------------------
+def merge_topk(sims, idx, k: int = 4):
+    """sims, idx [..., C]: candidates (similarity, global index) -> the k best per query, ordered by similarity
+    descending and, for equal similarities, index ascending (the library's tie rule).  Returns (sims, idx) [..., k]."""
+    # stable two-key sort: first by index ascending, then (stable) by similarity descending
+    order = torch.argsort(idx, dim=-1, stable=True)
+    s1, i1 = torch.gather(sims, -1, order), torch.gather(idx, -1, order)
+    order = torch.argsort(s1, dim=-1, descending=True, stable=True)
+    return torch.gather(s1, -1, order)[..., :k], torch.gather(i1, -1, order)[..., :k]
+
+
+def match_features_sharded(engine, source, prepared, n_local: int, shard_start: int, group=None):
+    """match_features (reference feature_retrieval.py:15-33, k=4, alpha=0, cos) against an index whose vectors
+    [shard_start, shard_start + n_local) live on this rank as the prepared blob `prepared`.  Every rank passes the same
+    `source` [B,768,T] and gets the same [B,768,T] back.  Exchanges: one all_gather of the local top-4
+    (similarity, global index) = 48 B per query and rank, and one all_reduce of the selected raw rows
+    [B,T,4,768] in which every slot has exactly one non-zero contributor (so the sum is exact)."""
+    world = dist.get_world_size(group)
+    sims, idx = engine.knn_topk(source, prepared, n_local)
+    gidx = idx + shard_start
+    all_s = [torch.empty_like(sims) for _ in range(world)]
+    all_i = [torch.empty_like(gidx) for _ in range(world)]
+    dist.all_gather(all_s, sims.contiguous(), group=group)
+    dist.all_gather(all_i, gidx.contiguous(), group=group)
+    _, sel = merge_topk(torch.cat(all_s, dim=-1), torch.cat(all_i, dim=-1))
+    local = sel - shard_start
+    local = torch.where((local >= 0) & (local < n_local), local, torch.full_like(local, -1))
+    slots = engine.knn_gather_slots(prepared, n_local, local)
+    dist.all_reduce(slots, op=dist.ReduceOp.SUM, group=group)
+    return engine.knn_finish(slots), sel
