@@ -23,7 +23,9 @@ namespace tvc {
 // One workgroup = 64 consecutive time steps of one utterance; its 16 waves split the channels
 // (c = wave, wave+16, ...), lanes run along time (coalesced).  Two-pass moments (mean, then
 // centred variance) through a 16x64 LDS exchange; every thread re-reads only values it wrote.
-template <bool DW>
+// CPT = channels per thread (C = 16 * CPT): the conv outputs stay in registers across the two moment passes and are
+// written once, normalised (the first version wrote them, re-read them twice and wrote again).
+template <bool DW, int CPT>
 static __global__ __launch_bounds__(1024) void dwconv_ln_kernel(const float* x, float* y,
                                                                const float* __restrict__ dw_w, const float* __restrict__ dw_b,
                                                                const float* __restrict__ g, const float* __restrict__ bta,
@@ -38,23 +40,27 @@ static __global__ __launch_bounds__(1024) void dwconv_ln_kernel(const float* x, 
     const float* xb = x + (long)b * C * T;
     float* yb = y + (long)b * C * T;
 
+    int tt[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        int q = tc + (j - 3) * dil;
+        tt[j] = q < 0 ? 0 : (q >= T ? T - 1 : q);
+    }
+    float v[CPT];
     float sum = 0.f;
-    for (int c = wave; c < C; c += NW) {
-        float v;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = wave + i * NW;
         if (DW) {
             const float* xr = xb + (long)c * T;
-            v = dw_b[c];
+            float a = dw_b[c];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                int tt = tc + (j - 3) * dil;
-                tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
-                v = fmaf(dw_w[c * 7 + j], xr[tt], v);
-            }
-            if (ok) yb[(long)c * T + t] = v;
+            for (int j = 0; j < 7; ++j) a = fmaf(dw_w[c * 7 + j], xr[tt[j]], a);
+            v[i] = a;
         } else {
-            v = xb[(long)c * T + tc];
+            v[i] = xb[(long)c * T + tc];
         }
-        sum += v;
+        sum += v[i];
     }
     red[wave][lane] = sum;
     __syncthreads();
@@ -64,9 +70,10 @@ static __global__ __launch_bounds__(1024) void dwconv_ln_kernel(const float* x, 
     const float mean = tot / (float)C;
     __syncthreads();
     float sq = 0.f;
-    for (int c = wave; c < C; c += NW) {
-        float v = (DW ? yb : xb)[(long)c * T + tc] - mean;
-        sq = fmaf(v, v, sq);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const float d = v[i] - mean;
+        sq = fmaf(d, d, sq);
     }
     red[wave][lane] = sq;
     __syncthreads();
@@ -76,11 +83,20 @@ static __global__ __launch_bounds__(1024) void dwconv_ln_kernel(const float* x, 
     const float var = tot2 / (float)C;
     const float rstd = 1.f / sqrtf(var + 1e-5f);
     if (!ok) return;
-    for (int c = wave; c < C; c += NW) {
-        long i = (long)c * T + t;
-        float v = (DW ? yb : xb)[i];
-        yb[i] = fmaf((v - mean) * rstd, g[c], bta[c]);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = wave + i * NW;
+        yb[(long)c * T + t] = fmaf((v[i] - mean) * rstd, g[c], bta[c]);
     }
+}
+template <bool DW>
+static int dwconv_ln_launch(tvc_ctx* ctx, hipStream_t s, const float* x, float* y, const float* dw_w, const float* dw_b, const float* g,
+                            const float* bta, int B, int C, int T, int dil) {
+    const dim3 grid((T + 63) / 64, B), blk(1024);
+    if (C == 384) hipLaunchKernelGGL((dwconv_ln_kernel<DW, 24>), grid, blk, 0, s, x, y, dw_w, dw_b, g, bta, C, T, dil);
+    else if (C == 128) hipLaunchKernelGGL((dwconv_ln_kernel<DW, 8>), grid, blk, 0, s, x, y, dw_w, dw_b, g, bta, C, T, dil);
+    else return fail(ctx, TVC_ERR_ARG, "dwconv_ln: unsupported channel count %d", C);
+    return 0;
 }
 
 // gx[b][c] = || h[b][c][:] ||_2   (one wavefront per row)
@@ -117,7 +133,7 @@ static __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* _
 }
 
 int run_layernorm(tvc_ctx* ctx, hipStream_t s, float* x, const float* g, const float* b, int B, int C, int T) {
-    hipLaunchKernelGGL((dwconv_ln_kernel<false>), dim3((T + 63) / 64, B), dim3(1024), 0, s, x, x, nullptr, nullptr, g, b, C, T, 1);
+    TVC_CHECK(dwconv_ln_launch<false>(ctx, s, x, x, nullptr, nullptr, g, b, B, C, T, 1));
     return launch_check(ctx, "layernorm");
 }
 
@@ -131,7 +147,7 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     ws.release(mk);
     if (dry) return 0;
     {
-        hipLaunchKernelGGL((dwconv_ln_kernel<true>), dim3((T + 63) / 64, B), dim3(1024), 0, s, x, y, w.dw_w, w.dw_b, w.ln_g, w.ln_b, C, T, w.dilation);
+        TVC_CHECK(dwconv_ln_launch<true>(ctx, s, x, y, w.dw_w, w.dw_b, w.ln_g, w.ln_b, B, C, T, w.dilation));
     }
     {
         EpiBias<ACT_GELU, false> ep{h, w.c2.bias, nullptr, C2, T, ncols, (long)C2 * T, 0};
