@@ -601,7 +601,8 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
                            const float* kscale = nullptr, bool flat = false) {
     if (Cin % (16 * TL::KG) != 0 || (FILM && Ccond % 16 != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of the slab depth");
     if (Cin / 16 > w.S6) return fail(ctx, TVC_ERR_ARG, "conv3s: weight image has fewer K16 steps than the launch walks");
-    static bool ready = false;
+    static bool ready_dev[64] = {};                 // the attribute is per (function, device): one flag per device of this process
+    bool& ready = ready_dev[ctx->device & 63];
     constexpr int lds = TL::lds_bytes(TAPS);
     if (!ready) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED>,
@@ -634,7 +635,8 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
         a.Ccond = Ccond;
     }
     a.ntiles = (a.MT / TL::MTB) * a.tiles_per_utt * B;
-    static int ncu = 0;
+    static int ncu_dev[64] = {};
+    int& ncu = ncu_dev[ctx->device & 63];
     if (!ncu) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv3s: device properties");

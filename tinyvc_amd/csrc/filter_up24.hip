@@ -392,7 +392,8 @@ __global__ __launch_bounds__(CF::NT) void up24_kernel(Up24Args a) {
 
 template <class CF>
 static int launch_up24(tvc_ctx* ctx, hipStream_t s, Up24Args a, int B) {
-    static int ncu = 0;
+    static int ncu_dev[64] = {};                    // per device of this process (the LDS attribute is per function and device)
+    int& ncu = ncu_dev[ctx->device & 63];
     const size_t lds = (size_t)CF::LDS_FLOATS * sizeof(float);
     if (!ncu) {
         hipDeviceProp_t prop;
