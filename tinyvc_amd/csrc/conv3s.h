@@ -52,6 +52,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef TVC_S_FLAT
 #define TVC_S_FLAT 1   // GEMM launches tile the flattened B * T column axis instead of every utterance separately
 #endif
+#ifndef S_XCD_MAP
+#define S_XCD_MAP 1   // row blocks of one column tile walk on the same XCD (shared L2)
+#endif
 #ifndef S_BPC
 #define S_BPC 1     // persistent workgroups per CU
 #endif
@@ -477,22 +480,44 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the first slab of every phase - including the
     // first phase of the NEXT tile - is loaded behind the last slab of the one before it, so only the very first
     // load of a workgroup is cold and the output stores of a tile overlap the next tile's input loads
-    auto coords = [&](int tile, int& mt0, int& b, int& t0) __attribute__((always_inline)) {
-        mt0 = (tile % mblocks) * MTB;
-        const int nt_id = tile / mblocks;
+    // Tile walk order.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8) and the persistent grid is a
+    // multiple of 8, so virtual tile v always runs on XCD v % 8.  All `mblocks` row blocks of one column tile re-read the
+    // same input tile: give them the same v % 8, i.e. the same L2 (the XCD L2s do not share), instead of spreading them
+    // over mblocks different ones:  v = ((nt / 8) * mblocks + mb) * 8 + nt % 8.
+    const int ncoltiles = ntiles / mblocks;
+    const int vtiles = S_XCD_MAP ? (ncoltiles + 7) / 8 * 8 * mblocks : ntiles;
+    auto coords = [&](int v, int& mt0, int& b, int& t0) __attribute__((always_inline)) -> bool {
+        int mb, nt_id;
+        if (S_XCD_MAP) {
+            const int r = v & 7, u = v >> 3;
+            mb = u % mblocks;
+            nt_id = (u / mblocks) * 8 + r;
+        } else {
+            mb = v % mblocks;
+            nt_id = v / mblocks;
+        }
+        mt0 = mb * MTB;
         b = nt_id / a.tiles_per_utt;
         t0 = (nt_id - b * a.tiles_per_utt) * TL::BN;
+        return nt_id < ncoltiles;
+    };
+    const int stride = gridDim.x;
+    auto next_valid = [&](int v) __attribute__((always_inline)) -> int {   // first valid virtual tile at or after v on this workgroup's walk
+        int m_, b_, t_;
+        while (v < vtiles && !coords(v, m_, b_, t_)) v += stride;
+        return v;
     };
     SlabRegs<TL> regs;
-    int tile = blockIdx.x, mt0, b, t0;
+    int tile = next_valid(blockIdx.x), mt0 = 0, b = 0, t0 = 0;
+    if (tile >= vtiles) return;
     coords(tile, mt0, b, t0);
     const int fT = a.flatT;
     const unsigned fstride = (unsigned)a.xstride;
     first_load<TL, TAPS>(regs, a.A6, a.MT, mt0, fT ? a.x : a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0, fT, fstride);
-    while (tile < ntiles) {
-        const int nxt = tile + gridDim.x;
+    while (tile < vtiles) {
+        const int nxt = next_valid(tile + stride);
         auto load_next_tile = [&]() __attribute__((always_inline)) {
-            if (nxt < ntiles) {
+            if (nxt < vtiles) {
                 int mt0n, bn, t0n;
                 coords(nxt, mt0n, bn, t0n);
                 first_load<TL, TAPS>(regs, a.A6, a.MT, mt0n, fT ? a.x : a.x + (long)bn * a.xstride, a.Cin, len, a.dil, t0n, fT, fstride);
@@ -502,7 +527,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         // this tile's bias rows -> LDS: read back with ds_read (lgkmcnt), so the epilogue math never waits on vmcnt
         // while the next phase's prefetch is in flight (a global bias load would drag that whole prefetch with it)
         float* Bs = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS);
-        if constexpr (!Epi::kIgemm) if (tile == (int)blockIdx.x || mblocks > 1) {
+        if constexpr (!Epi::kIgemm) {
             for (int i = threadIdx.x; i < TL::BM; i += TL::NTHR) {
                 int m = mt0 * 32 + i;
                 m = m < ep.M ? m : ep.M - 1;
@@ -576,7 +601,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                         }
                     }
                 tile = nxt;
-                if (tile < ntiles) coords(tile, mt0, b, t0);
+                if (tile < vtiles) coords(tile, mt0, b, t0);
                 continue;
             }
 #pragma unroll
@@ -591,7 +616,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 if (!(S_ABL & 16)) tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, ep.y2, ep.f2);
         }
         tile = nxt;
-        if (tile < ntiles) coords(tile, mt0, b, t0);
+        if (tile < vtiles) coords(tile, mt0, b, t0);
     }
 }
 
@@ -642,8 +667,10 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
         if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv3s: device properties");
         ncu = prop.multiProcessorCount;
     }
-    const int slots = ncu * bpc;                 // persistent: one resident workgroup per slot walks the tiles
-    dim3 g((unsigned)(a.ntiles < slots ? a.ntiles : slots));
+    const int slots = (ncu * bpc) / 8 * 8;        // persistent: one resident workgroup per slot walks the tiles (multiple of 8: see the XCD walk)
+    const int mblocks = a.MT / TL::MTB;
+    const int vtiles = S_XCD_MAP ? (a.ntiles / mblocks + 7) / 8 * 8 * mblocks : a.ntiles;
+    dim3 g((unsigned)(vtiles < slots ? vtiles : slots));
     hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED>), g, dim3(TL::NTHR), lds, s, a, ep);
     return 0;
 }
