@@ -104,6 +104,7 @@ struct ConvSArgs {
     const float* x;      // [B][Cin][len], utterance b at x + b * xstride
     long xstride;
     int Cin, len, dil, tiles_per_utt, ntiles;
+    int cmax = 0;        // > 0: input rows above cmax do not exist (their weights are zero): loads clamp the row index to cmax
     int flatT = 0;       // > 0: flat GEMM tiles over the B * flatT columns (len = B * flatT, B = 1 for the tile walk)
     const float* kscale = nullptr;   // optional per-(utterance, input channel) factor applied while staging (SCALED kernels), [B][Cin]
     const uint4* sc6 = nullptr;   // stacked FiLM [to_scale ; to_shift] image (1x1 over cond), FILM kernels only
@@ -148,6 +149,7 @@ struct SlabMap {
     int xdst[TL::X_PER];       // LDS row of the item, -1 = idle
     int xg8[TL::X_PER];        // first channel of the item inside the slab (0 or 8)
     int xk[TL::X_PER];         // flat GEMM tiles: factor-row offset of the item's utterance inside the staged Ks
+    unsigned xp[TL::X_PER];    // xo without its channel term (row-clamped launches rebuild the channel term per load)
 };
 // fT > 0 = flat GEMM tiles: the tile's columns are positions n = b * fT + t of the flattened [B * fT] axis (len = B * fT),
 // utterance b starts at element b * fstride, channels are fT apart; a tile may straddle utterances.
@@ -167,9 +169,11 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
         m.xg8[i] = ks * 16 + 8 * g;
         if (fT > 0) {
             const int b = p / fT, t = p - b * fT;
-            m.xo[i] = (unsigned)b * fstride + (unsigned)(m.xg8[i] * fT + t);
+            m.xp[i] = (unsigned)b * fstride + (unsigned)t;
+            m.xo[i] = m.xp[i] + (unsigned)(m.xg8[i] * fT);
             m.xk[i] = (b - t0 / fT) * kcin;
         } else {
+            m.xp[i] = (unsigned)p;
             m.xo[i] = (unsigned)(m.xg8[i] * len + p);
             m.xk[i] = 0;
         }
@@ -178,7 +182,7 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
 // global -> registers only (no use of the values here: the loads stay in flight behind the MFMAs)
 template <class TL, int TAPS>
 __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ A6, int MT, int mt0,
-                                          const float* __restrict__ xb, int Cin, int len, int s, int fT = 0) {
+                                          const float* __restrict__ xb, int Cin, int len, int s, int fT = 0, int cmax = 0) {
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER, STEPS = TAPS * TL::KG;
     const int cs = fT > 0 ? fT : len;                    // channel stride
     constexpr int PIECES = STEPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
@@ -198,6 +202,17 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
     if (S_ABL & 4) return;
     const float* xc = xb + (long)ci0 * cs;               // uniform base, 32-bit lane offsets
     // Cin % 16 == 0 is a launch precondition (every level routed here has 48/96/192/384 channels): no ragged slab
+    if (cmax > 0 && ci0 + 16 * TL::KG > cmax + 1) {      // the slab reaches past the last real input row: clamp (zero weights there)
+#pragma unroll
+        for (int i = 0; i < X_PER; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int cj = ci0 + m.xg8[i] + j;
+                cj = cj < cmax ? cj : cmax;
+                r.xr[i][j] = xb[m.xp[i] + (unsigned)(cj * cs)];
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < X_PER; ++i)
 #pragma unroll
@@ -206,10 +221,10 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
 // slab 0 of a phase, issued by whoever runs before it (previous phase / previous tile / kernel entry)
 template <class TL, int TAPS>
 __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0, const float* __restrict__ xb,
-                                           int Cin, int len, int dil, int t0, int fT = 0, unsigned fstride = 0) {
+                                           int Cin, int len, int dil, int t0, int fT = 0, unsigned fstride = 0, int cmax = 0) {
     SlabMap<TL> m;
     make_map<TL>(m, len, dil, t0, fT, fstride);
-    slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT);
+    slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT, cmax);
 }
 
 // acc += W (.) x over all slabs of one input tensor.  Slab 0 is already in flight in `r` (first_load); `next()`
@@ -217,7 +232,7 @@ __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restr
 template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, class Next>
 __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
                                             const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next,
-                                            const float* Ks = nullptr, int fT = 0, unsigned fstride = 0) {
+                                            const float* Ks = nullptr, int fT = 0, unsigned fstride = 0, int cmax = 0) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -261,7 +276,7 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     for (int s = 0; s < nslab; ++s) {
         slab_barrier();                            // every wave is done reading the previous slab
         lstore(s);                                 // slab s: registers -> LDS
-        if (s + 1 < nslab) slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT);   // flies across this slab's MFMAs
+        if (s + 1 < nslab) slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax);   // flies across this slab's MFMAs
         else next();
         slab_barrier();
         // fragments of tap t+1 are read while the MFMAs of tap t run
@@ -513,14 +528,14 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     coords(tile, mt0, b, t0);
     const int fT = a.flatT;
     const unsigned fstride = (unsigned)a.xstride;
-    first_load<TL, TAPS>(regs, a.A6, a.MT, mt0, fT ? a.x : a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0, fT, fstride);
+    first_load<TL, TAPS>(regs, a.A6, a.MT, mt0, fT ? a.x : a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0, fT, fstride, a.cmax);
     while (tile < vtiles) {
         const int nxt = next_valid(tile + stride);
         auto load_next_tile = [&]() __attribute__((always_inline)) {
             if (nxt < vtiles) {
                 int mt0n, bn, t0n;
                 coords(nxt, mt0n, bn, t0n);
-                first_load<TL, TAPS>(regs, a.A6, a.MT, mt0n, fT ? a.x : a.x + (long)bn * a.xstride, a.Cin, len, a.dil, t0n, fT, fstride);
+                first_load<TL, TAPS>(regs, a.A6, a.MT, mt0n, fT ? a.x : a.x + (long)bn * a.xstride, a.Cin, len, a.dil, t0n, fT, fstride, a.cmax);
             }
         };
         const float* xb = fT ? a.x : a.x + (long)b * a.xstride;
@@ -583,7 +598,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
         } else {
             split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (TL::NW <= 8 ? S_FB_G : S_FB), SCALED>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile, Ks, fT,
-                                                                             fstride);
+                                                                             fstride, a.cmax);
             if constexpr (Epi::kIgemm) {
                 // plain GEMM use (B = 1, len = all columns): the igemm epilogue functors finish the element
                 const int l31 = lane & 31, wn = wave - wm * TL::NWV;
@@ -623,7 +638,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
 template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false>
 inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
                            const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond, long xstride = 0, int bpc = S_BPC,
-                           const float* kscale = nullptr, bool flat = false) {
+                           const float* kscale = nullptr, bool flat = false, int cmax = 0) {
     if (Cin % (16 * TL::KG) != 0 || (FILM && Ccond % 16 != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of the slab depth");
     if (Cin / 16 > w.S6) return fail(ctx, TVC_ERR_ARG, "conv3s: weight image has fewer K16 steps than the launch walks");
     static bool ready_dev[64] = {};                 // the attribute is per (function, device): one flag per device of this process
@@ -640,6 +655,7 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     a.MT = w.MT6;
     if (SCALED && (!kscale || Cin > 768)) return fail(ctx, TVC_ERR_ARG, "conv3s: scaled launch needs factors for <= 768 channels");
     a.kscale = kscale;
+    a.cmax = cmax;
     a.x = x;
     a.xstride = xstride ? xstride : (long)Cin * len;
     a.Cin = Cin;
@@ -724,22 +740,26 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
 // functor (store(n, m, v[4])).  Cin must be a multiple of 16 and rows [K, Cin) must be readable (weights there are 0).
 template <int MTB, int NWV, int BPC, int KG, class Epi, bool SCALED>
 inline int gemm_s_launch_k(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
-                           const float* kscale) {
+                           const float* kscale, int cmax) {
     using TL = SplitTile<MTB, 1, NWV, 1, KG, 0>;
     // flat column tiles unless a tile could touch more than two utterances of a SCALED launch (factors of two are staged)
     // or the element offsets would not fit 32 bits
     const long xs = xstride ? xstride : (long)Cin * len;
     const bool flat = TVC_S_FLAT && B > 1 && xs * B < (1L << 31) && (!SCALED || len >= TL::BN);
-    return conv3s_launch_t<TL, 1, false, Epi, false, SCALED>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride, BPC, kscale, flat);
+    return conv3s_launch_t<TL, 1, false, Epi, false, SCALED>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride, BPC, kscale, flat, cmax);
 }
 template <int MTB, int NWV, int BPC, class Epi, bool SCALED = false>
 inline int gemm_s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
-                         const float* kscale = nullptr) {
+                         const float* kscale = nullptr, int krows = 0) {
     if (w.MT6 % MTB != 0) return fail(ctx, TVC_ERR_ARG, "gemm_s: row tiles do not divide");
+    // krows > 0: the input has only krows channel rows per utterance; Cin is rounded up to whole slabs and the loads of the
+    // missing rows are clamped to the last real one (their weights are zero)
+    const int cmax = krows > 0 ? krows - 1 : 0;
+    if (krows > 0) Cin = (krows + 31) / 32 * 32;
     // deepest slab the channel count allows: 48, 32 or 16 input channels per load -> LDS -> barrier round trip
-    if (TVC_S_KG >= 3 && Cin % 48 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 3, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale);
-    if (TVC_S_KG >= 2 && Cin % 32 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 2, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale);
-    return gemm_s_launch_k<MTB, NWV, BPC, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale);
+    if (TVC_S_KG >= 3 && Cin % 48 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 3, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, cmax);
+    if (TVC_S_KG >= 2 && Cin % 32 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 2, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, cmax);
+    return gemm_s_launch_k<MTB, NWV, BPC, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, cmax);
 }
 
 }  // namespace tvc

@@ -6,6 +6,9 @@
 
 namespace tvc {
 
+#ifndef TVC_SPLIT_ENC_IN
+#define TVC_SPLIT_ENC_IN 1
+#endif
 #ifndef TVC_ENC_FORK
 #define TVC_ENC_FORK 1    // pitch estimator on the side stream, beside the SSL chain
 #endif
@@ -176,6 +179,7 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
 
 // stacked input 1x1 (961 -> 384 | 128): rows < M0 go to y0, the rest to y1
 struct EpiSplit {
+    static constexpr bool kIgemm = true;
     float* y0;
     float* y1;
     const float* bias;
@@ -254,9 +258,14 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     float* xp = ws.get<float>((size_t)B * kPitchCh * T);
     float* lg = logits ? logits : ws.get<float>((size_t)B * kPitchClasses * T);
     if (!dry) {
-        LoadPlain ld{spec, kBins, T, (long)kBins * T};
         EpiSplit ep{xs, xp, ctx->enc_in.bias, kSslCh, kPitchCh, T, ncols};
-        igemm_launch(s, ctx->enc_in.At, ctx->enc_in.Mpad, ctx->enc_in.Kpad, ncols, T, ld, ep);
+        if (TVC_SPLIT_ENC && TVC_SPLIT_ENC_IN && ctx->enc_in.MT6 % ENC_MTB == 0) {
+            // 961 input rows: the last slab is clamped to row 960 (zero weights beyond)
+            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->enc_in, spec, B, kBins, T, (long)kBins * T, ep, nullptr, kBins)));
+        } else {
+            LoadPlain ld{spec, kBins, T, (long)kBins * T};
+            igemm_launch(s, ctx->enc_in.At, ctx->enc_in.Mpad, ctx->enc_in.Kpad, ncols, T, ld, ep);
+        }
         TVC_CHECK(run_layernorm(ctx, s, xs, ctx->ssl_ln_g, ctx->ssl_ln_b, B, kSslCh, T));
         TVC_CHECK(run_layernorm(ctx, s, xp, ctx->pit_ln_g, ctx->pit_ln_b, B, kPitchCh, T));
     }
