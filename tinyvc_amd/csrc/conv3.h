@@ -98,6 +98,10 @@ struct C3EpiFilmFused {
     const float* bsh;
     const float* res;
     int M, len;
+    // conv3s.h only: res_lin > 0 -> `res` is the low-rate [B][M][res_lin] tensor and the residual is its
+    // F.interpolate(scale_factor) (ATen scale float(1/scale_factor) in res_scale), evaluated in the epilogue
+    int res_lin = 0;
+    float res_scale = 0.f;
     __device__ __forceinline__ void store(int b, int t, int m, const float h[4], const float sc[4], const float sh[4]) const {
 #pragma unroll
         for (int r = 0; r < 4; ++r)

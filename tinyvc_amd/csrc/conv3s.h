@@ -22,6 +22,7 @@
 #pragma once
 #include <type_traits>
 #include "conv3.h"
+#include "small_kernels.h"
 #include "tvc_common.h"
 
 namespace tvc {
@@ -104,6 +105,8 @@ struct ConvSArgs {
     const float* x;      // [B][Cin][len], utterance b at x + b * xstride
     long xstride;
     int Cin, len, dil, tiles_per_utt, ntiles;
+    int lin = 0;         // LERP kernels: x is the low-rate tensor [B][Cin][lin]; the conv input is F.interpolate(x, scale_factor) = len samples
+    float lscale = 0.f;  //               ATen's source-coordinate scale float(1 / scale_factor)
     int cmax = 0;        // > 0: input rows above cmax do not exist (their weights are zero): loads clamp the row index to cmax
     int flatT = 0;       // > 0: flat GEMM tiles over the B * flatT columns (len = B * flatT, B = 1 for the tile walk)
     const float* kscale = nullptr;   // optional per-(utterance, input channel) factor applied while staging (SCALED kernels), [B][Cin]
@@ -142,6 +145,7 @@ struct SlabRegs {
     static constexpr int A_MAX = (3 * TL::KG * TL::MTB * 3 + TL::NW - 1) / TL::NW;   // up to 3 taps x KG channel groups of weight pieces
     u32x4 ar[A_MAX];
     float xr[TL::X_PER][8];
+    float xr2[TL::X_PER][8];   // LERP staging: the second interpolation tap
 };
 template <class TL>
 struct SlabMap {
@@ -150,11 +154,14 @@ struct SlabMap {
     int xg8[TL::X_PER];        // first channel of the item inside the slab (0 or 8)
     int xk[TL::X_PER];         // flat GEMM tiles: factor-row offset of the item's utterance inside the staged Ks
     unsigned xp[TL::X_PER];    // xo without its channel term (row-clamped launches rebuild the channel term per load)
+    unsigned xo1[TL::X_PER];   // LERP staging: offset of the second tap; w0 / w1 = the two weights (xo = first tap)
+    float w0[TL::X_PER], w1[TL::X_PER];
 };
 // fT > 0 = flat GEMM tiles: the tile's columns are positions n = b * fT + t of the flattened [B * fT] axis (len = B * fT),
 // utterance b starts at element b * fstride, channels are fT apart; a tile may straddle utterances.
-template <class TL>
-__device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t0, int fT = 0, unsigned fstride = 0, int kcin = 0) {
+template <class TL, bool LERP = false>
+__device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t0, int fT = 0, unsigned fstride = 0, int kcin = 0, int lin = 0,
+                                         float lscale = 0.f) {
     const int xw = TL::BN + 2 * dil;
 #pragma unroll
     for (int i = 0; i < TL::X_PER; ++i) {
@@ -172,6 +179,16 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
             m.xp[i] = (unsigned)b * fstride + (unsigned)t;
             m.xo[i] = m.xp[i] + (unsigned)(m.xg8[i] * fT);
             m.xk[i] = (b - t0 / fT) * kcin;
+        } else if (LERP) {
+            // the conv input at position p (already clamped = replicate padding of the interpolated signal) is
+            // w0 * x[i0] + w1 * x[i1] of the low-rate row (ATen linear, align_corners = False: small_kernels.h)
+            const Lerp lc = lerp_coord(p, lscale, lin);
+            m.xp[i] = (unsigned)lc.i0;
+            m.xo[i] = (unsigned)(m.xg8[i] * lin + lc.i0);
+            m.xo1[i] = (unsigned)(m.xg8[i] * lin + lc.i1);
+            m.w0[i] = lc.w0;
+            m.w1[i] = lc.w1;
+            m.xk[i] = 0;
         } else {
             m.xp[i] = (unsigned)p;
             m.xo[i] = (unsigned)(m.xg8[i] * len + p);
@@ -180,11 +197,11 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
     }
 }
 // global -> registers only (no use of the values here: the loads stay in flight behind the MFMAs)
-template <class TL, int TAPS>
+template <class TL, int TAPS, bool LERP = false>
 __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ A6, int MT, int mt0,
-                                          const float* __restrict__ xb, int Cin, int len, int s, int fT = 0, int cmax = 0) {
+                                          const float* __restrict__ xb, int Cin, int len, int s, int fT = 0, int cmax = 0, int lin = 0) {
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER, STEPS = TAPS * TL::KG;
-    const int cs = fT > 0 ? fT : len;                    // channel stride
+    const int cs = LERP ? lin : (fT > 0 ? fT : len);     // channel stride
     constexpr int PIECES = STEPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
     static_assert(A_PER <= SlabRegs<TL>::A_MAX, "weight pieces must fit the staging registers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -202,6 +219,16 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
     if (S_ABL & 4) return;
     const float* xc = xb + (long)ci0 * cs;               // uniform base, 32-bit lane offsets
     // Cin % 16 == 0 is a launch precondition (every level routed here has 48/96/192/384 channels): no ragged slab
+    if (LERP) {
+#pragma unroll
+        for (int i = 0; i < X_PER; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                r.xr[i][j] = xc[m.xo[i] + (unsigned)(j * cs)];
+                r.xr2[i][j] = xc[m.xo1[i] + (unsigned)(j * cs)];
+            }
+        return;
+    }
     if (cmax > 0 && ci0 + 16 * TL::KG > cmax + 1) {      // the slab reaches past the last real input row: clamp (zero weights there)
 #pragma unroll
         for (int i = 0; i < X_PER; ++i)
@@ -219,26 +246,27 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
         for (int j = 0; j < 8; ++j) r.xr[i][j] = xc[m.xo[i] + (unsigned)(j * cs)];
 }
 // slab 0 of a phase, issued by whoever runs before it (previous phase / previous tile / kernel entry)
-template <class TL, int TAPS>
+template <class TL, int TAPS, bool LERP = false>
 __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0, const float* __restrict__ xb,
-                                           int Cin, int len, int dil, int t0, int fT = 0, unsigned fstride = 0, int cmax = 0) {
+                                           int Cin, int len, int dil, int t0, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0,
+                                           float lscale = 0.f) {
     SlabMap<TL> m;
-    make_map<TL>(m, len, dil, t0, fT, fstride);
-    slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT, cmax);
+    make_map<TL, LERP>(m, len, dil, t0, fT, fstride, 0, lin, lscale);
+    slab_load<TL, TAPS, LERP>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT, cmax, lin);
 }
 
 // acc += W (.) x over all slabs of one input tensor.  Slab 0 is already in flight in `r` (first_load); `next()`
 // is called in its place behind the last slab, so the following phase or tile starts without a cold load.
-template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, class Next>
+template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, bool LERP = false, class Next>
 __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
                                             const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next,
-                                            const float* Ks = nullptr, int fT = 0, unsigned fstride = 0, int cmax = 0) {
+                                            const float* Ks = nullptr, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0, float lscale = 0.f) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NWV, wn = wave - wm * NWV;
     SlabMap<TL> m;
-    make_map<TL>(m, len, dil, t0, fT, fstride, Cin);
+    make_map<TL, LERP>(m, len, dil, t0, fT, fstride, Cin, lin, lscale);
     constexpr int STEPS = TAPS * TL::KG;               // K16 steps per slab: (channel group, tap)
     constexpr int PIECES = STEPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
     auto lstore = [&](int sl) __attribute__((always_inline)) {
@@ -252,6 +280,10 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
 #pragma unroll
         for (int i = 0; i < X_PER; ++i)
             if (m.xdst[i] >= 0 && !(S_ABL & 8)) {
+                if (LERP) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r.xr[i][j] = fmaf(m.w0[i], r.xr[i][j], __fmul_rn(m.w1[i], r.xr2[i][j]));   // = lerp_eval
+                }
                 if (LRELU) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) r.xr[i][j] = fmaxf(r.xr[i][j], 0.1f * r.xr[i][j]);   // = leaky_relu(x, 0.1)
@@ -276,7 +308,7 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     for (int s = 0; s < nslab; ++s) {
         slab_barrier();                            // every wave is done reading the previous slab
         lstore(s);                                 // slab s: registers -> LDS
-        if (s + 1 < nslab) slab_load<TL, TAPS>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax);   // flies across this slab's MFMAs
+        if (s + 1 < nslab) slab_load<TL, TAPS, LERP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin);   // flies across this slab's MFMAs
         else next();
         slab_barrier();
         // fragments of tap t+1 are read while the MFMAs of tap t run
@@ -416,7 +448,7 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
 // residual arrives as 16-byte loads) along time.  v already holds everything but the residual.
 template <class TL, bool RES>
 __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][TL::WN], float* __restrict__ y, const float* __restrict__ res,
-                                           int b, int M, int len, int mt0, int t0, float* __restrict__ y2 = nullptr, int f2 = 0) {
+                                           int b, int M, int len, int mt0, int t0, float* __restrict__ y2 = nullptr, int f2 = 0, int rlin = 0, float rscale = 0.f) {
     constexpr int WM = TL::WM, WN = TL::WN, BM = TL::BM, BN = TL::BN, OS = TL::OS, NTHR = TL::NTHR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -431,7 +463,8 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
                 Ot[((wm * WM + i) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)) * OS + (wn * WN + j) * 32 + l31] = v[i][j][r];
     slab_barrier();
     float* yb = y + ((long)b * M + mt0 * 32) * len + t0;      // offsets inside the tile's rows fit 32 bits
-    const float* rb = RES ? res + ((long)b * M + mt0 * 32) * len + t0 : nullptr;
+    // rlin > 0: the residual is F.interpolate(res_low) of a [B][M][rlin] tensor, evaluated here instead of read back
+    const float* rb = RES ? (rlin > 0 ? res + ((long)b * M + mt0 * 32) * rlin : res + ((long)b * M + mt0 * 32) * len + t0) : nullptr;
     const int rows = M - mt0 * 32 < BM ? M - mt0 * 32 : BM;
     const bool vec = (len & 3) == 0;                        // rows start 16-byte aligned (t0 is a multiple of 32)
     // optional 1/f2-rate copy for the next Downsample block (see C3EpiBias): pick for f2 = 3 / 5, two-sample mean for f2 = 4
@@ -443,7 +476,23 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
         if (row >= rows || t0 + c >= len) continue;
         const float4 o = *reinterpret_cast<const float4*>(Ot + row * OS + c);
         const int off = row * len + c;
-        if (vec && t0 + c + 3 < len) {
+        if (RES && rlin > 0) {
+            const float e[4] = {o.x, o.y, o.z, o.w};
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + c + u < len ? t0 + c + u : len - 1;
+                const Lerp lc = lerp_coord(t, rscale, rlin);
+                w[u] = e[u] + lerp_eval(lc, rb[row * rlin + lc.i0], rb[row * rlin + lc.i1]);
+            }
+            if (vec && t0 + c + 3 < len) {
+                *reinterpret_cast<float4*>(yb + off) = make_float4(w[0], w[1], w[2], w[3]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (t0 + c + u < len) yb[off + u] = w[u];
+            }
+        } else if (vec && t0 + c + 3 < len) {
             float4 w = o;
             if (RES) {
                 const float4 q = *reinterpret_cast<const float4*>(rb + off);
@@ -478,7 +527,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     }
 }
 
-template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false>
+template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false>
 __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ? S_WPE_F : (TL::NW <= 8 ? S_WPE_G : S_WPE)))) void conv3s_kernel(ConvSArgs a, Epi ep) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, A_U4 = TL::a_u4(TAPS);
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s[];
@@ -528,14 +577,15 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     coords(tile, mt0, b, t0);
     const int fT = a.flatT;
     const unsigned fstride = (unsigned)a.xstride;
-    first_load<TL, TAPS>(regs, a.A6, a.MT, mt0, fT ? a.x : a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0, fT, fstride, a.cmax);
+    first_load<TL, TAPS, LERP>(regs, a.A6, a.MT, mt0, fT ? a.x : a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0, fT, fstride, a.cmax, a.lin, a.lscale);
     while (tile < vtiles) {
         const int nxt = next_valid(tile + stride);
         auto load_next_tile = [&]() __attribute__((always_inline)) {
             if (nxt < vtiles) {
                 int mt0n, bn, t0n;
                 coords(nxt, mt0n, bn, t0n);
-                first_load<TL, TAPS>(regs, a.A6, a.MT, mt0n, fT ? a.x : a.x + (long)bn * a.xstride, a.Cin, len, a.dil, t0n, fT, fstride, a.cmax);
+                first_load<TL, TAPS, LERP>(regs, a.A6, a.MT, mt0n, fT ? a.x : a.x + (long)bn * a.xstride, a.Cin, len, a.dil, t0n, fT, fstride, a.cmax, a.lin,
+                                           a.lscale);
             }
         };
         const float* xb = fT ? a.x : a.x + (long)b * a.xstride;
@@ -574,8 +624,9 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             // the cond tile on the same output tiles; (conv, scale, shift) combine in registers.
             const float* cb = a.cond + (long)b * a.Ccond * len;
             const int mtoff = a.MT;                                   // the stacked FiLM image has 2 * a.MT m-tiles: scale rows, then shift rows
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
-                                               [&]() __attribute__((always_inline)) { film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, len, t0); });
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB, false, LERP>(
+                acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+                [&]() __attribute__((always_inline)) { film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, len, t0); }, nullptr, 0, 0u, 0, a.lin, a.lscale);
             f32x16 asc[WM][WN], ash[WM][WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
@@ -595,10 +646,10 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                     for (int j = 0; j < WN; ++j)
                         acc[i][j][r] = __fadd_rn(__fmul_rn(acc[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
                 }
-            tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0);
+            tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
         } else {
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (TL::NW <= 8 ? S_FB_G : S_FB), SCALED>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile, Ks, fT,
-                                                                             fstride, a.cmax);
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (TL::NW <= 8 ? S_FB_G : S_FB), SCALED, LERP>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+                                                                                                   load_next_tile, Ks, fT, fstride, a.cmax, a.lin, a.lscale);
             if constexpr (Epi::kIgemm) {
                 // plain GEMM use (B = 1, len = all columns): the igemm epilogue functors finish the element
                 const int l31 = lane & 31, wn = wave - wm * TL::NWV;
@@ -635,17 +686,17 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     }
 }
 
-template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false>
+template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false>
 inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
                            const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond, long xstride = 0, int bpc = S_BPC,
-                           const float* kscale = nullptr, bool flat = false, int cmax = 0) {
+                           const float* kscale = nullptr, bool flat = false, int cmax = 0, int lin = 0, float lscale = 0.f) {
     if (Cin % (16 * TL::KG) != 0 || (FILM && Ccond % 16 != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of the slab depth");
     if (Cin / 16 > w.S6) return fail(ctx, TVC_ERR_ARG, "conv3s: weight image has fewer K16 steps than the launch walks");
     static bool ready_dev[64] = {};                 // the attribute is per (function, device): one flag per device of this process
     bool& ready = ready_dev[ctx->device & 63];
     constexpr int lds = TL::lds_bytes(TAPS);
     if (!ready) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED, LERP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv3s setup: %s", hipGetErrorString(e));
         ready = true;
@@ -656,8 +707,11 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     if (SCALED && (!kscale || Cin > 768)) return fail(ctx, TVC_ERR_ARG, "conv3s: scaled launch needs factors for <= 768 channels");
     a.kscale = kscale;
     a.cmax = cmax;
+    a.lin = lin;
+    a.lscale = lscale;
+    if (LERP && (lin <= 0 || flat)) return fail(ctx, TVC_ERR_ARG, "conv3s: interpolated input needs its low-rate length");
     a.x = x;
-    a.xstride = xstride ? xstride : (long)Cin * len;
+    a.xstride = xstride ? xstride : (long)Cin * (LERP ? lin : len);
     a.Cin = Cin;
     a.len = len;
     a.dil = dil;
@@ -687,7 +741,7 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     const int mblocks = a.MT / TL::MTB;
     const int vtiles = S_XCD_MAP ? (a.ntiles / mblocks + 7) / 8 * 8 * mblocks : a.ntiles;
     dim3 g((unsigned)(vtiles < slots ? vtiles : slots));
-    hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED>), g, dim3(TL::NTHR), lds, s, a, ep);
+    hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED, LERP>), g, dim3(TL::NTHR), lds, s, a, ep);
     return 0;
 }
 
@@ -717,23 +771,24 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
 #endif
 
 // k3 conv on the split path; Mpad = 64 (48 channels) or a multiple of 96 (FilterNet levels with C = 96, 192, 384)
-template <bool LRELU, class Epi, bool FILM = false>
+template <bool LRELU, class Epi, bool FILM = false, bool LERP = false>
 inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
-                         const PackedW* wsc = nullptr, const PackedW* wsh = nullptr, const float* cond = nullptr, int Ccond = 0) {
+                         const PackedW* wsc = nullptr, const PackedW* wsh = nullptr, const float* cond = nullptr, int Ccond = 0, int lin = 0,
+                         float lscale = 0.f) {
     if (w.MT6 == 2) {   // 48 output channels: two m-tiles, the second half empty (still 1.4x fewer MFMA cycles than exact fp32 tiles)
         if constexpr (FILM)
-            return conv3s_launch_t<SplitTile<2, 1, TVC_S48F_NWV, 1>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond);
+            return conv3s_launch_t<SplitTile<2, 1, TVC_S48F_NWV, 1>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC,
+                                                                                                      nullptr, false, 0, lin, lscale);
         else
-            return conv3s_launch_t<SplitTile<2, 1, TVC_S48_NWV, 1>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond);
+            return conv3s_launch_t<SplitTile<2, 1, TVC_S48_NWV, 1>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC,
+                                                                                                     nullptr, false, 0, lin, lscale);
     }
     if constexpr (FILM)
-        return conv3s_launch_t<SplitTile<3, TVC_SF_WM, TVC_SF_NWV, TVC_SF_WN>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond);
-    else if (TVC_S_CKG == 2 && Cin % 32 == 0)   // two 16-channel groups per slab: 36 MFMAs per wave between barriers instead of 18
-        return conv3s_launch_t<SplitTile<3, TVC_S_WM, TVC_S_NWV, TVC_S_WN, 2>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond);
-    else if (TVC_S_MTB2 && w.MT6 % 2 == 0)   // 192 / 384 rows: 8-wave workgroups of two m-tiles, two per CU
-        return conv3s_launch_t<SplitTile<2, 1, 4, 1>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, 2);
+        return conv3s_launch_t<SplitTile<3, TVC_SF_WM, TVC_SF_NWV, TVC_SF_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0,
+                                                                                                                S_BPC, nullptr, false, 0, lin, lscale);
     else
-        return conv3s_launch_t<SplitTile<3, TVC_S_WM, TVC_S_NWV, TVC_S_WN>, 3, LRELU, Epi, FILM>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond);
+        return conv3s_launch_t<SplitTile<3, TVC_S_WM, TVC_S_NWV, TVC_S_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC,
+                                                                                                             nullptr, false, 0, lin, lscale);
 }
 
 // Plain GEMM on the split path: out(m, n) = sum_k W[m][k] x[b][k][t], n = b * len + t, finished by an igemm epilogue

@@ -9,6 +9,9 @@
 
 namespace tvc {
 
+#ifndef TVC_FUSE_LERP
+#define TVC_FUSE_LERP 1     // Upsample's interpolate evaluated inside c1's staging and c2's residual epilogue (split-path levels)
+#endif
 #ifndef TVC_FUSE_DECIM
 #define TVC_FUSE_DECIM 1    // Downsample's interpolate(1/f) written by the producing conv's epilogue (pick / two-sample mean)
 #endif
@@ -406,10 +409,14 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         } else if (!dry) {
             static const char* names[5] = {"filter.up0", "filter.up1", "filter.up2", "filter.up3", "filter.up4"};
             ProfScope ps(ctx, s, dry, names[i]);
-            // F.interpolate(scale_factor=f): ATen uses scale = float(1/f)
-            {
+            // F.interpolate(scale_factor=f): ATen uses scale = float(1/f).  On the split path the interpolated tensor is never
+            // written: c1 interpolates while it stages its input and c2's epilogue interpolates the residual (x_up).
+            const float lscale = (float)(1.0 / (double)u.factor);
+            const bool split_level = (C == 48 && TVC_SPLIT48) || (TVC_SPLIT && C % 96 == 0);
+            const bool lerp_fused = TVC_FUSE_LERP && split_level;
+            if (!lerp_fused) {
                 const LerpLaunch ll = lerp_launch((long)B * C, lo);
-                hipLaunchKernelGGL(lerp_resize_kernel, ll.grid, dim3(256), 0, s, x, xu, (long)B * C, lin, lo, (float)(1.0 / (double)u.factor), ll.tx);
+                hipLaunchKernelGGL(lerp_resize_kernel, ll.grid, dim3(256), 0, s, x, xu, (long)B * C, lin, lo, lscale, ll.tx);
             }
             for (int half = 0; half < 2; ++half) {
                 const PackedW& ca = half ? u.c3 : u.c1;
@@ -419,12 +426,20 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 float* xout = half ? xu : x1;  // 2nd half writes over xu (its input and residual are x1)
                 const PackedW& wsc = half ? u.sc2 : u.sc1;
                 const PackedW& wsh = half ? u.sh2 : u.sh1;
-                if (C == 48 && TVC_SPLIT48) {
-                    TVC_CHECK(conv3s_launch<true>(ctx, s, ca, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo}));
-                    const PackedW& fw48 = half ? u.film2 : u.film1;    // stacked, each group padded to whole 32-row tiles
-                    TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
-                                                                          C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
-                                                                          &fw48, &fw48, cond, C)));
+                if (split_level) {
+                    const PackedW& fw = half ? u.film2 : u.film1;      // stacked [to_scale ; to_shift] rows, each group padded to whole 32-row tiles
+                    if (half == 0 && lerp_fused) {
+                        TVC_CHECK((conv3s_launch<true, C3EpiBias<false>, false, true>(ctx, s, ca, x, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo},
+                                                                                      nullptr, nullptr, nullptr, 0, lin, lscale)));
+                        TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
+                                                                              C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, x, C, lo, lin, lscale},
+                                                                              &fw, &fw, cond, C)));
+                    } else {
+                        TVC_CHECK(conv3s_launch<true>(ctx, s, ca, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo}));
+                        TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
+                                                                              C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
+                                                                              &fw, &fw, cond, C)));
+                    }
                     continue;
                 }
                 if (C == 48 && TVC_USE_C48) {
@@ -433,14 +448,6 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                     conv3m48_launch<true, C3EpiFilmFused, true>(s, cb, h, B, C, lo, db,
                                                                 C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
                                                                 FilmOps{wsc.At, wsh.At, cond, C});
-                    continue;
-                }
-                if (TVC_SPLIT && C % 96 == 0) {
-                    TVC_CHECK(conv3s_launch<true>(ctx, s, ca, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo}));
-                    const PackedW& fw = half ? u.film2 : u.film1;      // stacked [to_scale ; to_shift] rows
-                    TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
-                                                                          C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, xin, C, lo},
-                                                                          &fw, &fw, cond, C)));
                     continue;
                 }
                 conv3_launch<true>(s, ca.At, ca.Mpad, xin, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo});
