@@ -153,7 +153,6 @@ struct SlabMap {
     int xdst[TL::X_PER];       // LDS row of the item, -1 = idle
     int xg8[TL::X_PER];        // first channel of the item inside the slab (0 or 8)
     int xk[TL::X_PER];         // flat GEMM tiles: factor-row offset of the item's utterance inside the staged Ks
-    unsigned xp[TL::X_PER];    // xo without its channel term (row-clamped launches rebuild the channel term per load)
     unsigned xo1[TL::X_PER];   // LERP staging: offset of the second tap; w0 / w1 = the two weights (xo = first tap)
     float w0[TL::X_PER], w1[TL::X_PER];
 };
@@ -176,28 +175,25 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
         m.xg8[i] = ks * 16 + 8 * g;
         if (fT > 0) {
             const int b = p / fT, t = p - b * fT;
-            m.xp[i] = (unsigned)b * fstride + (unsigned)t;
-            m.xo[i] = m.xp[i] + (unsigned)(m.xg8[i] * fT);
+            m.xo[i] = (unsigned)b * fstride + (unsigned)(m.xg8[i] * fT + t);
             m.xk[i] = (b - t0 / fT) * kcin;
         } else if (LERP) {
             // the conv input at position p (already clamped = replicate padding of the interpolated signal) is
             // w0 * x[i0] + w1 * x[i1] of the low-rate row (ATen linear, align_corners = False: small_kernels.h)
             const Lerp lc = lerp_coord(p, lscale, lin);
-            m.xp[i] = (unsigned)lc.i0;
             m.xo[i] = (unsigned)(m.xg8[i] * lin + lc.i0);
             m.xo1[i] = (unsigned)(m.xg8[i] * lin + lc.i1);
             m.w0[i] = lc.w0;
             m.w1[i] = lc.w1;
             m.xk[i] = 0;
         } else {
-            m.xp[i] = (unsigned)p;
             m.xo[i] = (unsigned)(m.xg8[i] * len + p);
             m.xk[i] = 0;
         }
     }
 }
 // global -> registers only (no use of the values here: the loads stay in flight behind the MFMAs)
-template <class TL, int TAPS, bool LERP = false>
+template <class TL, int TAPS, bool LERP = false, bool CLAMP = false>
 __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ A6, int MT, int mt0,
                                           const float* __restrict__ xb, int Cin, int len, int s, int fT = 0, int cmax = 0, int lin = 0) {
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER, STEPS = TAPS * TL::KG;
@@ -229,14 +225,14 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
             }
         return;
     }
-    if (cmax > 0 && ci0 + 16 * TL::KG > cmax + 1) {      // the slab reaches past the last real input row: clamp (zero weights there)
+    if constexpr (CLAMP) {   // input rows above cmax do not exist (their weights are zero): read row cmax instead; one code path, no branch
 #pragma unroll
         for (int i = 0; i < X_PER; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 int cj = ci0 + m.xg8[i] + j;
                 cj = cj < cmax ? cj : cmax;
-                r.xr[i][j] = xb[m.xp[i] + (unsigned)(cj * cs)];
+                r.xr[i][j] = xb[m.xo[i] + (unsigned)((cj - m.xg8[i]) * cs)];     // xo already carries the xg8 * cs channel term
             }
         return;
     }
@@ -246,18 +242,18 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
         for (int j = 0; j < 8; ++j) r.xr[i][j] = xc[m.xo[i] + (unsigned)(j * cs)];
 }
 // slab 0 of a phase, issued by whoever runs before it (previous phase / previous tile / kernel entry)
-template <class TL, int TAPS, bool LERP = false>
+template <class TL, int TAPS, bool LERP = false, bool CLAMP = false>
 __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0, const float* __restrict__ xb,
                                            int Cin, int len, int dil, int t0, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0,
                                            float lscale = 0.f) {
     SlabMap<TL> m;
     make_map<TL, LERP>(m, len, dil, t0, fT, fstride, 0, lin, lscale);
-    slab_load<TL, TAPS, LERP>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT, cmax, lin);
+    slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT, cmax, lin);
 }
 
 // acc += W (.) x over all slabs of one input tensor.  Slab 0 is already in flight in `r` (first_load); `next()`
 // is called in its place behind the last slab, so the following phase or tile starts without a cold load.
-template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, bool LERP = false, class Next>
+template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, bool LERP = false, bool CLAMP = false, class Next>
 __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
                                             const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next,
                                             const float* Ks = nullptr, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0, float lscale = 0.f) {
@@ -308,7 +304,7 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     for (int s = 0; s < nslab; ++s) {
         slab_barrier();                            // every wave is done reading the previous slab
         lstore(s);                                 // slab s: registers -> LDS
-        if (s + 1 < nslab) slab_load<TL, TAPS, LERP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin);   // flies across this slab's MFMAs
+        if (s + 1 < nslab) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin);   // flies across this slab's MFMAs
         else next();
         slab_barrier();
         // fragments of tap t+1 are read while the MFMAs of tap t run
@@ -527,7 +523,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     }
 }
 
-template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false>
+template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false, bool CLAMP = false>
 __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ? S_WPE_F : (TL::NW <= 8 ? S_WPE_G : S_WPE)))) void conv3s_kernel(ConvSArgs a, Epi ep) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, A_U4 = TL::a_u4(TAPS);
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s[];
@@ -577,14 +573,14 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     coords(tile, mt0, b, t0);
     const int fT = a.flatT;
     const unsigned fstride = (unsigned)a.xstride;
-    first_load<TL, TAPS, LERP>(regs, a.A6, a.MT, mt0, fT ? a.x : a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0, fT, fstride, a.cmax, a.lin, a.lscale);
+    first_load<TL, TAPS, LERP, CLAMP>(regs, a.A6, a.MT, mt0, fT ? a.x : a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0, fT, fstride, a.cmax, a.lin, a.lscale);
     while (tile < vtiles) {
         const int nxt = next_valid(tile + stride);
         auto load_next_tile = [&]() __attribute__((always_inline)) {
             if (nxt < vtiles) {
                 int mt0n, bn, t0n;
                 coords(nxt, mt0n, bn, t0n);
-                first_load<TL, TAPS, LERP>(regs, a.A6, a.MT, mt0n, fT ? a.x : a.x + (long)bn * a.xstride, a.Cin, len, a.dil, t0n, fT, fstride, a.cmax, a.lin,
+                first_load<TL, TAPS, LERP, CLAMP>(regs, a.A6, a.MT, mt0n, fT ? a.x : a.x + (long)bn * a.xstride, a.Cin, len, a.dil, t0n, fT, fstride, a.cmax, a.lin,
                                            a.lscale);
             }
         };
@@ -648,7 +644,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 }
             tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
         } else {
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (TL::NW <= 8 ? S_FB_G : S_FB), SCALED, LERP>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (TL::NW <= 8 ? S_FB_G : S_FB), SCALED, LERP, CLAMP>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                                                                                                    load_next_tile, Ks, fT, fstride, a.cmax, a.lin, a.lscale);
             if constexpr (Epi::kIgemm) {
                 // plain GEMM use (B = 1, len = all columns): the igemm epilogue functors finish the element
@@ -686,7 +682,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     }
 }
 
-template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false>
+template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false, bool CLAMP = false>
 inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
                            const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond, long xstride = 0, int bpc = S_BPC,
                            const float* kscale = nullptr, bool flat = false, int cmax = 0, int lin = 0, float lscale = 0.f) {
@@ -696,7 +692,7 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     bool& ready = ready_dev[ctx->device & 63];
     constexpr int lds = TL::lds_bytes(TAPS);
     if (!ready) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED, LERP>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED, LERP, CLAMP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv3s setup: %s", hipGetErrorString(e));
         ready = true;
@@ -707,6 +703,7 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     if (SCALED && (!kscale || Cin > 768)) return fail(ctx, TVC_ERR_ARG, "conv3s: scaled launch needs factors for <= 768 channels");
     a.kscale = kscale;
     a.cmax = cmax;
+    if (CLAMP != (cmax > 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: row clamp is a compile-time property of the launch");
     a.lin = lin;
     a.lscale = lscale;
     if (LERP && (lin <= 0 || flat)) return fail(ctx, TVC_ERR_ARG, "conv3s: interpolated input needs its low-rate length");
@@ -741,7 +738,7 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     const int mblocks = a.MT / TL::MTB;
     const int vtiles = S_XCD_MAP ? (a.ntiles / mblocks + 7) / 8 * 8 * mblocks : a.ntiles;
     dim3 g((unsigned)(vtiles < slots ? vtiles : slots));
-    hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED, LERP>), g, dim3(TL::NTHR), lds, s, a, ep);
+    hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED, LERP, CLAMP>), g, dim3(TL::NTHR), lds, s, a, ep);
     return 0;
 }
 
@@ -793,7 +790,7 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
 
 // Plain GEMM on the split path: out(m, n) = sum_k W[m][k] x[b][k][t], n = b * len + t, finished by an igemm epilogue
 // functor (store(n, m, v[4])).  Cin must be a multiple of 16 and rows [K, Cin) must be readable (weights there are 0).
-template <int MTB, int NWV, int BPC, int KG, class Epi, bool SCALED>
+template <int MTB, int NWV, int BPC, int KG, class Epi, bool SCALED, bool CLAMP>
 inline int gemm_s_launch_k(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
                            const float* kscale, int cmax) {
     using TL = SplitTile<MTB, 1, NWV, 1, KG, 0>;
@@ -801,20 +798,25 @@ inline int gemm_s_launch_k(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     // or the element offsets would not fit 32 bits
     const long xs = xstride ? xstride : (long)Cin * len;
     const bool flat = TVC_S_FLAT && B > 1 && xs * B < (1L << 31) && (!SCALED || len >= TL::BN);
-    return conv3s_launch_t<TL, 1, false, Epi, false, SCALED>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride, BPC, kscale, flat, cmax);
+    return conv3s_launch_t<TL, 1, false, Epi, false, SCALED, false, CLAMP>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride, BPC, kscale, flat,
+                                                                           cmax);
 }
 template <int MTB, int NWV, int BPC, class Epi, bool SCALED = false>
 inline int gemm_s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
-                         const float* kscale = nullptr, int krows = 0) {
+                         const float* kscale = nullptr) {
     if (w.MT6 % MTB != 0) return fail(ctx, TVC_ERR_ARG, "gemm_s: row tiles do not divide");
-    // krows > 0: the input has only krows channel rows per utterance; Cin is rounded up to whole slabs and the loads of the
-    // missing rows are clamped to the last real one (their weights are zero)
-    const int cmax = krows > 0 ? krows - 1 : 0;
-    if (krows > 0) Cin = (krows + 31) / 32 * 32;
     // deepest slab the channel count allows: 48, 32 or 16 input channels per load -> LDS -> barrier round trip
-    if (TVC_S_KG >= 3 && Cin % 48 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 3, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, cmax);
-    if (TVC_S_KG >= 2 && Cin % 32 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 2, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, cmax);
-    return gemm_s_launch_k<MTB, NWV, BPC, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, cmax);
+    if (TVC_S_KG >= 3 && Cin % 48 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 3, Epi, SCALED, false>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, 0);
+    if (TVC_S_KG >= 2 && Cin % 32 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 2, Epi, SCALED, false>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, 0);
+    return gemm_s_launch_k<MTB, NWV, BPC, 1, Epi, SCALED, false>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, 0);
+}
+// The input has only `krows` channel rows per utterance (not a multiple of the slab depth): K is rounded up to whole 32-channel
+// slabs and the loads of the missing rows are clamped to the last real one (their weights are zero).  Its own instantiation:
+// a second load path inside the shared kernels cost them 4 % (waitcnt placement), measured.
+template <int MTB, int NWV, int BPC, class Epi>
+inline int gemm_s_launch_ragged(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int krows, int len, long xstride, const Epi& ep) {
+    if (w.MT6 % MTB != 0) return fail(ctx, TVC_ERR_ARG, "gemm_s: row tiles do not divide");
+    return gemm_s_launch_k<MTB, NWV, BPC, 2, Epi, false, true>(ctx, s, w, x, B, (krows + 31) / 32 * 32, len, xstride, ep, nullptr, krows - 1);
 }
 
 }  // namespace tvc

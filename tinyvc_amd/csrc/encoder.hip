@@ -261,7 +261,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
         EpiSplit ep{xs, xp, ctx->enc_in.bias, kSslCh, kPitchCh, T, ncols};
         if (TVC_SPLIT_ENC && TVC_SPLIT_ENC_IN && ctx->enc_in.MT6 % ENC_MTB == 0) {
             // 961 input rows: the last slab is clamped to row 960 (zero weights beyond)
-            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->enc_in, spec, B, kBins, T, (long)kBins * T, ep, nullptr, kBins)));
+            TVC_CHECK((gemm_s_launch_ragged<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->enc_in, spec, B, kBins, T, (long)kBins * T, ep)));
         } else {
             LoadPlain ld{spec, kBins, T, (long)kBins * T};
             igemm_launch(s, ctx->enc_in.At, ctx->enc_in.Mpad, ctx->enc_in.Kpad, ncols, T, ld, ep);
