@@ -150,6 +150,103 @@ struct Packer {
         pw->S6 = nslab;
         fix.push_back({&pw->A6, ab.put(img)});
     }
+    // Weight blob of one half of the split-precision fused ups.4 kernel (filter_up24s.hip): 42 pieces of 1 KiB in
+    // v_mfma_f32_32x32x16_bf16 A-lane order (row m = lane & 31, k = 8 * (lane >> 5) + j), bf16 x 3 parts each:
+    //   [conv a: 5 steps][3 parts] [conv b: 5 steps][3 parts] [FiLM: 2 steps][to_scale, to_shift][3 parts]
+    // followed by 304 floats: biases a, b, scale, shift (32 each), the folded output taps [24][7] and their bias.
+    // K runs in units of (tap, 8-channel group): unit u = 2 * step + (lane >> 5), tap = u / 3, group = u % 3 (a 24-channel
+    // conv has 9 units, the 10th is zero; FiLM's 1x1 has 3).
+    // Second half: Upsample.c5 (1x1, decoder.py:171,189) and FilterNet.output_layer (k7, decoder.py:220,233) have nothing
+    // between them, so they are one k7 conv 24 -> 1: w75[c][j] = sum_m w7[m][j] w5[m][c], b75 = b7 + sum_{m,j} w7[m][j] b5[m]
+    // (replicate padding commutes with the 1x1), accumulated in double.
+    void up24s_half(const float** slot, const std::string& ca, const std::string& cb, const std::string& film, const std::string& c5,
+                    const std::string& out7) {
+        const HostTensor* wa = find(ca + ".weight");
+        const HostTensor* ba = find(ca + ".bias");
+        const HostTensor* wb = find(cb + ".weight");
+        const HostTensor* bb = find(cb + ".bias");
+        const HostTensor* wsc = find(film + ".to_scale.weight");
+        const HostTensor* bsc = find(film + ".to_scale.bias");
+        const HostTensor* wsh = find(film + ".to_shift.weight");
+        const HostTensor* bsh = find(film + ".to_shift.bias");
+        if (!wa || !ba || !wb || !bb || !wsc || !bsc || !wsh || !bsh) return;
+        const int C = 24;
+        if (wa->data.size() != (size_t)C * C * 3 || wb->data.size() != (size_t)C * C * 3 || wsc->data.size() != (size_t)C * C ||
+            wsh->data.size() != (size_t)C * C) {
+            if (missing.empty()) missing = ca + " (unexpected shape for the 24-channel block)";
+            return;
+        }
+        std::vector<float> img(42 * 256 + 304, 0.f);
+        uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
+        auto to_bf16 = [](float f) -> uint16_t {
+            uint32_t u;
+            std::memcpy(&u, &f, 4);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        auto from_bf16 = [](uint16_t h) -> float {
+            uint32_t u = (uint32_t)h << 16;
+            float f;
+            std::memcpy(&f, &u, 4);
+            return f;
+        };
+        auto put3 = [&](int piece0, int lane, int j, float w) {   // parts of one value into pieces piece0, +1, +2
+            uint16_t h1 = to_bf16(w);
+            float r = w - from_bf16(h1);
+            uint16_t h2 = to_bf16(r);
+            float r2 = r - from_bf16(h2);
+            uint16_t h3 = to_bf16(r2);
+            size_t base = ((size_t)piece0 * 64 + lane) * 8 + j;
+            o[base] = h1;
+            o[base + 512] = h2;
+            o[base + 1024] = h3;
+        };
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int m = lane & 31, lh = lane >> 5;
+                for (int s = 0; s < 5; ++s) {
+                    const int u = 2 * s + lh, tap = u / 3, ci = 8 * (u % 3) + j;
+                    const bool real = u < 9 && m < C;
+                    put3(s * 3, lane, j, real ? wa->data[((size_t)m * C + ci) * 3 + tap] : 0.f);
+                    put3(15 + s * 3, lane, j, real ? wb->data[((size_t)m * C + ci) * 3 + tap] : 0.f);
+                }
+                for (int s = 0; s < 2; ++s) {
+                    const int u = 2 * s + lh, ci = 8 * u + j;
+                    const bool real = u < 3 && m < C;
+                    put3(30 + (s * 2 + 0) * 3, lane, j, real ? wsc->data[(size_t)m * C + ci] : 0.f);
+                    put3(30 + (s * 2 + 1) * 3, lane, j, real ? wsh->data[(size_t)m * C + ci] : 0.f);
+                }
+            }
+        float* fl = img.data() + 42 * 256;
+        for (int m = 0; m < C; ++m) {
+            fl[m] = ba->data[m];
+            fl[32 + m] = bb->data[m];
+            fl[64 + m] = bsc->data[m];
+            fl[96 + m] = bsh->data[m];
+        }
+        if (!c5.empty()) {
+            const HostTensor* w5 = find(c5 + ".weight");
+            const HostTensor* b5 = find(c5 + ".bias");
+            const HostTensor* w7 = find(out7 + ".weight");
+            const HostTensor* b7 = find(out7 + ".bias");
+            if (!w5 || !b5 || !w7 || !b7) return;
+            if (w5->data.size() != (size_t)C * C || w7->data.size() != (size_t)C * 7 || b7->data.size() != 1) {
+                if (missing.empty()) missing = c5 + " (unexpected shape for the folded output conv)";
+                return;
+            }
+            double bias = b7->data[0];
+            for (int c = 0; c < C; ++c)
+                for (int j = 0; j < 7; ++j) {
+                    double acc = 0.0;
+                    for (int m = 0; m < C; ++m) acc += (double)w7->data[(size_t)m * 7 + j] * (double)w5->data[(size_t)m * C + c];
+                    fl[128 + c * 7 + j] = (float)acc;
+                }
+            for (int m = 0; m < C; ++m)
+                for (int j = 0; j < 7; ++j) bias += (double)w7->data[(size_t)m * 7 + j] * (double)b5->data[m];
+            fl[128 + 168] = (float)bias;
+        }
+        fix.push_back({slot, ab.put(img)});
+    }
     void convnext(const std::string& p, ConvNeXtW* w, int C, int dil) {
         w->C = C;
         w->dilation = dil;
@@ -386,6 +483,10 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
         pk.conv({p + ".film1.to_shift"}, &u.sh1, u.cin, 1);
         pk.conv({p + ".film2.to_scale"}, &u.sc2, u.cin, 1);
         pk.conv({p + ".film2.to_shift"}, &u.sh2, u.cin, 1);
+        if (u.cin == 24) {
+            pk.up24s_half(&u.s24a, p + ".c1", p + ".c2", p + ".film1", "", "");
+            pk.up24s_half(&u.s24b, p + ".c3", p + ".c4", p + ".film2", p + ".c5", "filter_net.output_layer");
+        }
     }
     pk.conv({"filter_net.output_layer"}, &ctx->flt_out, ch[4], 7);
     pk.raw("filter_net.output_layer.weight", &ctx->flt_out_w, (size_t)ch[4] * 7);

@@ -282,6 +282,9 @@ static void conv_launch(hipStream_t s, const PackedW& w, const float* x, int cin
 #ifndef TVC_SPLIT
 #define TVC_SPLIT 1
 #endif
+#ifndef TVC_UP24_SPLIT
+#define TVC_UP24_SPLIT 1   // fused ups.4 + output layer on the split-precision bf16 MFMA path (filter_up24s.hip); 0 = fp32 16x16x4 tiles (filter_up24.hip)
+#endif
 #ifndef TVC_SPLIT48
 #define TVC_SPLIT48 1   // 48-channel levels on the split path too (rows padded 48 -> 64; with the stacked FiLM phase ups.3 1.49 -> 1.25 ms)
 #endif
@@ -404,7 +407,8 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         if (!dry && C == 24) {
             // last level: Upsample block + output_layer in two launches, waveform written directly
             ProfScope ps(ctx, s, dry, "filter.up4+out");
-            TVC_CHECK(run_up24_fused(ctx, s, u, x, cond, x1, wave, B, lo, ctx->flt_out_w, ctx->flt_out_b));
+            if (TVC_UP24_SPLIT) TVC_CHECK(run_up24_split(ctx, s, u, x, cond, x1, wave, B, lo));
+            else TVC_CHECK(run_up24_fused(ctx, s, u, x, cond, x1, wave, B, lo, ctx->flt_out_w, ctx->flt_out_b));
             fused_out = true;
         } else if (!dry) {
             static const char* names[5] = {"filter.up0", "filter.up1", "filter.up2", "filter.up3", "filter.up4"};

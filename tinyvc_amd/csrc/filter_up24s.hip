@@ -1,0 +1,415 @@
+// Split-precision version of the fused 24-channel full-rate block (FilterNet ups[4] + output_layer,
+// decoder.py:173-190,220,233): same fusion as filter_up24.hip, but every conv / FiLM 1x1 runs on
+// v_mfma_f32_32x32x16_bf16 with both operands split into three bf16 parts (six part-products, fp32-equivalent
+// accuracy: conv3s.h), 2.3x fewer matrix-pipe cycles than the fp32 16x16x4 tiles.
+//
+//   half A:  x_up = interp(x, x5) -> lrelu -> c1(d1) -> lrelu -> c2(d3) -> FiLM1(cond) -> + x_up          => x1
+//   half B:  x1 -> lrelu -> c3(d9) -> lrelu -> c4(d27) -> FiLM2(cond) -> + x1 -> [c5 . output k7 folded]   => wave
+//
+// One persistent 8-wave workgroup per CU walks tiles of W output samples.
+//   LDS     Xs[part][8-channel group][position][8 bf16]: lrelu(input tile), split while it is deposited;
+//           Hs, same layout: lrelu(first conv + bias), split by the first conv's epilogue;
+//           R[24][PS] fp32: the raw input tile (residual); half B overwrites it in place with x2 for the output conv;
+//           Wt: the block's weights, pre-split on the host into MFMA A-lane order (api.hip up24s_half), resident.
+//   K order a 24-channel k3 conv has 9 (tap, 8-channel group) units; a K16 step takes two of them, one per lane half
+//           (5 steps, the 10th unit has zero weights).  A tap is a row offset in Xs / Hs, so every B fragment is one
+//           ds_read_b128 of a contiguous 512-byte run per lane half.
+//   tiles   a wave owns 32 output columns x all 24 (padded 32) rows: 30 MFMAs per conv, 24 for FiLM's scale and shift
+//           (cond fragments are loaded from HBM straight into B-fragment order and split in registers).
+//   HBM     per tile: input tile + halo and cond in, one tile out; the next tile's input is in flight in registers
+//           across the whole tile (raw s_barrier: __syncthreads would wait for it).
+#include "conv3s.h"
+#include "small_kernels.h"
+#include "tvc_common.h"
+
+namespace tvc {
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+#ifndef U24S_WPE
+#define U24S_WPE 2     // 8 waves per CU: 256 registers each
+#endif
+
+template <int W_, int D1_, int D2_, bool SECOND_, int E_>
+struct U24S {
+    static constexpr int C = 24, W = W_, D1 = D1_, D2 = D2_, E = E_, H = D1_ + D2_;
+    static constexpr bool SECOND = SECOND_;
+    static constexpr int NWAVES = 8, NT = 512;
+    static constexpr int W2 = W + 2 * E;                       // columns the second conv must produce (position t0 - E + n)
+    static constexpr int NT2 = (W2 + 31) / 32, W2r = NT2 * 32;
+    static constexpr int NT1 = (W2 + 2 * D2 + 31) / 32;        // first-conv column tiles (position t0 - E - D2 + h)
+    static constexpr int HP = NT1 * 32;                        // Hs rows per (part, group)
+    static constexpr int XW = W2 + 2 * H;                      // input columns (position t0 - E - H + c)
+    static constexpr int XP = XW;
+    static constexpr int PS = W2r + 4;                         // fp32 residual tile row stride
+    static constexpr int ITEMS = 3 * XW, XPER = (ITEMS + NT - 1) / NT;
+    static constexpr int PIECES = 42, FL = 304;
+    static constexpr int LDS_BYTES = (9 * XP + 9 * HP + PIECES * 64) * 16 + (FL + C * PS) * 4;
+    static_assert(NT2 <= NWAVES, "one second-conv tile per wave");
+    static_assert(XW - H >= W2, "residual columns");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+struct Up24SArgs {
+    const float* x;      // half A: low-rate input [B][24][len/xf]; half B: x1 [B][24][len]
+    const float* cond;   // [B][24][len]
+    float* out;          // half A: x1 [B][24][len]; half B: waveform [B][len]
+    const u32x4* img;    // weight blob (api.hip up24s_half)
+    int len, xf, tiles_per_utt, ntiles;
+    float interp_scale;
+};
+
+// three bf16 parts of 4 fp32 values (8 bytes each)
+__device__ __forceinline__ void split4(const float (&v)[4], u32x2& p1, u32x2& p2, u32x2& p3) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f32x2 a = {v[2 * j], v[2 * j + 1]};
+        bf16x2 h1 = __builtin_convertvector(a, bf16x2);
+        f32x2 r = a - __builtin_convertvector(h1, f32x2);
+        bf16x2 h2 = __builtin_convertvector(r, bf16x2);
+        f32x2 r2 = r - __builtin_convertvector(h2, f32x2);
+        bf16x2 h3 = __builtin_convertvector(r2, bf16x2);
+        p1[j] = __builtin_bit_cast(unsigned, h1);
+        p2[j] = __builtin_bit_cast(unsigned, h2);
+        p3[j] = __builtin_bit_cast(unsigned, h3);
+    }
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// acc += W (.) src over the 9 (tap, group) units of a 24-channel k3 conv for this wave's 32 columns.
+// src = Xs / Hs ([part][group][P rows]), wt = the conv's 15 pieces, col = this lane's column of tap 0, clamped to [lo, hi].
+template <int P, int DIL>
+__device__ __forceinline__ void conv24_phase(f32x16& acc, const u32x4* src, const u32x4* wt, int col, int lo, int hi, int lane) {
+    const int lh = lane >> 5;
+    // unit u = 2 s + lh -> tap u / 3, group u % 3 (u = 9: zero weights, any valid row)
+    constexpr int TAP0[5] = {0, 0, 1, 2, 2}, GRP0[5] = {0, 2, 1, 0, 2};
+    constexpr int TAP1[5] = {0, 1, 1, 2, 2}, GRP1[5] = {1, 0, 2, 1, 2};
+    int row[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        int c = col + (lh ? TAP1[s] : TAP0[s]) * DIL;
+        c = c < lo ? lo : (c > hi ? hi : c);
+        row[s] = (lh ? GRP1[s] : GRP0[s]) * P + c;
+    }
+    bf16x8 af[2][3], bf[2][3];
+    auto frags = [&](int s, int fb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            bf[fb][p] = __builtin_bit_cast(bf16x8, src[p * 3 * P + row[s]]);
+            af[fb][p] = __builtin_bit_cast(bf16x8, wt[(s * 3 + p) * 64 + lane]);
+        }
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int fb = s & 1;
+        if (s + 1 < 5) frags(s + 1, fb ^ 1);
+        __builtin_amdgcn_sched_barrier(0);   // next step's LDS reads stay above this step's MFMAs
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][PA[q]], bf[fb][PB[q]], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <class CF>
+__global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE))) void up24s_kernel(Up24SArgs a) {
+    constexpr int C = CF::C, W = CF::W, D1 = CF::D1, D2 = CF::D2, H = CF::H, E = CF::E, NT = CF::NT;
+    constexpr int XP = CF::XP, HP = CF::HP, PS = CF::PS, XW = CF::XW, XPER = CF::XPER;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem_u);
+    u32x4* Hs = Xs + 9 * XP;
+    u32x4* Wt = Hs + 9 * HP;
+    float* Fl = reinterpret_cast<float*>(Wt + CF::PIECES * 64);   // ba, bb, bsc, bsh [32 each], w75 [24][7], b75
+    float* R = Fl + CF::FL;                                       // [24][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int len = a.len;
+    const int lin = CF::SECOND ? len : len / a.xf;
+
+    // ---- once per workgroup: weights and biases -> LDS -------------------------------------------------
+    for (int i = tid; i < CF::PIECES * 64 + CF::FL / 4; i += NT) Wt[i] = a.img[i];
+
+    // ---- input tile staging: an item = 8 channels of one position ---------------------------------------
+    float xr0[XPER][8], xr1[XPER][8];
+    auto item = [&](int i, int& g, int& c) __attribute__((always_inline)) {
+        const int idx = tid + i * NT;
+        g = idx / XW;
+        c = idx - g * XW;
+        return idx < CF::ITEMS;          // idle items still load (g = 3 -> 2: a valid address), never store
+    };
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+        const int b = tile / a.tiles_per_utt;
+        const int px0 = (tile - b * a.tiles_per_utt) * W - E - H;
+        const float* xb = a.x + (long)b * C * lin;
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) {
+            int g, c;
+            item(i, g, c);
+            g = g > 2 ? 2 : g;
+            int p = px0 + c;
+            p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+            if (CF::SECOND) {
+                const unsigned o = (unsigned)(8 * g * lin + p);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xr0[i][j] = xb[o + (unsigned)(j * lin)];
+            } else {
+                const Lerp lc = lerp_coord(p, a.interp_scale, lin);
+                const unsigned o0 = (unsigned)(8 * g * lin + lc.i0), o1 = (unsigned)(8 * g * lin + lc.i1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xr0[i][j] = xb[o0 + (unsigned)(j * lin)];
+                    xr1[i][j] = xb[o1 + (unsigned)(j * lin)];
+                }
+            }
+        }
+    };
+    auto deposit = [&](int tile) __attribute__((always_inline)) {
+        const int b = tile / a.tiles_per_utt;
+        const int px0 = (tile - b * a.tiles_per_utt) * W - E - H;
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) {
+            int g, c;
+            if (!item(i, g, c)) continue;
+            float v[8];
+            if (CF::SECOND) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = xr0[i][j];
+            } else {
+                int p = px0 + c;
+                p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+                const Lerp lc = lerp_coord(p, a.interp_scale, lin);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = lerp_eval(lc, xr0[i][j], xr1[i][j]);
+            }
+            const int rc = c - H;                                  // residual column
+            if (rc >= 0 && rc < CF::W2r) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) R[(8 * g + j) * PS + rc] = v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.1f * v[j]);   // = leaky_relu(x, 0.1)
+            uint4 p1, p2, p3;
+            split8(v, p1, p2, p3);
+            Xs[(0 + g) * XP + c] = __builtin_bit_cast(u32x4, p1);
+            Xs[(3 + g) * XP + c] = __builtin_bit_cast(u32x4, p2);
+            Xs[(6 + g) * XP + c] = __builtin_bit_cast(u32x4, p3);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) {
+        fetch(tile);
+        deposit(tile);
+    }
+    slab_barrier();
+
+    for (; tile < a.ntiles; tile += gridDim.x) {
+        const int b = tile / a.tiles_per_utt;
+        const int t0 = (tile - b * a.tiles_per_utt) * W;
+        const int px0 = t0 - E - H;       // position of Xs column 0
+        const int ph0 = t0 - E - D2;      // position of Hs column 0
+        const int p20 = t0 - E;           // position of second-conv column 0
+        const int next = tile + gridDim.x;
+
+        // FiLM cond of this wave's second-conv tile, straight into B-fragment order: step 0 = channels 8 lh + j,
+        // step 1 = channels 16 + j for lh = 0 (the other half is the zero unit)
+        float cr0[8], cr1[8];
+        if (wave < CF::NT2) {
+            const float* cb = a.cond + (long)b * C * len;
+            int t = p20 + wave * 32 + l31;
+            t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                cr0[j] = cb[(unsigned)((8 * lh + j) * len + t)];
+                cr1[j] = cb[(unsigned)((16 + j) * len + t)];
+            }
+        }
+        if (next < a.ntiles) fetch(next);   // lands in registers during the whole tile
+
+        // ---- S1: Hs = split(lrelu(conv_a(lrelu(x)) + ba)) ---------------------------------------------
+        for (int nt = wave; nt < CF::NT1; nt += CF::NWAVES) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int h = nt * 32 + l31;
+            conv24_phase<XP, D1>(acc, Xs, Wt, h, 0, XW - 1, lane);      // Xs already holds the replicate-padded input
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const f32x4s bv = *reinterpret_cast<const f32x4s*>(Fl + 8 * g + 4 * lh);
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float t = acc[4 * g + q] + bv[q];
+                    v[q] = fmaxf(t, 0.1f * t);
+                }
+                u32x2 p1, p2, p3;
+                split4(v, p1, p2, p3);
+                u32x2* hrow = reinterpret_cast<u32x2*>(Hs);
+                hrow[((0 + g) * HP + h) * 2 + lh] = p1;
+                hrow[((3 + g) * HP + h) * 2 + lh] = p2;
+                hrow[((6 + g) * HP + h) * 2 + lh] = p3;
+            }
+        }
+        slab_barrier();
+
+        // ---- S2: (conv_b(Hs) + bb) * scale + shift + res ------------------------------------------------
+        if (wave < CF::NT2) {
+            const int n = wave * 32 + l31;
+            const int t = p20 + n;
+            bf16x8 cf[2][3];
+            {
+                uint4 p1, p2, p3;
+                split8(cr0, p1, p2, p3);
+                cf[0][0] = __builtin_bit_cast(bf16x8, p1);
+                cf[0][1] = __builtin_bit_cast(bf16x8, p2);
+                cf[0][2] = __builtin_bit_cast(bf16x8, p3);
+                split8(cr1, p1, p2, p3);
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                cf[1][0] = __builtin_bit_cast(bf16x8, lh ? z : p1);
+                cf[1][1] = __builtin_bit_cast(bf16x8, lh ? z : p2);
+                cf[1][2] = __builtin_bit_cast(bf16x8, lh ? z : p3);
+            }
+            f32x16 acc, asc, ash;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = asc[r] = ash[r] = 0.f;
+            const int lo = -ph0 > 0 ? -ph0 : 0;                                    // the layer's own replicate padding
+            const int hi = (len - 1 - ph0) < (HP - 1) ? (len - 1 - ph0) : (HP - 1);
+            conv24_phase<HP, D2>(acc, Hs, Wt + 15 * 64, n, lo, hi, lane);
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 fa[2][3];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) fa[mt][p] = __builtin_bit_cast(bf16x8, Wt[(30 + (s * 2 + mt) * 3 + p) * 64 + lane]);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    asc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][PA[q]], cf[s][PB[q]], asc, 0, 0, 0);
+                    ash = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][PA[q]], cf[s][PB[q]], ash, 0, 0, 0);
+                }
+            }
+            float* ob = CF::SECOND ? nullptr : a.out + (long)b * C * len;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const f32x4s bb = *reinterpret_cast<const f32x4s*>(Fl + 32 + 8 * g + 4 * lh);
+                const f32x4s bs = *reinterpret_cast<const f32x4s*>(Fl + 64 + 8 * g + 4 * lh);
+                const f32x4s bh = *reinterpret_cast<const f32x4s*>(Fl + 96 + 8 * g + 4 * lh);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = 8 * g + 4 * lh + q;
+                    const float hval = acc[4 * g + q] + bb[q];
+                    const float sc = asc[4 * g + q] + bs[q];
+                    const float sh = ash[4 * g + q] + bh[q];
+                    const float res = R[m * PS + n];
+                    const float v = __fadd_rn(__fadd_rn(__fmul_rn(hval, sc), sh), res);
+                    if (CF::SECOND)
+                        R[m * PS + n] = v;                                     // x2 stays on chip
+                    else if (n < W && t < len)
+                        ob[(unsigned)(m * len + t)] = v;                       // x1
+                }
+            }
+        }
+        if (CF::SECOND) {
+            slab_barrier();
+            // ---- S4: c5 and output_layer folded into one Conv1d(24 -> 1, k7, replicate) on the parked x2 tile ----
+            // 8 lanes per group of 4 consecutive outputs, 3 channels each: per channel 10 activations and 7
+            // (broadcast) weights feed 28 FMAs; the 8 partial sums meet through three shuffles.
+            const float* W7 = Fl + 128;
+            const int part = tid & 7;
+            const int lo = -p20 > 0 ? -p20 : 0;
+            const int hi = (len - 1 - p20) < (CF::W2 - 1) ? (len - 1 - p20) : (CF::W2 - 1);
+            for (int g0 = 0; g0 < (W + 3) / 4; g0 += NT / 8) {      // uniform trip count: the shuffles need every lane
+                const int g = g0 + (tid >> 3);
+                float o4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (4 * g < W) {
+                    int cols[10];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        int c = 4 * g + E - 3 + i;
+                        cols[i] = c < lo ? lo : (c > hi ? hi : c);
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        const int c = part * 3 + cc;
+                        float xv[10], wv[7];
+#pragma unroll
+                        for (int i = 0; i < 10; ++i) xv[i] = R[c * PS + cols[i]];
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) wv[j] = W7[c * 7 + j];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int j = 0; j < 7; ++j) o4[q] = fmaf(wv[j], xv[q + j], o4[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o4[q] += __shfl_xor(o4[q], 1);
+                    o4[q] += __shfl_xor(o4[q], 2);
+                    o4[q] += __shfl_xor(o4[q], 4);
+                }
+                const int o = 4 * g + part;                  // lanes 0..3 of a group store outputs 4g..4g+3
+                const float v = part == 0 ? o4[0] : (part == 1 ? o4[1] : (part == 2 ? o4[2] : o4[3]));
+                if (part < 4 && o < W && t0 + o < len) a.out[(long)b * len + t0 + o] = v + W7[168];
+            }
+        }
+        // ---- next tile's input: registers -> LDS ----------------------------------------------------------
+        slab_barrier();                                   // every wave is done with Xs, Hs and R
+        if (next < a.ntiles) deposit(next);
+        slab_barrier();
+    }
+}
+
+template <class CF>
+static int launch_up24s(tvc_ctx* ctx, hipStream_t s, Up24SArgs a, int B) {
+    static int ncu_dev[64] = {};                    // per device of this process (the LDS attribute is per function and device)
+    int& ncu = ncu_dev[ctx->device & 63];
+    const size_t lds = (size_t)CF::LDS_BYTES;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)up24s_kernel<CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "up24s setup: %s", hipGetErrorString(e));
+        ncu = prop.multiProcessorCount;
+    }
+    a.tiles_per_utt = (a.len + CF::W - 1) / CF::W;
+    a.ntiles = a.tiles_per_utt * B;
+    int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    hipLaunchKernelGGL((up24s_kernel<CF>), dim3(grid), dim3(CF::NT), lds, s, a);
+    return launch_check(ctx, "up24s");
+}
+
+#ifndef U24S_WA
+#define U24S_WA 250
+#endif
+#ifndef U24S_WB
+#define U24S_WB 250
+#endif
+
+// Upsample block with cin == 24 followed by FilterNet.output_layer:
+// x [B][24][len/f], cond [B][24][len] -> wave [B][len]; x1 is scratch [B][24][len].
+int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, const float* cond, float* x1, float* wave, int B, int len) {
+    if (!u.s24a || !u.s24b) return fail(ctx, TVC_ERR_STATE, "up24s: the split weight blobs of the 24-channel block are missing");
+    if ((long)len * 24 >= (1L << 31)) return fail(ctx, TVC_ERR_ARG, "up24s: utterance too long for 32-bit element offsets");
+    using CA = U24S<U24S_WA, 1, 3, false, 0>;
+    using CB = U24S<U24S_WB, 9, 27, true, 3>;
+    Up24SArgs a{};
+    a.len = len;
+    a.xf = u.factor;
+    a.interp_scale = (float)(1.0 / (double)u.factor);
+    a.cond = cond;
+    a.x = x;
+    a.out = x1;
+    a.img = reinterpret_cast<const u32x4*>(u.s24a);
+    TVC_CHECK(launch_up24s<CA>(ctx, s, a, B));
+    a.x = x1;
+    a.out = wave;
+    a.img = reinterpret_cast<const u32x4*>(u.s24b);
+    return launch_up24s<CB>(ctx, s, a, B);
+}
+
+}  // namespace tvc

@@ -55,6 +55,8 @@ struct DownW {
 struct UpW {
     PackedW c1, c2, c3, c4, c5, film1, film2;  // film = [to_scale ; to_shift] stacked on M (2C)
     PackedW sc1, sh1, sc2, sh2;                // the same FiLM 1x1s packed separately (fused block kernels)
+    const float* s24a = nullptr;               // cin == 24: weight blobs of the two halves of the split-precision fused block (filter_up24s.hip)
+    const float* s24b = nullptr;
     int cin = 0, cout = 0, factor = 1;
 };
 
@@ -218,6 +220,7 @@ int run_prepare_index(tvc_ctx*, hipStream_t, const float* index, float* prepared
 // fused FilterNet kernels (filter_fused.hip)
 int run_up24_fused(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len,
                    const float* w7, const float* b7);
+int run_up24_split(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len);
 int run_down0(tvc_ctx*, hipStream_t, const PackedW& w, const float* source, const float* energy, float* out, int B, int len);
 int run_out_conv7(tvc_ctx*, hipStream_t, const float* x, const float* w_raw, const float* bias, float* y, int B, int C, int len);
 
