@@ -27,6 +27,9 @@ namespace tvc {
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 
+#ifndef U24S_ABL
+#define U24S_ABL 0   // timing ablations (wrong results): 1 no S1 MFMA, 2 no S2 conv MFMA, 4 no FiLM MFMA, 8 no deposit, 16 no S1 epilogue, 32 no S4, 64 no fetch, 128 no S2 epilogue
+#endif
 #ifndef U24S_WPE
 #define U24S_WPE 2     // 8 waves per CU: 256 registers each
 #endif
@@ -74,6 +77,22 @@ __device__ __forceinline__ void split4(const float (&v)[4], u32x2& p1, u32x2& p2
         p2[j] = __builtin_bit_cast(unsigned, h2);
         p3[j] = __builtin_bit_cast(unsigned, h3);
     }
+}
+// uniform base (SGPR pair) + 32-bit byte offset per lane: the global_load saddr form, no 64-bit vector address arithmetic
+// Global accesses as uniform base (SGPR pair) + 32-bit byte offset per lane (the global_load saddr form): the row bases are
+// pinned into SGPRs through an empty asm, otherwise the compiler re-associates base + row stride into chains of 64-bit
+// vector adds (one v_lshl_add_u64 per load).
+typedef const __attribute__((address_space(1))) float* gcf32;
+typedef __attribute__((address_space(1))) float* gf32;
+__device__ __forceinline__ float ldg_so(const float* base, unsigned byte_off) {
+    gcf32 p = (gcf32)base;
+    asm("" : "+s"(p));
+    return *reinterpret_cast<gcf32>(reinterpret_cast<const __attribute__((address_space(1))) char*>(p) + byte_off);
+}
+__device__ __forceinline__ void stg_so(float* base, unsigned byte_off, float v) {
+    gf32 p = (gf32)base;
+    asm("" : "+s"(p));
+    *reinterpret_cast<gf32>(reinterpret_cast<__attribute__((address_space(1))) char*>(p) + byte_off) = v;
 }
 __device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
@@ -133,61 +152,61 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     for (int i = tid; i < CF::PIECES * 64 + CF::FL / 4; i += NT) Wt[i] = a.img[i];
 
     // ---- input tile staging: an item = 8 channels of one position ---------------------------------------
-    float xr0[XPER][8], xr1[XPER][8];
-    auto item = [&](int i, int& g, int& c) __attribute__((always_inline)) {
+    // Per-thread item geometry is tile-invariant; global addresses are a uniform per-channel base (SGPRs) plus one 32-bit
+    // lane offset per item, so a load costs no vector address arithmetic.
+    float xr0[XPER][8], xr1[XPER][8], lam[XPER];
+    int ig8[XPER], ic[XPER];
+    bool ilive[XPER];
+#pragma unroll
+    for (int i = 0; i < XPER; ++i) {
         const int idx = tid + i * NT;
-        g = idx / XW;
-        c = idx - g * XW;
-        return idx < CF::ITEMS;          // idle items still load (g = 3 -> 2: a valid address), never store
-    };
+        int g = idx / XW;
+        ic[i] = idx - g * XW;
+        ilive[i] = idx < CF::ITEMS;      // idle items still load (g = 3 -> 2: a valid address), never store
+        ig8[i] = 8 * (g > 2 ? 2 : g);
+    }
     auto fetch = [&](int tile) __attribute__((always_inline)) {
         const int b = tile / a.tiles_per_utt;
         const int px0 = (tile - b * a.tiles_per_utt) * W - E - H;
         const float* xb = a.x + (long)b * C * lin;
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
-            int g, c;
-            item(i, g, c);
-            g = g > 2 ? 2 : g;
-            int p = px0 + c;
+            int p = px0 + ic[i];
             p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
             if (CF::SECOND) {
-                const unsigned o = (unsigned)(8 * g * lin + p);
+                const unsigned o = 4u * (unsigned)(ig8[i] * lin + p);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xr0[i][j] = xb[o + (unsigned)(j * lin)];
+                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xb + (long)j * lin, o);
             } else {
                 const Lerp lc = lerp_coord(p, a.interp_scale, lin);
-                const unsigned o0 = (unsigned)(8 * g * lin + lc.i0), o1 = (unsigned)(8 * g * lin + lc.i1);
+                lam[i] = lc.w1;
+                const unsigned o0 = 4u * (unsigned)(ig8[i] * lin + lc.i0), o1 = 4u * (unsigned)(ig8[i] * lin + lc.i1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    xr0[i][j] = xb[o0 + (unsigned)(j * lin)];
-                    xr1[i][j] = xb[o1 + (unsigned)(j * lin)];
+                    xr0[i][j] = ldg_so(xb + (long)j * lin, o0);
+                    xr1[i][j] = ldg_so(xb + (long)j * lin, o1);
                 }
             }
         }
     };
-    auto deposit = [&](int tile) __attribute__((always_inline)) {
-        const int b = tile / a.tiles_per_utt;
-        const int px0 = (tile - b * a.tiles_per_utt) * W - E - H;
+    auto deposit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
-            int g, c;
-            if (!item(i, g, c)) continue;
+            if (!ilive[i]) continue;
+            const int g = ig8[i] >> 3, c = ic[i];
             float v[8];
             if (CF::SECOND) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = xr0[i][j];
             } else {
-                int p = px0 + c;
-                p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
-                const Lerp lc = lerp_coord(p, a.interp_scale, lin);
+                const float w0 = 1.f - lam[i];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = lerp_eval(lc, xr0[i][j], xr1[i][j]);
+                for (int j = 0; j < 8; ++j) v[j] = fmaf(w0, xr0[i][j], __fmul_rn(lam[i], xr1[i][j]));   // = lerp_eval
             }
             const int rc = c - H;                                  // residual column
             if (rc >= 0 && rc < CF::W2r) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) R[(8 * g + j) * PS + rc] = v[j];
+                for (int j = 0; j < 8; ++j) R[(ig8[i] + j) * PS + rc] = v[j];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.1f * v[j]);   // = leaky_relu(x, 0.1)
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     int tile = blockIdx.x;
     if (tile < a.ntiles) {
         fetch(tile);
-        deposit(tile);
+        deposit();
     }
     slab_barrier();
 
@@ -221,13 +240,14 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
             const float* cb = a.cond + (long)b * C * len;
             int t = p20 + wave * 32 + l31;
             t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
+            const unsigned o0 = 4u * (unsigned)(8 * lh * len + t), o1 = 4u * (unsigned)t;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                cr0[j] = cb[(unsigned)((8 * lh + j) * len + t)];
-                cr1[j] = cb[(unsigned)((16 + j) * len + t)];
+                cr0[j] = ldg_so(cb + (long)j * len, o0);
+                cr1[j] = ldg_so(cb + (long)(16 + j) * len, o1);
             }
         }
-        if (next < a.ntiles) fetch(next);   // lands in registers during the whole tile
+        if (next < a.ntiles && !(U24S_ABL & 64)) fetch(next);   // lands in registers during the whole tile
 
         // ---- S1: Hs = split(lrelu(conv_a(lrelu(x)) + ba)) ---------------------------------------------
         for (int nt = wave; nt < CF::NT1; nt += CF::NWAVES) {
@@ -235,9 +255,9 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const int h = nt * 32 + l31;
-            conv24_phase<XP, D1>(acc, Xs, Wt, h, 0, XW - 1, lane);      // Xs already holds the replicate-padded input
+            if (!(U24S_ABL & 1)) conv24_phase<XP, D1>(acc, Xs, Wt, h, 0, XW - 1, lane);      // Xs already holds the replicate-padded input
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
+            for (int g = 0; g < ((U24S_ABL & 16) ? 0 : 3); ++g) {
                 const f32x4s bv = *reinterpret_cast<const f32x4s*>(Fl + 8 * g + 4 * lh);
                 float v[4];
 #pragma unroll
@@ -277,10 +297,10 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
             for (int r = 0; r < 16; ++r) acc[r] = asc[r] = ash[r] = 0.f;
             const int lo = -ph0 > 0 ? -ph0 : 0;                                    // the layer's own replicate padding
             const int hi = (len - 1 - ph0) < (HP - 1) ? (len - 1 - ph0) : (HP - 1);
-            conv24_phase<HP, D2>(acc, Hs, Wt + 15 * 64, n, lo, hi, lane);
+            if (!(U24S_ABL & 2)) conv24_phase<HP, D2>(acc, Hs, Wt + 15 * 64, n, lo, hi, lane);
             constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < ((U24S_ABL & 4) ? 0 : 2); ++s) {
                 bf16x8 fa[2][3];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -293,8 +313,9 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 }
             }
             float* ob = CF::SECOND ? nullptr : a.out + (long)b * C * len;
+            const unsigned oo = 4u * (unsigned)(4 * lh * len + t);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
+            for (int g = 0; g < ((U24S_ABL & 128) ? 0 : 3); ++g) {
                 const f32x4s bb = *reinterpret_cast<const f32x4s*>(Fl + 32 + 8 * g + 4 * lh);
                 const f32x4s bs = *reinterpret_cast<const f32x4s*>(Fl + 64 + 8 * g + 4 * lh);
                 const f32x4s bh = *reinterpret_cast<const f32x4s*>(Fl + 96 + 8 * g + 4 * lh);
@@ -309,11 +330,11 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                     if (CF::SECOND)
                         R[m * PS + n] = v;                                     // x2 stays on chip
                     else if (n < W && t < len)
-                        ob[(unsigned)(m * len + t)] = v;                       // x1
+                        stg_so(ob + (long)(8 * g + q) * len, oo, v);           // x1 (uniform row base + lane offset)
                 }
             }
         }
-        if (CF::SECOND) {
+        if (CF::SECOND && !(U24S_ABL & 32)) {
             slab_barrier();
             // ---- S4: c5 and output_layer folded into one Conv1d(24 -> 1, k7, replicate) on the parked x2 tile ----
             // 8 lanes per group of 4 consecutive outputs, 3 channels each: per channel 10 activations and 7
@@ -359,7 +380,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         }
         // ---- next tile's input: registers -> LDS ----------------------------------------------------------
         slab_barrier();                                   // every wave is done with Xs, Hs and R
-        if (next < a.ntiles) deposit(next);
+        if (next < a.ntiles && !(U24S_ABL & 8)) deposit();
         slab_barrier();
     }
 }
@@ -394,7 +415,7 @@ static int launch_up24s(tvc_ctx* ctx, hipStream_t s, Up24SArgs a, int B) {
 // x [B][24][len/f], cond [B][24][len] -> wave [B][len]; x1 is scratch [B][24][len].
 int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, const float* cond, float* x1, float* wave, int B, int len) {
     if (!u.s24a || !u.s24b) return fail(ctx, TVC_ERR_STATE, "up24s: the split weight blobs of the 24-channel block are missing");
-    if ((long)len * 24 >= (1L << 31)) return fail(ctx, TVC_ERR_ARG, "up24s: utterance too long for 32-bit element offsets");
+    if ((long)len * 24 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "up24s: utterance too long for 32-bit element offsets");
     using CA = U24S<U24S_WA, 1, 3, false, 0>;
     using CB = U24S<U24S_WB, 9, 27, true, 3>;
     Up24SArgs a{};
