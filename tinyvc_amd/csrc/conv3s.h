@@ -68,8 +68,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef S_FB_F
 #define S_FB_F 1   // FiLM-fused kernels: two accumulator sets live, single fragment set keeps the slab loops spill-free
 #endif
+#ifndef S_DB
+#define S_DB 0     // 1: 12-wave conv workgroups use two staging buffers, slab s+1 is split and written to LDS while slab s multiplies (one barrier per slab); measured slower (7.08 -> 7.3-7.6 ms for every S_EARLY order)
+#endif
+#ifndef S_DB_G
+#define S_DB_G 0   // the same for the 8-wave GEMM workgroups (two of them share a CU: LDS allows it only without the SCALED factor rows)
+#endif
+#ifndef S_EARLY
+#define S_EARLY 2   // which waves stage the next slab BEFORE their MFMAs (the others after): 0 none, 1 all, 2 (wave >> 2) & 1, 3 wave & 1
+#endif
 #ifndef S_ABL
-#define S_ABL 0   // timing ablations (wrong results): 1 no MFMA, 2 no weight loads, 4 no input loads, 8 no input split/stores, 16 no output stores
+#define S_ABL 0   // timing ablations (wrong results): 1 no MFMA, 2 no weight loads, 4 no input loads, 8 no input split/stores, 16 no output stores, 32 no residual, 64 park only (no vector pass), 128 park + barriers only
 #endif
 
 
@@ -87,14 +96,16 @@ struct SplitTile {
     static constexpr int X_U4 = KG * XG_U4;
     static constexpr int X_PER = (KG * 2 * XROW + NTHR - 1) / NTHR;             // staging items per thread
     static constexpr int a_u4(int taps) { return taps * KG * MTB * 3 * 64; }
+    static constexpr bool DB = NW > 8 ? (S_DB != 0) : (S_DB_G != 0);           // double-buffered staging
+    static constexpr int stage_u4(int taps) { return a_u4(taps) + X_U4; }
     static constexpr int KS_MAX = 2 * 768;                                      // SCALED launch: factors of <= 768 input channels for the <= 2 utterances a tile touches
     static constexpr int OS = BN + 4;                                           // row stride (floats) of the output tile parked in LDS
     static constexpr int lds_bytes(int taps) {
-        const int stage = (a_u4(taps) + X_U4) * 16, out = BM * OS * 4;
+        const int stage = stage_u4(taps) * 16 * (DB ? 2 : 1), out = BM * OS * 4;
         return (stage > out ? stage : out) + 3 * BM * 4 + KS_MAX * 4;      // + bias / FiLM-bias rows of this workgroup + input-channel factors
     }
     static constexpr int bias_off(int taps) {                  // float offset of that area
-        const int stage = (a_u4(taps) + X_U4) * 16, out = BM * OS * 4;
+        const int stage = stage_u4(taps) * 16 * (DB ? 2 : 1), out = BM * OS * 4;
         return (stage > out ? stage : out) / 4;
     }
 };
@@ -115,6 +126,28 @@ struct ConvSArgs {
     const float* cond = nullptr;
     int Ccond = 0;
 };
+
+// Global accesses as uniform base (SGPR pair) + 32-bit byte offset per lane (the global_load saddr form): the row bases are
+// pinned into SGPRs through an empty asm, otherwise the compiler re-associates base + row stride into chains of 64-bit
+// vector adds (one v_lshl_add_u64 per load).
+typedef const __attribute__((address_space(1))) float* gcf32;
+typedef __attribute__((address_space(1))) float* gf32;
+__device__ __forceinline__ float ldg_so(const float* base, unsigned byte_off) {
+    gcf32 p = (gcf32)base;
+    asm("" : "+s"(p));
+    return *reinterpret_cast<gcf32>(reinterpret_cast<const __attribute__((address_space(1))) char*>(p) + byte_off);
+}
+__device__ __forceinline__ void stg_so(float* base, unsigned byte_off, float v) {
+    gf32 p = (gf32)base;
+    asm("" : "+s"(p));
+    *reinterpret_cast<gf32>(reinterpret_cast<__attribute__((address_space(1))) char*>(p) + byte_off) = v;
+}
+__device__ __forceinline__ u32x4 ldg_so4(const uint4* base, unsigned byte_off) {
+    typedef const __attribute__((address_space(1))) u32x4* gcu4;
+    gcu4 p = (gcu4)base;
+    asm("" : "+s"(p));
+    return *reinterpret_cast<gcu4>(reinterpret_cast<const __attribute__((address_space(1))) char*>(p) + byte_off);
+}
 
 // three bf16 parts of 8 fp32 values, packed for one 16-byte LDS row each
 __device__ __forceinline__ void split8(const float (&v)[8], uint4& p1, uint4& p2, uint4& p3) {
@@ -209,7 +242,7 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
             int q = wave + i * NW;
             q = q < PIECES ? q : PIECES - 1;
             const int tap = q / (MTB * 3), rem = q - tap * (MTB * 3);
-            r.ar[i] = *reinterpret_cast<const u32x4*>(a_src + ((long)(s * STEPS + tap) * MT * 192 + rem * 64) + lane);
+            r.ar[i] = ldg_so4(a_src + (long)s * STEPS * MT * 192, 16u * (unsigned)(tap * MT * 192 + rem * 64 + lane));   // uniform slab base + this wave's piece
         }
     }
     if (S_ABL & 4) return;
@@ -220,8 +253,8 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
         for (int i = 0; i < X_PER; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                r.xr[i][j] = xc[m.xo[i] + (unsigned)(j * cs)];
-                r.xr2[i][j] = xc[m.xo1[i] + (unsigned)(j * cs)];
+                r.xr[i][j] = ldg_so(xc + (long)j * cs, 4u * m.xo[i]);
+                r.xr2[i][j] = ldg_so(xc + (long)j * cs, 4u * m.xo1[i]);
             }
         return;
     }
@@ -239,7 +272,7 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
 #pragma unroll
     for (int i = 0; i < X_PER; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.xr[i][j] = xc[m.xo[i] + (unsigned)(j * cs)];
+        for (int j = 0; j < 8; ++j) r.xr[i][j] = ldg_so(xc + (long)j * cs, 4u * m.xo[i]);   // uniform row base + one 32-bit lane offset per item
 }
 // slab 0 of a phase, issued by whoever runs before it (previous phase / previous tile / kernel entry)
 template <class TL, int TAPS, bool LERP = false, bool CLAMP = false>
@@ -265,12 +298,15 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     make_map<TL, LERP>(m, len, dil, t0, fT, fstride, Cin, lin, lscale);
     constexpr int STEPS = TAPS * TL::KG;               // K16 steps per slab: (channel group, tap)
     constexpr int PIECES = STEPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
-    auto lstore = [&](int sl) __attribute__((always_inline)) {
+    constexpr int STG = TL::DB ? A_U4 + TL::X_U4 : 0;     // u4 stride between the two staging buffers
+    auto lstore = [&](int sl, int buf) __attribute__((always_inline)) {
+        uint4* Asb = As + buf * STG;
+        uint4* Xsb = Xs + buf * STG;
         if (!(S_ABL & 2)) {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 const int q = wave + i * NW;
-                if (q < PIECES) *reinterpret_cast<u32x4*>(As + q * 64 + lane) = r.ar[i];
+                if (q < PIECES) *reinterpret_cast<u32x4*>(Asb + q * 64 + lane) = r.ar[i];
             }
         }
 #pragma unroll
@@ -292,21 +328,46 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
                 }
                 uint4 p1, p2, p3;
                 split8(r.xr[i], p1, p2, p3);
-                Xs[m.xdst[i]] = p1;
-                Xs[2 * XROW + m.xdst[i]] = p2;
-                Xs[4 * XROW + m.xdst[i]] = p3;
+                Xsb[m.xdst[i]] = p1;
+                Xsb[2 * XROW + m.xdst[i]] = p2;
+                Xsb[4 * XROW + m.xdst[i]] = p3;
             }
     };
 
     const int nslab = Cin / (16 * TL::KG);
-    const uint4* as = As + wm * WM * 192 + lane;
-    const uint4* xs = Xs + lh * XROW + wn * WN * 32 + l31;
-    for (int s = 0; s < nslab; ++s) {
-        slab_barrier();                            // every wave is done reading the previous slab
-        lstore(s);                                 // slab s: registers -> LDS
-        if (s + 1 < nslab) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin);   // flies across this slab's MFMAs
+    const uint4* as0 = As + wm * WM * 192 + lane;
+    const uint4* xs0 = Xs + lh * XROW + wn * WN * 32 + l31;
+    // Double-buffered staging: slab s + 1 is split and written into the other buffer while slab s multiplies, one barrier per
+    // slab.  Half of the waves stage first and multiply second, the others the reverse, so the SIMD's vector and matrix
+    // pipes both have work all the time (with a single buffer every wave staged, then every wave multiplied).
+    const bool early = S_EARLY == 1 || (S_EARLY == 2 && ((wave >> 2) & 1)) || (S_EARLY == 3 && (wave & 1));
+    if (TL::DB) {
+        slab_barrier();                            // the previous phase / tile is done with both buffers
+        lstore(0, 0);
+        if (1 < nslab) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, 1, fT, cmax, lin);
         else next();
-        slab_barrier();
+    }
+    for (int s = 0; s < nslab; ++s) {
+        auto stage_next = [&]() __attribute__((always_inline)) {
+            if (s + 1 < nslab) {
+                lstore(s + 1, (s + 1) & 1);
+                if (s + 2 < nslab) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 2, fT, cmax, lin);
+                else next();
+            }
+        };
+        if (TL::DB) {
+            slab_barrier();                        // slab s is complete in its buffer; every wave has finished reading the other one
+            if (early) stage_next();
+            __builtin_amdgcn_sched_barrier(0);     // the staging code stays on its side of the MFMAs (hoisted above them it drags its vmcnt wait along)
+        } else {
+            slab_barrier();                            // every wave is done reading the previous slab
+            lstore(s, 0);                              // slab s: registers -> LDS
+            if (s + 1 < nslab) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin);   // flies across this slab's MFMAs
+            else next();
+            slab_barrier();
+        }
+        const uint4* as = as0 + (s & 1) * STG;
+        const uint4* xs = xs0 + (s & 1) * STG;
         // fragments of tap t+1 are read while the MFMAs of tap t run
         bf16x8 af[2][WM][3], bf[2][WN][3];
         auto frags = [&](int tap, int fb) __attribute__((always_inline)) {
@@ -342,6 +403,8 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][i][PA[q]], bf[fb][j][PB[q]], acc[i][j], 0, 0, 0);
             if (FB == 2) __builtin_amdgcn_sched_barrier(0);
         }
+        if (TL::DB) __builtin_amdgcn_sched_barrier(0);
+        if (TL::DB && !early) stage_next();
     }
 }
 
@@ -361,7 +424,7 @@ __device__ __forceinline__ void film_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
             int q = wave + i * NW;
             q = q < PIECES ? q : PIECES - 1;
             const int grp = q / (MTB * 3), rem = q - grp * (MTB * 3);
-            r.ar[i] = *reinterpret_cast<const u32x4*>(F6 + (((long)s * MT + mt0 + grp * mtoff) * 192 + rem * 64) + lane);
+            r.ar[i] = ldg_so4(F6 + ((long)s * MT + mt0) * 192, 16u * (unsigned)(grp * mtoff * 192 + rem * 64 + lane));
         }
     }
     if (S_ABL & 4) return;
@@ -369,7 +432,7 @@ __device__ __forceinline__ void film_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
 #pragma unroll
     for (int i = 0; i < X_PER; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.xr[i][j] = xc[m.xo[i] + (unsigned)(j * len)];
+        for (int j = 0; j < 8; ++j) r.xr[i][j] = ldg_so(xc + (long)j * len, 4u * m.xo[i]);
 }
 template <class TL>
 __device__ __forceinline__ void film_first_load(SlabRegs<TL>& r, const uint4* __restrict__ F6, int MT, int mt0, int mtoff,
@@ -390,15 +453,17 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
     SlabMap<TL> m;
     make_map<TL>(m, len, 0, t0);
     const int nslab = Cin / 16;
-    const uint4* as = As + wm * WM * 192 + lane;
-    const uint4* xs = Xs + lh * XROW + wn * WN * 32 + l31;
-    for (int s = 0; s < nslab; ++s) {
-        slab_barrier();
+    const uint4* as0 = As + wm * WM * 192 + lane;
+    const uint4* xs0 = Xs + lh * XROW + wn * WN * 32 + l31;
+    const int stg = TL::DB ? (int)(Xs - As) + TL::X_U4 : 0;      // u4 stride between the two staging buffers (same as the conv phase's)
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+        uint4* Asb = As + buf * stg;
+        uint4* Xsb = Xs + buf * stg;
         if (!(S_ABL & 2)) {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 const int q = wave + i * NW;
-                if (q < PIECES) *reinterpret_cast<u32x4*>(As + q * 64 + lane) = r.ar[i];
+                if (q < PIECES) *reinterpret_cast<u32x4*>(Asb + q * 64 + lane) = r.ar[i];
             }
         }
 #pragma unroll
@@ -406,13 +471,39 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
             if (m.xdst[i] >= 0 && !(S_ABL & 8)) {
                 uint4 p1, p2, p3;
                 split8(r.xr[i], p1, p2, p3);
-                Xs[m.xdst[i]] = p1;
-                Xs[2 * XROW + m.xdst[i]] = p2;
-                Xs[4 * XROW + m.xdst[i]] = p3;
+                Xsb[m.xdst[i]] = p1;
+                Xsb[2 * XROW + m.xdst[i]] = p2;
+                Xsb[4 * XROW + m.xdst[i]] = p3;
             }
-        if (s + 1 < nslab) film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, s + 1);
-        else next();
+    };
+    const bool early = S_EARLY == 1 || (S_EARLY == 2 && ((wave >> 2) & 1)) || (S_EARLY == 3 && (wave & 1));
+    if (TL::DB) {
         slab_barrier();
+        lstore(0);
+        if (1 < nslab) film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, 1);
+        else next();
+    }
+    for (int s = 0; s < nslab; ++s) {
+        auto stage_next = [&]() __attribute__((always_inline)) {
+            if (s + 1 < nslab) {
+                lstore((s + 1) & 1);
+                if (s + 2 < nslab) film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, s + 2);
+                else next();
+            }
+        };
+        if (TL::DB) {
+            slab_barrier();
+            if (early) stage_next();
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            slab_barrier();
+            lstore(0);
+            if (s + 1 < nslab) film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, s + 1);
+            else next();
+            slab_barrier();
+        }
+        const uint4* as = as0 + (s & 1) * stg;
+        const uint4* xs = xs0 + (s & 1) * stg;
         bf16x8 fc[WM][3], fh[WM][3], bf[WN][3];
 #pragma unroll
         for (int j = 0; j < WN; ++j)
@@ -436,6 +527,8 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
                         asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[i][PA[q]], bf[j][PB[q]], asc[i][j], 0, 0, 0);
                         ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i][PA[q]], bf[j][PB[q]], ash[i][j], 0, 0, 0);
                     }
+        if (TL::DB) __builtin_amdgcn_sched_barrier(0);
+        if (TL::DB && !early) stage_next();
     }
 }
 
@@ -460,6 +553,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     slab_barrier();
     float* yb = y + ((long)b * M + mt0 * 32) * len + t0;      // offsets inside the tile's rows fit 32 bits
     // rlin > 0: the residual is F.interpolate(res_low) of a [B][M][rlin] tensor, evaluated here instead of read back
+    if (S_ABL & 128) return;
     const float* rb = RES ? (rlin > 0 ? res + ((long)b * M + mt0 * 32) * rlin : res + ((long)b * M + mt0 * 32) * len + t0) : nullptr;
     const int rows = M - mt0 * 32 < BM ? M - mt0 * 32 : BM;
     const bool vec = (len & 3) == 0;                        // rows start 16-byte aligned (t0 is a multiple of 32)
@@ -470,6 +564,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     for (int idx = tid; idx < BM * (BN / 4); idx += NTHR) {
         const int row = idx / (BN / 4), c = (idx - row * (BN / 4)) * 4;
         if (row >= rows || t0 + c >= len) continue;
+        if (S_ABL & 64) continue;
         const float4 o = *reinterpret_cast<const float4*>(Ot + row * OS + c);
         const int off = row * len + c;
         if (RES && rlin > 0) {
@@ -642,7 +737,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                     for (int j = 0; j < WN; ++j)
                         acc[i][j][r] = __fadd_rn(__fmul_rn(acc[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
                 }
-            tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
+            tile_store<TL, !(S_ABL & 32)>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
         } else {
             split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (TL::NW <= 8 ? S_FB_G : S_FB), SCALED, LERP, CLAMP>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                                                                                                    load_next_tile, Ks, fT, fstride, a.cmax, a.lin, a.lscale);
@@ -675,7 +770,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                     for (int j = 0; j < WN; ++j) acc[i][j][r] += bm;
                 }
             if constexpr (!Epi::kIgemm)
-                if (!(S_ABL & 16)) tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, ep.y2, ep.f2);
+                if (!(S_ABL & 16)) tile_store<TL, Epi::kRes && !(S_ABL & 32)>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, ep.y2, ep.f2);
         }
         tile = nxt;
         if (tile < vtiles) coords(tile, mt0, b, t0);

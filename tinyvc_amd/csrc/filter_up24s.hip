@@ -79,21 +79,6 @@ __device__ __forceinline__ void split4(const float (&v)[4], u32x2& p1, u32x2& p2
     }
 }
 // uniform base (SGPR pair) + 32-bit byte offset per lane: the global_load saddr form, no 64-bit vector address arithmetic
-// Global accesses as uniform base (SGPR pair) + 32-bit byte offset per lane (the global_load saddr form): the row bases are
-// pinned into SGPRs through an empty asm, otherwise the compiler re-associates base + row stride into chains of 64-bit
-// vector adds (one v_lshl_add_u64 per load).
-typedef const __attribute__((address_space(1))) float* gcf32;
-typedef __attribute__((address_space(1))) float* gf32;
-__device__ __forceinline__ float ldg_so(const float* base, unsigned byte_off) {
-    gcf32 p = (gcf32)base;
-    asm("" : "+s"(p));
-    return *reinterpret_cast<gcf32>(reinterpret_cast<const __attribute__((address_space(1))) char*>(p) + byte_off);
-}
-__device__ __forceinline__ void stg_so(float* base, unsigned byte_off, float v) {
-    gf32 p = (gf32)base;
-    asm("" : "+s"(p));
-    *reinterpret_cast<gf32>(reinterpret_cast<__attribute__((address_space(1))) char*>(p) + byte_off) = v;
-}
 __device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
