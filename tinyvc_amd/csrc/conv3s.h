@@ -542,15 +542,17 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / TL::NWV, wn = wave - wm * TL::NWV;
-    slab_barrier();                                // every wave is done with the staging buffers
+    auto park = [&]() __attribute__((always_inline)) {
+        slab_barrier();                                // every wave is done with the staging buffers
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Ot[((wm * WM + i) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)) * OS + (wn * WN + j) * 32 + l31] = v[i][j][r];
-    slab_barrier();
+                for (int r = 0; r < 16; ++r)
+                    Ot[((wm * WM + i) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)) * OS + (wn * WN + j) * 32 + l31] = v[i][j][r];
+        slab_barrier();
+    };
     float* yb = y + ((long)b * M + mt0 * 32) * len + t0;      // offsets inside the tile's rows fit 32 bits
     // rlin > 0: the residual is F.interpolate(res_low) of a [B][M][rlin] tensor, evaluated here instead of read back
     if (S_ABL & 128) return;
@@ -560,6 +562,97 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     // optional 1/f2-rate copy for the next Downsample block (see C3EpiBias): pick for f2 = 3 / 5, two-sample mean for f2 = 4
     const int len2 = f2 > 0 ? len / f2 : 0;
     float* y2b = y2 ? y2 + ((long)b * M + mt0 * 32) * len2 : nullptr;
+    if constexpr (RES) {
+        if (rlin > 0) {
+            // a thread's four columns are the same for every row it visits: the interpolation coordinates are computed once
+            constexpr int G = BN / 4, RS = NTHR / G;
+            static_assert(NTHR % G == 0, "column groups must tile the workgroup");
+            const int c = (tid % G) * 4;
+            unsigned o0[4], o1[4];
+            float lam[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + c + u < len ? t0 + c + u : len - 1;
+                const Lerp lc = lerp_coord(t, rscale, rlin);
+                o0[u] = 4u * (unsigned)lc.i0;
+                o1[u] = 4u * (unsigned)lc.i1;
+                lam[u] = lc.w1;
+            }
+            const bool full = vec && t0 + c + 3 < len;
+            // the residual taps of every row this thread will store are requested before the tile is parked: their latency
+            // runs under the two barriers and the LDS round trip instead of in front of every store
+            constexpr int NR = (BM + RS - 1) / RS;
+            float x0[NR][4], x1[NR][4];
+            const bool live = t0 + c < len;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                int row = tid / G + k * RS;
+                row = row < rows ? row : rows - 1;
+                const float* rr = rb + (long)row * rlin;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    x0[k][u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rr) + o0[u]);
+                    x1[k][u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rr) + o1[u]);
+                }
+            }
+            park();
+            if (!live) return;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const int row = tid / G + k * RS;
+                if (row >= rows) break;
+                const float4 o = *reinterpret_cast<const float4*>(Ot + row * OS + c);
+                const float e[4] = {o.x, o.y, o.z, o.w};
+                float w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = e[u] + fmaf(1.f - lam[u], x0[k][u], __fmul_rn(lam[u], x1[k][u]));          // = e + lerp_eval
+                const int off = row * len + c;
+                if (full) {
+                    *reinterpret_cast<float4*>(yb + off) = make_float4(w[0], w[1], w[2], w[3]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (t0 + c + u < len) yb[off + u] = w[u];
+                }
+            }
+            return;
+        }
+        if (vec && t0 + BN <= len) {
+            // whole tile inside the utterance: the residual rows are requested before the tile is parked (same reason)
+            constexpr int G = BN / 4, RS = NTHR / G, NR = (BM + RS - 1) / RS;
+            const int c = (tid % G) * 4;
+            float4 q[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                int row = tid / G + k * RS;
+                row = row < rows ? row : rows - 1;
+                q[k] = *reinterpret_cast<const float4*>(rb + row * len + c);
+            }
+            park();
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const int row = tid / G + k * RS;
+                if (row >= rows) break;
+                float4 w = *reinterpret_cast<const float4*>(Ot + row * OS + c);
+                w.x += q[k].x; w.y += q[k].y; w.z += q[k].z; w.w += q[k].w;
+                *reinterpret_cast<float4*>(yb + row * len + c) = w;
+                if (y2b) {
+                    const float e[4] = {w.x, w.y, w.z, w.w};
+                    if (f2 == 4) {
+                        y2b[row * len2 + ((t0 + c) >> 2)] = fmaf(0.5f, e[1], __fmul_rn(0.5f, e[2]));
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int t = t0 + c + u, qq = t / f2;
+                            if (t - qq * f2 == (f2 >> 1)) y2b[row * len2 + qq] = e[u];
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
+    park();
 #pragma unroll 2
     for (int idx = tid; idx < BM * (BN / 4); idx += NTHR) {
         const int row = idx / (BN / 4), c = (idx - row * (BN / 4)) * 4;
