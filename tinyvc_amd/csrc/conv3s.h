@@ -77,6 +77,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef S_EARLY
 #define S_EARLY 2   // which waves stage the next slab BEFORE their MFMAs (the others after): 0 none, 1 all, 2 (wave >> 2) & 1, 3 wave & 1
 #endif
+#ifndef S_TRANS
+#define S_TRANS 0   // 1: conv epilogues with the MFMA operands swapped - the accumulator tile is [sample][channel], a lane holds 4 consecutive samples of ONE channel and stores 16 bytes straight from registers (no LDS park, no barriers); measured slower than the parked full-line stores (6.99 -> 7.39 ms)
+#endif
 #ifndef S_ABL
 #define S_ABL 0   // timing ablations (wrong results): 1 no MFMA, 2 no weight loads, 4 no input loads, 8 no input split/stores, 16 no output stores, 32 no residual, 64 park only (no vector pass), 128 park + barriers only
 #endif
@@ -102,7 +105,7 @@ struct SplitTile {
     static constexpr int OS = BN + 4;                                           // row stride (floats) of the output tile parked in LDS
     static constexpr int lds_bytes(int taps) {
         const int stage = stage_u4(taps) * 16 * (DB ? 2 : 1), out = BM * OS * 4;
-        return (stage > out ? stage : out) + 3 * BM * 4 + KS_MAX * 4;      // + bias / FiLM-bias rows of this workgroup + input-channel factors
+        return (stage > out ? stage : out) + 2 * 3 * BM * 4 + KS_MAX * 4;  // + bias / FiLM-bias rows of this workgroup (two tiles' worth) + input-channel factors
     }
     static constexpr int bias_off(int taps) {                  // float offset of that area
         const int stage = stage_u4(taps) * 16 * (DB ? 2 : 1), out = BM * OS * 4;
@@ -286,7 +289,7 @@ __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restr
 
 // acc += W (.) x over all slabs of one input tensor.  Slab 0 is already in flight in `r` (first_load); `next()`
 // is called in its place behind the last slab, so the following phase or tile starts without a cold load.
-template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, bool LERP = false, bool CLAMP = false, class Next>
+template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, bool LERP = false, bool CLAMP = false, bool TRANS = false, class Next>
 __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
                                             const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next,
                                             const float* Ks = nullptr, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0, float lscale = 0.f) {
@@ -400,7 +403,8 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
                         if (!(S_ABL & 1) || q == 0)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][i][PA[q]], bf[fb][j][PB[q]], acc[i][j], 0, 0, 0);
+                            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[fb][j][PB[q]], af[fb][i][PA[q]], acc[i][j], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][i][PA[q]], bf[fb][j][PB[q]], acc[i][j], 0, 0, 0);
             if (FB == 2) __builtin_amdgcn_sched_barrier(0);
         }
         if (TL::DB) __builtin_amdgcn_sched_barrier(0);
@@ -441,7 +445,7 @@ __device__ __forceinline__ void film_first_load(SlabRegs<TL>& r, const uint4* __
     make_map<TL>(m, len, 0, t0);
     film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, 0);
 }
-template <class TL, class Next>
+template <class TL, bool TRANS = false, class Next>
 __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16 (&ash)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ F6,
                                            int MT, int mt0, int mtoff, const float* __restrict__ xb, int Cin, int len, int t0, uint4* As, uint4* Xs,
                                            Next next) {
@@ -524,8 +528,13 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
                     if (!(S_ABL & 1) || q == 0) {
-                        asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[i][PA[q]], bf[j][PB[q]], asc[i][j], 0, 0, 0);
-                        ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i][PA[q]], bf[j][PB[q]], ash[i][j], 0, 0, 0);
+                        if (TRANS) {
+                            asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB[q]], fc[i][PA[q]], asc[i][j], 0, 0, 0);
+                            ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB[q]], fh[i][PA[q]], ash[i][j], 0, 0, 0);
+                        } else {
+                            asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[i][PA[q]], bf[j][PB[q]], asc[i][j], 0, 0, 0);
+                            ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i][PA[q]], bf[j][PB[q]], ash[i][j], 0, 0, 0);
+                        }
                     }
         if (TL::DB) __builtin_amdgcn_sched_barrier(0);
         if (TL::DB && !early) stage_next();
@@ -711,9 +720,95 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     }
 }
 
+// Output tile -> HBM straight from the accumulators of a TRANS phase: register 4 g + q of a lane is sample
+// 8 g + 4 (lane >> 5) + q of channel (lane & 31), i.e. four consecutive samples per g: one 16-byte store (and one 16-byte
+// residual load) each.  Every residual tap is requested before the first store.  v holds everything but the residual.
+template <class TL, bool RES>
+__device__ __forceinline__ void tile_store_t(const f32x16 (&v)[TL::WM][TL::WN], float* __restrict__ y, const float* __restrict__ res, int b, int M, int len,
+                                             int mt0, int t0, float* __restrict__ y2 = nullptr, int f2 = 0, int rlin = 0, float rscale = 0.f) {
+    constexpr int WM = TL::WM, WN = TL::WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / TL::NWV, wn = wave - wm * TL::NWV;
+    const bool vec = (len & 3) == 0;
+    const int len2 = f2 > 0 ? len / f2 : 0;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int m = mt0 * 32 + (wm * WM + i) * 32 + l31;
+            const int tb = t0 + (wn * WN + j) * 32 + 4 * lh;          // sample of register 0; g adds 8
+            if (m >= M || tb >= len) continue;
+            float* yr = y + ((long)b * M + m) * len;
+            float rv[4][4];
+            if constexpr (RES) {
+                if (rlin > 0) {                                   // residual = F.interpolate(res_low)[t], evaluated here
+                    const float* rr = res + ((long)b * M + m) * rlin;
+                    float x0[4][4], x1[4][4], lam[4][4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            int t = tb + 8 * g + q;
+                            t = t < len ? t : len - 1;
+                            const Lerp lc = lerp_coord(t, rscale, rlin);
+                            x0[g][q] = rr[lc.i0];
+                            x1[g][q] = rr[lc.i1];
+                            lam[g][q] = lc.w1;
+                        }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rv[g][q] = fmaf(1.f - lam[g][q], x0[g][q], __fmul_rn(lam[g][q], x1[g][q]));   // = lerp_eval
+                } else {
+                    const float* rr = res + ((long)b * M + m) * len;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int t = tb + 8 * g;
+                        if (vec && t + 3 < len) {
+                            const float4 q4 = *reinterpret_cast<const float4*>(rr + t);
+                            rv[g][0] = q4.x; rv[g][1] = q4.y; rv[g][2] = q4.z; rv[g][3] = q4.w;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rv[g][q] = t + q < len ? rr[t + q] : 0.f;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int t = tb + 8 * g;
+                if (t >= len) continue;
+                float e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = RES ? v[i][j][4 * g + q] + rv[g][q] : v[i][j][4 * g + q];
+                if (vec && t + 3 < len) {
+                    *reinterpret_cast<float4*>(yr + t) = make_float4(e[0], e[1], e[2], e[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (t + q < len) yr[t + q] = e[q];
+                }
+                if (y2) {     // 1/f2-rate copy for the next Downsample block (see C3EpiBias): pick for f2 = 3 / 5, two-sample mean for f2 = 4
+                    float* y2r = y2 + ((long)b * M + m) * len2;
+                    if (f2 == 4) {
+                        if (t + 2 < len) y2r[t >> 2] = fmaf(0.5f, e[1], __fmul_rn(0.5f, e[2]));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int tt = t + q, qq = tt / f2;
+                            if (tt < len && tt - qq * f2 == (f2 >> 1)) y2r[qq] = e[q];
+                        }
+                    }
+                }
+            }
+        }
+}
+
 template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false, bool CLAMP = false>
 __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ? S_WPE_F : (TL::NW <= 8 ? S_WPE_G : S_WPE)))) void conv3s_kernel(ConvSArgs a, Epi ep) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, A_U4 = TL::a_u4(TAPS);
+    constexpr bool TRANS = S_TRANS && !Epi::kIgemm;     // accumulators as [sample][channel]: direct 16-byte stores (tile_store_t)
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s[];
     uint4* As = smem_s;
     uint4* Xs = smem_s + A_U4;
@@ -762,7 +857,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     const int fT = a.flatT;
     const unsigned fstride = (unsigned)a.xstride;
     first_load<TL, TAPS, LERP, CLAMP>(regs, a.A6, a.MT, mt0, fT ? a.x : a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0, fT, fstride, a.cmax, a.lin, a.lscale);
-    while (tile < vtiles) {
+    for (int tile_no = 0; tile < vtiles; ++tile_no) {
         const int nxt = next_valid(tile + stride);
         auto load_next_tile = [&]() __attribute__((always_inline)) {
             if (nxt < vtiles) {
@@ -775,7 +870,8 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         const float* xb = fT ? a.x : a.x + (long)b * a.xstride;
         // this tile's bias rows -> LDS: read back with ds_read (lgkmcnt), so the epilogue math never waits on vmcnt
         // while the next phase's prefetch is in flight (a global bias load would drag that whole prefetch with it)
-        float* Bs = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS);
+        // (two copies by tile parity: without the LDS park no barrier separates a fast wave's next tile from a slow wave's epilogue)
+        float* Bs = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS) + (tile_no & 1) * 3 * TL::BM;
         if constexpr (!Epi::kIgemm) {
             for (int i = threadIdx.x; i < TL::BM; i += TL::NTHR) {
                 int m = mt0 * 32 + i;
@@ -787,7 +883,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 }
             }
         }
-        float* Ks = Bs + 3 * TL::BM;
+        float* Ks = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS) + 6 * TL::BM;
         if constexpr (SCALED) {
             // first use is behind the first slab's barrier; the previous tile's last use is behind its last one
             const int b0 = fT ? t0 / fT : b;                      // flat tiles: the (at most two) utterances this tile touches
@@ -808,7 +904,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             // the cond tile on the same output tiles; (conv, scale, shift) combine in registers.
             const float* cb = a.cond + (long)b * a.Ccond * len;
             const int mtoff = a.MT;                                   // the stacked FiLM image has 2 * a.MT m-tiles: scale rows, then shift rows
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB, false, LERP>(
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB, false, LERP, false, TRANS>(
                 acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                 [&]() __attribute__((always_inline)) { film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, len, t0); }, nullptr, 0, 0u, 0, a.lin, a.lscale);
             f32x16 asc[WM][WN], ash[WM][WN];
@@ -818,21 +914,36 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) asc[i][j][r] = ash[i][j][r] = 0.f;
-            film_phase<TL>(asc, ash, regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, a.Ccond, len, t0, As, Xs, load_next_tile);
-            // out = ((h + b)(sc + b_sc)) + (sh + b_sh), + residual in the vector pass
+            film_phase<TL, TRANS>(asc, ash, regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, a.Ccond, len, t0, As, Xs, load_next_tile);
+            // out = ((h + b)(sc + b_sc)) + (sh + b_sh), + residual in the store pass
+            if constexpr (TRANS) {
+                const int l31 = lane & 31;
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rl + i * 32 + (r & 3) + 8 * (r >> 2);
+                for (int i = 0; i < WM; ++i) {
+                    const int row = (wm * WM + i) * 32 + l31;                 // a lane holds ONE channel
                     const float bm = Bs[row], bs = Bs[TL::BM + row], bh = Bs[2 * TL::BM + row];
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j][r] = __fadd_rn(__fmul_rn(acc[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[i][j][r] = __fadd_rn(__fmul_rn(acc[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
                 }
-            tile_store<TL, !(S_ABL & 32)>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
+                tile_store_t<TL, !(S_ABL & 32)>(acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
+            } else {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rl + i * 32 + (r & 3) + 8 * (r >> 2);
+                        const float bm = Bs[row], bs = Bs[TL::BM + row], bh = Bs[2 * TL::BM + row];
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j][r] = __fadd_rn(__fmul_rn(acc[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
+                    }
+                tile_store<TL, !(S_ABL & 32)>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
+            }
         } else {
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (TL::NW <= 8 ? S_FB_G : S_FB), SCALED, LERP, CLAMP>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (TL::NW <= 8 ? S_FB_G : S_FB), SCALED, LERP, CLAMP, TRANS>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                                                                                                    load_next_tile, Ks, fT, fstride, a.cmax, a.lin, a.lscale);
             if constexpr (Epi::kIgemm) {
                 // plain GEMM use (B = 1, len = all columns): the igemm epilogue functors finish the element
@@ -854,16 +965,28 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 if (tile < vtiles) coords(tile, mt0, b, t0);
                 continue;
             }
+            if constexpr (TRANS) {
+                const int l31 = lane & 31;
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i) {
+                    const float bm = Bs[(wm * WM + i) * 32 + l31];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float bm = Bs[rl + i * 32 + (r & 3) + 8 * (r >> 2)];
+                    for (int j = 0; j < WN; ++j)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) acc[i][j][r] += bm;
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += bm;
                 }
-            if constexpr (!Epi::kIgemm)
+                if (!(S_ABL & 16)) tile_store_t<TL, Epi::kRes && !(S_ABL & 32)>(acc, ep.y, ep.res, b, ep.M, len, mt0, t0, ep.y2, ep.f2);
+            } else if constexpr (!Epi::kIgemm) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float bm = Bs[rl + i * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) acc[i][j][r] += bm;
+                    }
                 if (!(S_ABL & 16)) tile_store<TL, Epi::kRes && !(S_ABL & 32)>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, ep.y2, ep.f2);
+            }
         }
         tile = nxt;
         if (tile < vtiles) coords(tile, mt0, b, t0);
@@ -985,7 +1108,7 @@ inline int gemm_s_launch_k(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     // flat column tiles unless a tile could touch more than two utterances of a SCALED launch (factors of two are staged)
     // or the element offsets would not fit 32 bits
     const long xs = xstride ? xstride : (long)Cin * len;
-    const bool flat = TVC_S_FLAT && B > 1 && xs * B < (1L << 31) && (!SCALED || len >= TL::BN);
+    const bool flat = TVC_S_FLAT && B > 1 && xs * B < (1L << 30) && (!SCALED || len >= TL::BN);
     return conv3s_launch_t<TL, 1, false, Epi, false, SCALED, false, CLAMP>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride, BPC, kscale, flat,
                                                                            cmax);
 }
