@@ -247,6 +247,46 @@ struct Packer {
         }
         fix.push_back({slot, ab.put(img)});
     }
+    // Weight blob of the split-precision downs.0 kernel (filter_up24s.hip): the 17 -> 24 k3 conv in the same 15-piece layout
+    // as a 24-channel conv (input rows 17..23 zero), then 32 bias floats.
+    void down0s(const float** slot, const std::string& name) {
+        const HostTensor* w = find(name + ".weight");
+        const HostTensor* b = find(name + ".bias");
+        if (!w || !b) return;
+        const int C = 24, CI = 17;
+        if (w->data.size() != (size_t)C * CI * 3 || b->data.size() != (size_t)C) return;
+        std::vector<float> img(15 * 256 + 32, 0.f);
+        uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
+        auto to_bf16 = [](float f) -> uint16_t {
+            uint32_t u;
+            std::memcpy(&u, &f, 4);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        auto from_bf16 = [](uint16_t h) -> float {
+            uint32_t u = (uint32_t)h << 16;
+            float f;
+            std::memcpy(&f, &u, 4);
+            return f;
+        };
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j)
+                for (int s = 0; s < 5; ++s) {
+                    const int m = lane & 31, u = 2 * s + (lane >> 5), tap = u / 3, ci = 8 * (u % 3) + j;
+                    const float v = (u < 9 && m < C && ci < CI) ? w->data[((size_t)m * CI + ci) * 3 + tap] : 0.f;
+                    uint16_t h1 = to_bf16(v);
+                    float r = v - from_bf16(h1);
+                    uint16_t h2 = to_bf16(r);
+                    float r2 = r - from_bf16(h2);
+                    uint16_t h3 = to_bf16(r2);
+                    size_t base = ((size_t)(s * 3) * 64 + lane) * 8 + j;
+                    o[base] = h1;
+                    o[base + 512] = h2;
+                    o[base + 1024] = h3;
+                }
+        for (int m = 0; m < C; ++m) img[15 * 256 + m] = b->data[m];
+        fix.push_back({slot, ab.put(img)});
+    }
     void convnext(const std::string& p, ConvNeXtW* w, int C, int dil) {
         w->C = C;
         w->dilation = dil;
@@ -455,6 +495,7 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
     pk.raw("filter_net.f0_in.weight", &ctx->flt_f_w, ch[0]);
     pk.raw("filter_net.f0_in.bias", &ctx->flt_f_b, ch[0]);
     pk.conv({"filter_net.downs.0"}, &ctx->flt_down0, kHarm + 2, 3);
+    pk.down0s(&ctx->flt_down0s, "filter_net.downs.0");
     for (int i = 1; i <= 4; ++i) {
         DownW& d = ctx->downs[i - 1];
         d.cin = ch[5 - i];

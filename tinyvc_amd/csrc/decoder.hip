@@ -282,6 +282,9 @@ static void conv_launch(hipStream_t s, const PackedW& w, const float* x, int cin
 #ifndef TVC_SPLIT
 #define TVC_SPLIT 1
 #endif
+#ifndef TVC_DOWN0_SPLIT
+#define TVC_DOWN0_SPLIT 1   // downs.0 (17 -> 24 channels at the full rate) on the split-precision path (filter_up24s.hip)
+#endif
 #ifndef TVC_UP24_SPLIT
 #define TVC_UP24_SPLIT 1   // fused ups.4 + output layer on the split-precision bf16 MFMA path (filter_up24s.hip); 0 = fp32 16x16x4 tiles (filter_up24.hip)
 #endif
@@ -304,7 +307,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
     bool xi_fused[5] = {false, false, false, false, false};
     for (int i = 1; i <= 4; ++i) {
         const DownW& d = ctx->downs[i - 1];
-        const bool producer_ok = i == 1 ? (TVC_USE_C48 != 0)                                     // downs.0 conv (16x16x4 kernel), factor 5: pick
+        const bool producer_ok = i == 1 ? (TVC_USE_C48 != 0 || TVC_DOWN0_SPLIT != 0)                                     // downs.0 conv (16x16x4 kernel), factor 5: pick
                                         : (TVC_SPLIT && ctx->downs[i - 2].cin % 16 == 0 && ctx->downs[i - 2].cout % 96 == 0 &&   // conv3s c3 of the block before
                                            len_dn[i - 1] % 4 == 0);
         if (TVC_FUSE_DECIM && producer_ok && ((d.factor == 5 && i == 1) || ((d.factor == 3 || d.factor == 4) && i > 1)) && len_dn[i - 1] % d.factor == 0) {
@@ -318,7 +321,9 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         LoadPlain ld{content, kSslDim, T, (long)kSslDim * T};
         EpiSumCond ep{x, ctx->flt_content_in.bias, nullptr, f0, nullptr, nullptr, ctx->flt_f_w, ctx->flt_f_b, ch[0], T, B * T};
         igemm_launch(s, ctx->flt_content_in.At, ctx->flt_content_in.Mpad, ctx->flt_content_in.Kpad, B * T, T, ld, ep);
-        if (TVC_USE_C48)   // downs[0]: k3 conv over cat[source (16 ch), energy (1 ch)], read from the two tensors in place
+        if (TVC_DOWN0_SPLIT && (!xi_fused[1] || L % 5 == 0))   // downs[0] on the split-precision path; its epilogue also writes Downsample 1's 1/5-rate input
+            TVC_CHECK(run_down0_split(ctx, s, ctx->flt_down0s, source, energy, skip[0], xi_fused[1] ? xi_pre[1] : nullptr, B, (int)L));
+        else if (TVC_USE_C48)   // downs[0]: k3 conv over cat[source (16 ch), energy (1 ch)], read from the two tensors in place
             conv3mt_launch<2, false>(s, ctx->flt_down0, source, B, 17, (int)L, 1,
                                      C3EpiBias<false, 5>{skip[0], ctx->flt_down0.bias, nullptr, 24, (int)L, xi_fused[1] ? xi_pre[1] : nullptr,
                                                          xi_fused[1] ? 5 : 0},

@@ -418,4 +418,119 @@ int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, co
     return launch_up24s<CB>(ctx, s, a, B);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// FilterNet.downs[0] (decoder.py:206,224,227): Conv1d(17 -> 24, k3, replicate) over cat[source (16 ch), energy (1 ch)] at
+// the full sample rate, on the same split-precision machinery: the 17 channels are three 8-channel groups (rows 17..23
+// zero), 9 (tap, group) units = 5 K16 steps, 30 MFMAs per 32 samples.  HBM-bound (reads 17 rows, writes 24 + the
+// 1/5-rate copy Downsample 1 starts from): persistent workgroups, two LDS input tiles, the input of tile i + 2 in flight in
+// registers while tile i multiplies, one barrier per tile.
+struct Down0SArgs {
+    const float* source;   // [B][16][L]
+    const float* energy;   // [B][1][L]
+    float* out;            // [B][24][L]
+    float* y2;             // optional [B][24][L / 5]: F.interpolate(out, scale_factor = 1/5) = the sample at 5 d + 2
+    const u32x4* img;      // 15 weight pieces + 32 bias floats (api.hip down0s)
+    int len, tiles_per_utt, ntiles;
+};
+
+static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void down0s_kernel(Down0SArgs a) {
+    constexpr int W = 254, XW = 256, XP = XW, NT = 512;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_d[];
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem_d);              // [2 buffers][3 parts][3 groups][XP]
+    u32x4* Wt = Xs + 2 * 9 * XP;                               // 15 pieces
+    float* Bi = reinterpret_cast<float*>(Wt + 15 * 64);        // bias [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int len = a.len;
+    for (int i = tid; i < 15 * 64 + 8; i += NT) Wt[i] = a.img[i];
+
+    // staging: thread -> (group tid >> 8 of the 16 source rows, column tid & 255); threads 0..255 also carry the energy row
+    const int g = tid >> 8, c = tid & 255;
+    float xa[8], xe = 0.f;
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+        const int b = tile / a.tiles_per_utt;
+        int p = (tile - b * a.tiles_per_utt) * W - 1 + c;
+        p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+        const float* sb = a.source + (long)b * 16 * len;
+        const unsigned o = 4u * (unsigned)(8 * g * len + p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xa[j] = ldg_so(sb + (long)j * len, o);
+        xe = ldg_so(a.energy + (long)b * len, 4u * (unsigned)p);
+    };
+    auto deposit = [&](int buf) __attribute__((always_inline)) {
+        u32x4* X = Xs + buf * 9 * XP;
+        uint4 p1, p2, p3;
+        split8(xa, p1, p2, p3);
+        X[(0 + g) * XP + c] = __builtin_bit_cast(u32x4, p1);
+        X[(3 + g) * XP + c] = __builtin_bit_cast(u32x4, p2);
+        X[(6 + g) * XP + c] = __builtin_bit_cast(u32x4, p3);
+        if (tid < 256) {                                       // group 2 = [energy, 0 x 7]
+            const float ve[8] = {xe, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            split8(ve, p1, p2, p3);
+            X[(0 + 2) * XP + c] = __builtin_bit_cast(u32x4, p1);
+            X[(3 + 2) * XP + c] = __builtin_bit_cast(u32x4, p2);
+            X[(6 + 2) * XP + c] = __builtin_bit_cast(u32x4, p3);
+        }
+    };
+
+    int tile = blockIdx.x, cur = 0;
+    if (tile >= a.ntiles) return;
+    fetch(tile);
+    deposit(0);
+    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+    slab_barrier();
+    const int len2 = len / 5;
+    for (; tile < a.ntiles; tile += gridDim.x, cur ^= 1) {
+        const int b = tile / a.tiles_per_utt;
+        const int t0 = (tile - b * a.tiles_per_utt) * W;
+        const int next = tile + gridDim.x, next2 = next + gridDim.x;
+        if (next < a.ntiles) deposit(cur ^ 1);            // tile i + 1 (requested one tile ago) -> the other buffer
+        if (next2 < a.ntiles) fetch(next2);               // tile i + 2 flies across this tile
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int n = wave * 32 + l31;
+        conv24_phase<XP, 1>(acc, Xs + cur * 9 * XP, Wt, n, 0, XW - 1, lane);
+        const int t = t0 + n;
+        if (n < W && t < len) {
+            float* ob = a.out + (long)b * 24 * len;
+            const unsigned oo = 4u * (unsigned)(4 * lh * len + t);
+            const int q5 = t / 5;
+            const bool pick = a.y2 != nullptr && t - 5 * q5 == 2;
+#pragma unroll
+            for (int gg = 0; gg < 3; ++gg) {
+                const f32x4s bv = *reinterpret_cast<const f32x4s*>(Bi + 8 * gg + 4 * lh);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = acc[4 * gg + q] + bv[q];
+                    stg_so(ob + (long)(8 * gg + q) * len, oo, v);
+                    if (pick) a.y2[((long)b * 24 + 8 * gg + 4 * lh + q) * len2 + q5] = v;
+                }
+            }
+        }
+        slab_barrier();
+    }
+}
+
+int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len) {
+    if (!blob) return fail(ctx, TVC_ERR_STATE, "down0s: the split weight blob of downs.0 is missing");
+    if ((long)len * 24 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "down0s: utterance too long for 32-bit byte offsets");
+    if (y2 && len % 5 != 0) return fail(ctx, TVC_ERR_ARG, "down0s: the 1/5-rate copy needs len % 5 == 0");
+    static int ncu_dev[64] = {};
+    int& ncu = ncu_dev[ctx->device & 63];
+    constexpr size_t lds = (2 * 9 * 256 + 15 * 64 + 8) * 16;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)down0s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "down0s setup: %s", hipGetErrorString(e));
+        ncu = prop.multiProcessorCount;
+    }
+    Down0SArgs a{source, energy, out, y2, reinterpret_cast<const u32x4*>(blob), len, (len + 253) / 254, 0};
+    a.ntiles = a.tiles_per_utt * B;
+    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    hipLaunchKernelGGL(down0s_kernel, dim3(grid), dim3(512), lds, s, a);
+    return launch_check(ctx, "down0s");
+}
+
 }  // namespace tvc

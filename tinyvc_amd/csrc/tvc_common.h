@@ -109,6 +109,7 @@ struct tvc_ctx {
     const float* src_f_b = nullptr;
     // filter net
     tvc::PackedW flt_content_in, flt_down0, flt_out;
+    const float* flt_down0s = nullptr;   // downs.0 weight blob of the split-precision kernel (filter_up24s.hip)
     const float* flt_out_w = nullptr;  // output_layer weight, raw [1][24][7]
     const float* flt_out_b = nullptr;
     const float* flt_f_w = nullptr;
@@ -221,6 +222,7 @@ int run_prepare_index(tvc_ctx*, hipStream_t, const float* index, float* prepared
 int run_up24_fused(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len,
                    const float* w7, const float* b7);
 int run_up24_split(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len);
+int run_down0_split(tvc_ctx*, hipStream_t, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len);
 int run_down0(tvc_ctx*, hipStream_t, const PackedW& w, const float* source, const float* energy, float* out, int B, int len);
 int run_out_conv7(tvc_ctx*, hipStream_t, const float* x, const float* w_raw, const float* bias, float* y, int B, int C, int len);
 
