@@ -287,6 +287,47 @@ struct Packer {
         for (int m = 0; m < C; ++m) img[15 * 256 + m] = b->data[m];
         fix.push_back({slot, ab.put(img)});
     }
+    // Weight blob of one 24-input-channel k3 conv for conv24s_kernel (filter_up24s.hip): pieces [step][m-tile][part]
+    // (same (tap, group) K order as up24s_half), then 64 bias floats.  M = 24 (one m-tile) or 48 (two).
+    void conv24s(const float** slot, const std::string& name, int M) {
+        const HostTensor* w = find(name + ".weight");
+        const HostTensor* b = find(name + ".bias");
+        if (!w || !b) return;
+        const int CI = 24, MT = (M + 31) / 32;
+        if (w->data.size() != (size_t)M * CI * 3 || b->data.size() != (size_t)M) return;
+        std::vector<float> img((size_t)15 * MT * 256 + 64, 0.f);
+        uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
+        auto to_bf16 = [](float f) -> uint16_t {
+            uint32_t u;
+            std::memcpy(&u, &f, 4);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        auto from_bf16 = [](uint16_t h) -> float {
+            uint32_t u = (uint32_t)h << 16;
+            float f;
+            std::memcpy(&f, &u, 4);
+            return f;
+        };
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j)
+                for (int s = 0; s < 5; ++s)
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int m = 32 * mt + (lane & 31), u = 2 * s + (lane >> 5), tap = u / 3, ci = 8 * (u % 3) + j;
+                        const float v = (u < 9 && m < M) ? w->data[((size_t)m * CI + ci) * 3 + tap] : 0.f;
+                        uint16_t h1 = to_bf16(v);
+                        float r = v - from_bf16(h1);
+                        uint16_t h2 = to_bf16(r);
+                        float r2 = r - from_bf16(h2);
+                        uint16_t h3 = to_bf16(r2);
+                        size_t base = ((size_t)((s * MT + mt) * 3) * 64 + lane) * 8 + j;
+                        o[base] = h1;
+                        o[base + 512] = h2;
+                        o[base + 1024] = h3;
+                    }
+        for (int m = 0; m < M; ++m) img[(size_t)15 * MT * 256 + m] = b->data[m];
+        fix.push_back({slot, ab.put(img)});
+    }
     void convnext(const std::string& p, ConvNeXtW* w, int C, int dil) {
         w->C = C;
         w->dilation = dil;
@@ -506,6 +547,11 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
         pk.conv({p + ".c1"}, &d.c1, d.cin, 3);
         pk.conv({p + ".c2"}, &d.c2, d.cin, 3);
         pk.conv({p + ".c3"}, &d.c3, d.cin, 3);
+        if (d.cin == 24 && d.cout == 48) {
+            pk.conv24s(&d.s24c1, p + ".c1", 24);
+            pk.conv24s(&d.s24c2, p + ".c2", 24);
+            pk.conv24s(&d.s24c3, p + ".c3", 48);
+        }
     }
     for (int i = 0; i < 5; ++i) {
         UpW& u = ctx->ups[i];

@@ -282,6 +282,9 @@ static void conv_launch(hipStream_t s, const PackedW& w, const float* x, int cin
 #ifndef TVC_SPLIT
 #define TVC_SPLIT 1
 #endif
+#ifndef TVC_DOWN24_SPLIT
+#define TVC_DOWN24_SPLIT 1   // Downsample 1 (24 -> 48 channels at 1/5 rate): c1, c2, c3 on the split-precision path (conv24s_kernel)
+#endif
 #ifndef TVC_DOWN0_SPLIT
 #define TVC_DOWN0_SPLIT 1   // downs.0 (17 -> 24 channels at the full rate) on the split-precision path (filter_up24s.hip)
 #endif
@@ -308,7 +311,8 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
     for (int i = 1; i <= 4; ++i) {
         const DownW& d = ctx->downs[i - 1];
         const bool producer_ok = i == 1 ? (TVC_USE_C48 != 0 || TVC_DOWN0_SPLIT != 0)                                     // downs.0 conv (16x16x4 kernel), factor 5: pick
-                                        : (TVC_SPLIT && ctx->downs[i - 2].cin % 16 == 0 && ctx->downs[i - 2].cout % 96 == 0 &&   // conv3s c3 of the block before
+                                        : (((TVC_SPLIT && ctx->downs[i - 2].cin % 16 == 0 && ctx->downs[i - 2].cout % 96 == 0) ||   // conv3s c3 of the block before
+                                            (TVC_DOWN24_SPLIT && ctx->downs[i - 2].cin == 24 && ctx->downs[i - 2].cout == 48 && d.factor == 4)) &&   // conv24s c3
                                            len_dn[i - 1] % 4 == 0);
         if (TVC_FUSE_DECIM && producer_ok && ((d.factor == 5 && i == 1) || ((d.factor == 3 || d.factor == 4) && i > 1)) && len_dn[i - 1] % d.factor == 0) {
             xi_pre[i] = ws.get<float>((size_t)B * d.cin * len_dn[i]);
@@ -358,7 +362,10 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                     igemm_launch(s, d.res.At, d.res.Mpad, d.res.Kpad, nc, len, ld, ep);
                 }
             }
-            if (d.cin == 24 && TVC_USE_C48) {   // 24 output channels = two 16-row tiles, many small waves
+            const bool d24s = TVC_DOWN24_SPLIT && d.cin == 24 && d.cout == 48;
+            if (d24s) {   // the whole 24-channel block on the split-precision path; c3's epilogue adds res and writes the next block's 1/4-rate input
+                TVC_CHECK(run_down24_split(ctx, s, d, xi, res, h1, h2, skip[i], (i < 4 && xi_fused[i + 1]) ? xi_pre[i + 1] : nullptr, B, len));
+            } else if (d.cin == 24 && TVC_USE_C48) {   // 24 output channels = two 16-row tiles, many small waves
                 conv3mt_launch<2, true>(s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
                 conv3mt_launch<2, true>(s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
             } else if (d.cin == 48 && TVC_SPLIT48) {
@@ -374,7 +381,8 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 conv3_launch<true>(s, d.c1.At, d.c1.Mpad, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
                 conv3_launch<true>(s, d.c2.At, d.c2.Mpad, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
             }
-            if (d.cout == 48 && d.cin % 16 == 0 && TVC_SPLIT48 >= 2)
+            if (d24s) {
+            } else if (d.cout == 48 && d.cin % 16 == 0 && TVC_SPLIT48 >= 2)
                 TVC_CHECK(conv3s_launch<true>(ctx, s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len}));
             else if (d.cout == 48 && TVC_USE_C48)
                 conv3m48_launch<true>(s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});

@@ -213,7 +213,6 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     for (; tile < a.ntiles; tile += gridDim.x) {
         const int b = tile / a.tiles_per_utt;
         const int t0 = (tile - b * a.tiles_per_utt) * W;
-        const int px0 = t0 - E - H;       // position of Xs column 0
         const int ph0 = t0 - E - D2;      // position of Hs column 0
         const int p20 = t0 - E;           // position of second-conv column 0
         const int next = tile + gridDim.x;
@@ -531,6 +530,206 @@ int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float*
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     hipLaunchKernelGGL(down0s_kernel, dim3(grid), dim3(512), lds, s, a);
     return launch_check(ctx, "down0s");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One 24-input-channel k3 conv (Downsample 1's c1 / c2 / c3, decoder.py:143-158) on the same machinery: 24 -> 24 (one
+// m-tile) or 24 -> 48 (two), optional leaky_relu on the input, optional residual, optional 1/4-rate copy for the next
+// Downsample block (mean of samples 4 d + 1 and 4 d + 2, see C3EpiBias).  Persistent, double-buffered input tiles.
+template <int MT_, int DIL_, bool LRELU_, bool RES_>
+struct C24S {
+    static constexpr int MT = MT_, DIL = DIL_;
+    static constexpr bool LRELU = LRELU_, RES = RES_;
+    static constexpr int XW = 256, XP = XW, W = (XW - 2 * DIL) / 4 * 4, NT = 512;
+    static constexpr int PIECES = 15 * MT, FL = 64;
+    static constexpr int LDS_BYTES = (2 * 9 * XP + PIECES * 64) * 16 + FL * 4;
+    static_assert(W % 4 == 0, "the 1/4-rate copy pairs samples inside a tile");
+};
+struct Conv24SArgs {
+    const float* x;        // [B][24][len]
+    const float* res;      // [B][M][len] (RES)
+    float* out;            // [B][M][len]
+    float* y2;             // optional [B][M][len / 4]
+    const u32x4* img;      // 15 * MT weight pieces [step][m-tile][part], then 64 bias floats
+    int M, len, tiles_per_utt, ntiles;
+};
+
+template <class CF>
+__global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) void conv24s_kernel(Conv24SArgs a) {
+    constexpr int W = CF::W, XW = CF::XW, XP = CF::XP, NT = CF::NT, MT = CF::MT, DIL = CF::DIL;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_c[];
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem_c);              // [2 buffers][3 parts][3 groups][XP]
+    u32x4* Wt = Xs + 2 * 9 * XP;
+    float* Bi = reinterpret_cast<float*>(Wt + CF::PIECES * 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int len = a.len, M = a.M;
+    for (int i = tid; i < CF::PIECES * 64 + CF::FL / 4; i += NT) Wt[i] = a.img[i];
+
+    // staging items (group, column): 768 of them, thread -> item tid and (tid < 256) item tid + 512
+    float xa[2][8];
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+        const int b = tile / a.tiles_per_utt;
+        const int px0 = (tile - b * a.tiles_per_utt) * W - DIL;
+        const float* xb = a.x + (long)b * 24 * len;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * NT;
+            const int g = (idx >> 8) > 2 ? 2 : (idx >> 8), c = idx & 255;     // idle items load a valid address
+            int p = px0 + c;
+            p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+            const unsigned o = 4u * (unsigned)(8 * g * len + p);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xa[i][j] = ldg_so(xb + (long)j * len, o);
+        }
+    };
+    auto deposit = [&](int buf) __attribute__((always_inline)) {
+        u32x4* X = Xs + buf * 9 * XP;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * NT;
+            if (idx >= 768) continue;
+            const int g = idx >> 8, c = idx & 255;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = CF::LRELU ? fmaxf(xa[i][j], 0.1f * xa[i][j]) : xa[i][j];
+            uint4 p1, p2, p3;
+            split8(v, p1, p2, p3);
+            X[(0 + g) * XP + c] = __builtin_bit_cast(u32x4, p1);
+            X[(3 + g) * XP + c] = __builtin_bit_cast(u32x4, p2);
+            X[(6 + g) * XP + c] = __builtin_bit_cast(u32x4, p3);
+        }
+    };
+
+    int tile = blockIdx.x, cur = 0;
+    if (tile >= a.ntiles) return;
+    fetch(tile);
+    deposit(0);
+    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+    slab_barrier();
+    const int len2 = len >> 2;
+    for (; tile < a.ntiles; tile += gridDim.x, cur ^= 1) {
+        const int b = tile / a.tiles_per_utt;
+        const int t0 = (tile - b * a.tiles_per_utt) * W;
+        const int next = tile + gridDim.x, next2 = next + gridDim.x;
+        if (next < a.ntiles) deposit(cur ^ 1);            // tile i + 1 (requested one tile ago) -> the other buffer
+        if (next2 < a.ntiles) fetch(next2);               // tile i + 2 flies across this tile
+        const int n = wave * 32 + l31;
+        const int t = t0 + n;
+        const bool live = n < W && t < len;
+        const unsigned oo = 4u * (unsigned)(4 * lh * len + (t < len ? t : len - 1));
+        // residual rows of this lane, requested before the multiply
+        float rv[MT][4][4];
+        if (CF::RES) {
+            const float* rb = a.res + (long)b * M * len;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        int m = 32 * mt + 8 * g + q;                     // row of lane half 0; half 1 is 4 further (in oo)
+                        m = m + 4 < M ? m : M - 5;                       // rows past M are never stored: any valid address
+                        rv[mt][g][q] = ldg_so(rb + (long)m * len, oo);
+                    }
+        }
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        {   // 9 (tap, group) units in 5 K16 steps (conv24_phase), MT m-tiles sharing every B fragment
+            const u32x4* src = Xs + cur * 9 * XP;
+            constexpr int TAP0[5] = {0, 0, 1, 2, 2}, GRP0[5] = {0, 2, 1, 0, 2};
+            constexpr int TAP1[5] = {0, 1, 1, 2, 2}, GRP1[5] = {1, 0, 2, 1, 2};
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+            bf16x8 af[2][MT][3], bf[2][3];
+            auto frags = [&](int s, int fb) __attribute__((always_inline)) {
+                int c = n + (lh ? TAP1[s] : TAP0[s]) * DIL;
+                c = c > XW - 1 ? XW - 1 : c;
+                const int row = (lh ? GRP1[s] : GRP0[s]) * XP + c;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    bf[fb][p] = __builtin_bit_cast(bf16x8, src[p * 3 * XP + row]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) af[fb][mt][p] = __builtin_bit_cast(bf16x8, Wt[((s * MT + mt) * 3 + p) * 64 + lane]);
+                }
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const int fb = s & 1;
+                if (s + 1 < 5) frags(s + 1, fb ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][mt][PA[q]], bf[fb][PB[q]], acc[mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {
+            float* ob = a.out + (long)b * M * len;
+            const bool pair = a.y2 != nullptr && (t & 3) == 1 && t + 1 < len;      // 1/4-rate copy: mean of samples 4 d + 1, 4 d + 2
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (32 * mt + 8 * g >= M) continue;                            // uniform
+                    const f32x4s bv = *reinterpret_cast<const f32x4s*>(Bi + 32 * mt + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v = acc[mt][4 * g + q] + bv[q];
+                        if (CF::RES) v += rv[mt][g][q];
+                        const float vn = __shfl_down(v, 1);                        // sample t + 1 (same tile: W % 4 == 0)
+                        const int m = 32 * mt + 8 * g + 4 * lh + q;
+                        if (live && m < M) {
+                            stg_so(ob + (long)(32 * mt + 8 * g + q) * len, oo, v);
+                            if (pair) a.y2[((long)b * M + m) * len2 + (t >> 2)] = fmaf(0.5f, v, __fmul_rn(0.5f, vn));
+                        }
+                    }
+                }
+        }
+        slab_barrier();
+    }
+}
+
+template <class CF>
+static int launch_conv24s(tvc_ctx* ctx, hipStream_t s, Conv24SArgs a, int B) {
+    static int ncu_dev[64] = {};
+    int& ncu = ncu_dev[ctx->device & 63];
+    const size_t lds = (size_t)CF::LDS_BYTES;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv24s_kernel<CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv24s setup: %s", hipGetErrorString(e));
+        ncu = prop.multiProcessorCount;
+    }
+    a.tiles_per_utt = (a.len + CF::W - 1) / CF::W;
+    a.ntiles = a.tiles_per_utt * B;
+    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    hipLaunchKernelGGL((conv24s_kernel<CF>), dim3(grid), dim3(CF::NT), lds, s, a);
+    return launch_check(ctx, "conv24s");
+}
+
+// Downsample block with 24 input channels (decoder.py:143-158) after its interpolate and down_res:
+// xi [B][24][len] -> h1 -> h2 -> out [B][48][len] (+ res), and optionally the next block's 1/4-rate input.
+int run_down24_split(tvc_ctx* ctx, hipStream_t s, const DownW& d, const float* xi, const float* res, float* h1, float* h2, float* out, float* y2, int B,
+                     int len) {
+    if (!d.s24c1 || !d.s24c2 || !d.s24c3) return fail(ctx, TVC_ERR_STATE, "conv24s: the split weight blobs of the 24-channel Downsample block are missing");
+    if (d.cin != 24 || d.cout != 48) return fail(ctx, TVC_ERR_ARG, "conv24s: 24 -> 48 channels only");
+    if ((long)len * 48 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "conv24s: utterance too long for 32-bit byte offsets");
+    if (y2 && len % 4 != 0) return fail(ctx, TVC_ERR_ARG, "conv24s: the 1/4-rate copy needs len % 4 == 0");
+    Conv24SArgs a{};
+    a.len = len;
+    a.x = xi; a.out = h1; a.M = 24; a.img = reinterpret_cast<const u32x4*>(d.s24c1);
+    TVC_CHECK((launch_conv24s<C24S<1, 1, true, false>>(ctx, s, a, B)));
+    a.x = h1; a.out = h2; a.img = reinterpret_cast<const u32x4*>(d.s24c2);
+    TVC_CHECK((launch_conv24s<C24S<1, 2, true, false>>(ctx, s, a, B)));
+    a.x = h2; a.out = out; a.res = res; a.y2 = y2; a.M = 48; a.img = reinterpret_cast<const u32x4*>(d.s24c3);
+    return launch_conv24s<C24S<2, 4, true, true>>(ctx, s, a, B);
 }
 
 }  // namespace tvc

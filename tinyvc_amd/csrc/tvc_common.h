@@ -50,6 +50,9 @@ struct ConvNeXtW {
 
 struct DownW {
     PackedW res, c1, c2, c3;
+    const float* s24c1 = nullptr;   // cin == 24: weight blobs of conv24s_kernel (filter_up24s.hip)
+    const float* s24c2 = nullptr;
+    const float* s24c3 = nullptr;
     int cin = 0, cout = 0, factor = 1;
 };
 struct UpW {
@@ -223,6 +226,7 @@ int run_up24_fused(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const fl
                    const float* w7, const float* b7);
 int run_up24_split(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len);
 int run_down0_split(tvc_ctx*, hipStream_t, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len);
+int run_down24_split(tvc_ctx*, hipStream_t, const DownW& d, const float* xi, const float* res, float* h1, float* h2, float* out, float* y2, int B, int len);
 int run_down0(tvc_ctx*, hipStream_t, const PackedW& w, const float* source, const float* energy, float* out, int B, int len);
 int run_out_conv7(tvc_ctx*, hipStream_t, const float* x, const float* w_raw, const float* bias, float* y, int B, int C, int len);
 
