@@ -160,7 +160,7 @@ def main():
                        "parallelism": f"utterance-dp{world}", "x_realtime": audio_s / dt},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": measured_filter_traffic(B, L),
-                         "kernel": "FilterNet Conv1d stack = the filter_net launches of one step (fused ups.4+output kernels, split-precision conv3s for the 48..384-channel levels, fp32 16x16x4 tiles for the 24-channel ones), hipEvent pair on the launch stream",
+                         "kernel": "FilterNet Conv1d stack = the filter_net launches of one step (split-precision bf16x3 MFMA everywhere: fused ups.4+output kernels, conv3s for the 48..384-channel levels, conv24s / down0s for the 24-channel ones), hipEvent pair on the launch stream",
                          "algorithmic_bytes_per_launch": FILTER_BYTES_PER_SAMPLE * B * L,
                          "launch_ms": t_filter * 1e3,
                          "fp32_mfma_tflops": FILTER_FLOPS_PER_SAMPLE * B * L / t_filter / 1e12 if t_filter > 0 else None,

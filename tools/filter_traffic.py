@@ -6,7 +6,7 @@ bench.py reads for `roofline.traffic`.
     python tools/filter_traffic.py FETCH.db WRITE.db profiles/rNN_filter_traffic_pmc.json
 
 FilterNet's launches of a step are the dispatches from the content/f0 input contraction
-(igemm ... EpiSumCond) through the second fused ups.4 kernel (up24_kernel<... true ...>).
+(igemm ... EpiSumCond) through the second fused ups.4 kernel (up24s_kernel<U24S<..., true, ...>> / up24_kernel<Up24Cfg<..., true, ...>>).
 FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 B);
 the doubling is re-checked here on the fused ups.4 first-half kernel, whose byte counts are known.
 """
@@ -25,13 +25,22 @@ def per_dispatch(db, counter):
     return [agg[k] for k in sorted(agg)]
 
 
+def is_up24(name, second):
+    """the fused ups.4 kernels: up24_kernel<Up24Cfg<W, D1, D2, SECOND, ...>> (fp32) or up24s_kernel<U24S<W, D1, D2, SECOND, E>> (split)."""
+    for tag in ("Up24Cfg", "U24S"):
+        if tag in name:
+            args = name.split(tag)[-1]
+            return ("true" in args) == second
+    return False
+
+
 def filter_segments(disp):
     """[(first, last)] index ranges of FilterNet launches, one per step."""
     segs, start = [], None
     for i, (name, _, _) in enumerate(disp):
         if "EpiSumCond" in name:
             start = i                                   # the last one before the fused ups.4 kernels is FilterNet's input layer
-        if start is not None and "up24_kernel" in name and "true" in name.split("Up24Cfg")[-1]:
+        if start is not None and is_up24(name, second=True):
             segs.append((start, i))
             start = None
     return segs
@@ -48,8 +57,8 @@ def main(fetch_db, write_db, out):
     fetch_kb = sum(v for _, v, _ in f[fa:fb + 1])
     write_kb = sum(v for _, v, _ in w[wa:wb + 1])
     ms = sum(d for _, _, d in f[fa:fb + 1]) / 1e6
-    halfA = [x for x in f[fa:fb + 1] if "up24_kernel" in x[0] and "false" in x[0].split("Up24Cfg")[-1]]
-    halfAw = [x for x in w[wa:wb + 1] if "up24_kernel" in x[0] and "false" in x[0].split("Up24Cfg")[-1]]
+    halfA = [x for x in f[fa:fb + 1] if is_up24(x[0], second=False)]
+    halfAw = [x for x in w[wa:wb + 1] if is_up24(x[0], second=False)]
     res = {
         "note": "FilterNet launches of one bench step (64 x 4 s, default bench.py workload): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                 "separate passes (with --kernel-trace only), summed by tools/filter_traffic.py. FETCH_SIZE is doubled as "
