@@ -80,6 +80,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef S_TRANS
 #define S_TRANS 0   // 1: conv epilogues with the MFMA operands swapped - the accumulator tile is [sample][channel], a lane holds 4 consecutive samples of ONE channel and stores 16 bytes straight from registers (no LDS park, no barriers); measured slower than the parked full-line stores (6.99 -> 7.39 ms)
 #endif
+#ifndef S_PF
+#define S_PF 2   // residual rows requested at a time by the lerp epilogue
+#endif
 #ifndef S_ABL
 #define S_ABL 0   // timing ablations (wrong results): 1 no MFMA, 2 no weight loads, 4 no input loads, 8 no input split/stores, 16 no output stores, 32 no residual, 64 park only (no vector pass), 128 park + barriers only
 #endif
@@ -548,7 +551,12 @@ template <class TL, bool RES>
 __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][TL::WN], float* __restrict__ y, const float* __restrict__ res,
                                            int b, int M, int len, int mt0, int t0, float* __restrict__ y2 = nullptr, int f2 = 0, int rlin = 0, float rscale = 0.f) {
     constexpr int WM = TL::WM, WN = TL::WN, BM = TL::BM, BN = TL::BN, OS = TL::OS, NTHR = TL::NTHR;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The thread index is laundered through an empty asm: everything below depends on it only, so the compiler would hoist
+    // all of the store pass's index math (64-bit offsets included) out of the persistent tile loop and keep ~25 registers
+    // live across the MFMA phases - enough to push the FiLM kernels into scratch.  Recomputing it per tile is free.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / TL::NWV, wn = wave - wm * TL::NWV;
     auto park = [&]() __attribute__((always_inline)) {
@@ -562,6 +570,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
                     Ot[((wm * WM + i) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)) * OS + (wn * WN + j) * 32 + l31] = v[i][j][r];
         slab_barrier();
     };
+    __builtin_amdgcn_sched_barrier(0);                         // nothing of the store pass moves up into the FiLM combine (three accumulator sets live there)
     float* yb = y + ((long)b * M + mt0 * 32) * len + t0;      // offsets inside the tile's rows fit 32 bits
     // rlin > 0: the residual is F.interpolate(res_low) of a [B][M][rlin] tensor, evaluated here instead of read back
     if (S_ABL & 128) return;
@@ -590,38 +599,49 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
             const bool full = vec && t0 + c + 3 < len;
             // the residual taps of every row this thread will store are requested before the tile is parked: their latency
             // runs under the two barriers and the LDS round trip instead of in front of every store
-            constexpr int NR = (BM + RS - 1) / RS;
-            float x0[NR][4], x1[NR][4];
+            // (two rows at a time: all four at once pushed the FiLM kernels into scratch)
+            constexpr int NR = (BM + RS - 1) / RS, PF = S_PF;
+            float x0[PF][4], x1[PF][4];
             const bool live = t0 + c < len;
+            auto request = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                int row = tid / G + k * RS;
-                row = row < rows ? row : rows - 1;
-                const float* rr = rb + (long)row * rlin;
+                for (int k = 0; k < PF; ++k) {
+                    int row = tid / G + (k0 + k) * RS;
+                    row = row < rows ? row : rows - 1;
+                    const unsigned ro = 4u * (unsigned)(row * rlin);          // uniform tile base + 32-bit byte offsets (rows of one tile are < 2^30 B apart)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    x0[k][u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rr) + o0[u]);
-                    x1[k][u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rr) + o1[u]);
+                    for (int u = 0; u < 4; ++u) {
+                        x0[k][u] = ldg_so(rb, ro + o0[u]);
+                        x1[k][u] = ldg_so(rb, ro + o1[u]);
+                    }
                 }
-            }
+            };
+            __builtin_amdgcn_sched_barrier(0);     // the requests stay below the FiLM combine: hoisted above it they overlap the three live accumulator sets
+            request(0);
             park();
             if (!live) return;
 #pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                const int row = tid / G + k * RS;
-                if (row >= rows) break;
-                const float4 o = *reinterpret_cast<const float4*>(Ot + row * OS + c);
-                const float e[4] = {o.x, o.y, o.z, o.w};
-                float w[4];
+            for (int k0 = 0; k0 < NR; k0 += PF) {
+                float w[PF][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) w[u] = e[u] + fmaf(1.f - lam[u], x0[k][u], __fmul_rn(lam[u], x1[k][u]));          // = e + lerp_eval
-                const int off = row * len + c;
-                if (full) {
-                    *reinterpret_cast<float4*>(yb + off) = make_float4(w[0], w[1], w[2], w[3]);
-                } else {
+                for (int k = 0; k < PF; ++k)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (t0 + c + u < len) yb[off + u] = w[u];
+                    for (int u = 0; u < 4; ++u) w[k][u] = fmaf(1.f - lam[u], x0[k][u], __fmul_rn(lam[u], x1[k][u]));          // = lerp_eval
+                if (k0 + PF < NR) request(k0 + PF);                  // next rows fly while these are stored
+#pragma unroll
+                for (int k = 0; k < PF; ++k) {
+                    const int row = tid / G + (k0 + k) * RS;
+                    if (row >= rows) break;
+                    const float4 o = *reinterpret_cast<const float4*>(Ot + row * OS + c);
+                    const float e[4] = {o.x + w[k][0], o.y + w[k][1], o.z + w[k][2], o.w + w[k][3]};
+                    const int off = row * len + c;
+                    if (full) {
+                        *reinterpret_cast<float4*>(yb + off) = make_float4(e[0], e[1], e[2], e[3]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (t0 + c + u < len) yb[off + u] = e[u];
+                    }
                 }
             }
             return;
@@ -631,6 +651,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
             constexpr int G = BN / 4, RS = NTHR / G, NR = (BM + RS - 1) / RS;
             const int c = (tid % G) * 4;
             float4 q[NR];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
                 int row = tid / G + k * RS;
@@ -1054,10 +1075,16 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
 }
 
 #ifndef TVC_S_WN
-#define TVC_S_WN 1
+#define TVC_S_WN 2   // plain convs of the 96..384-channel levels: a wave owns two 32-sample n-tiles (96 x 256 workgroup tile); every weight fragment and every slab's staging round trip serves twice the columns (6.73 -> 6.56 ms)
 #endif
 #ifndef TVC_S48_NWV   // waves (= 32-sample n-tiles) per m-tile of the 48-channel workgroups
 #define TVC_S48_NWV 6
+#endif
+#ifndef TVC_S48_WN    // 32-sample n-tiles per wave of the 48-channel workgroups
+#define TVC_S48_WN 1
+#endif
+#ifndef TVC_S48F_WN
+#define TVC_S48F_WN 1
 #endif
 #ifndef TVC_S48F_NWV
 #define TVC_S48F_NWV 6
@@ -1085,10 +1112,10 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
                          float lscale = 0.f) {
     if (w.MT6 == 2) {   // 48 output channels: two m-tiles, the second half empty (still 1.4x fewer MFMA cycles than exact fp32 tiles)
         if constexpr (FILM)
-            return conv3s_launch_t<SplitTile<2, 1, TVC_S48F_NWV, 1>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC,
+            return conv3s_launch_t<SplitTile<2, 1, TVC_S48F_NWV, TVC_S48F_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC,
                                                                                                       nullptr, false, 0, lin, lscale);
         else
-            return conv3s_launch_t<SplitTile<2, 1, TVC_S48_NWV, 1>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC,
+            return conv3s_launch_t<SplitTile<2, 1, TVC_S48_NWV, TVC_S48_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC,
                                                                                                      nullptr, false, 0, lin, lscale);
     }
     if constexpr (FILM)
