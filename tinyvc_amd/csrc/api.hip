@@ -373,6 +373,21 @@ void build_dft_tables(Packer& pk, tvc_ctx* ctx) {
         pk.fix.push_back({&pw.bias, pk.ab.put(bias)});
         pk.a6(&pw, At);
     };
+    {   // FFT tables (fft.hip)
+        std::vector<float> t960(2 * 960), t1920(2 * 961 + 2), hann(N);
+        for (int j = 0; j < 960; ++j) {
+            t960[2 * j] = (float)std::cos(two_pi * j / 960.0);
+            t960[2 * j + 1] = (float)std::sin(two_pi * j / 960.0);
+        }
+        for (int k = 0; k <= 960; ++k) {
+            t1920[2 * k] = (float)std::cos(two_pi * k / 1920.0);
+            t1920[2 * k + 1] = (float)std::sin(two_pi * k / 1920.0);
+        }
+        for (int n = 0; n < N; ++n) hann[n] = (float)(0.5 - 0.5 * std::cos(two_pi * n / N));
+        pk.fix.push_back({&ctx->fft_tw960, pk.ab.put(t960)});
+        pk.fix.push_back({&ctx->fft_tw1920, pk.ab.put(t1920)});
+        pk.fix.push_back({&ctx->fft_hann, pk.ab.put(hann)});
+    }
     auto ang = [&](long f, long n) { return two_pi * (double)((f * n) % N) / N; };
     {   // forward real part: rows k = n-1 (n = 1..960), columns f = 0..960
         PackedW& pw = ctx->stft_re;

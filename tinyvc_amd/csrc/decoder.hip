@@ -7,6 +7,10 @@
 #include "small_kernels.h"
 #include "tvc_common.h"
 
+#ifndef TVC_FFT
+#define TVC_FFT 1   // filtered-noise iSTFT as wave-level FFTs (fft.hip); 0 = real-DFT GEMMs
+#endif
+
 namespace tvc {
 
 #ifndef TVC_FUSE_LERP
@@ -245,6 +249,9 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
         hipLaunchKernelGGL(angle_fill_kernel, dim3(grid_for((long)B * kBins * T)), dim3(256), 0, s, ang, (long)B * kBins * T, seed);
         angle = ang;
     }
+    if (TVC_FFT) {
+        TVC_CHECK(run_noise_ifft(ctx, s, kern, angle, frames, B, T));
+    } else {
     hipLaunchKernelGGL(noise_spec_kernel, dim3(grid_for((long)B * kBins * T)), dim3(256), 0, s, kern, angle, yri, (long)kBins * T, B);
     {   // even part from the real halves (rows 0..960 of yri), then odd part from the imaginary halves of bins 1..959
 #if TVC_SPLIT_IDFT
@@ -261,6 +268,7 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
         EpiFramesPart<true> eo{frames, ncols};
         igemm_launch(s, ctx->istft_o.At, ctx->istft_o.Mpad, ctx->istft_o.Kpad, ncols, T, lo, eo);
 #endif
+    }
     }
     hipLaunchKernelGGL(noise_ola_kernel, dim3(grid_for((long)B * L)), dim3(256), 0, s, frames, source, B, T);
     if (fork) TVC_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
@@ -282,6 +290,7 @@ static void conv_launch(hipStream_t s, const PackedW& w, const float* x, int cin
 #ifndef TVC_SPLIT
 #define TVC_SPLIT 1
 #endif
+
 #ifndef TVC_DOWN24_SPLIT
 #define TVC_DOWN24_SPLIT 1   // Downsample 1 (24 -> 48 channels at 1/5 rate): c1, c2, c3 on the split-precision path (conv24s_kernel)
 #endif

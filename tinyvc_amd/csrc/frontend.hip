@@ -12,6 +12,9 @@ namespace tvc {
 #define DFT_NWV 4
 #define DFT_BPC 2   // measured best of {4x4x1, 2x4x2, 2x4x1, 4x2x2, 2x8x1, 4x3x1}
 #endif
+#ifndef TVC_FFT
+#define TVC_FFT 1   // |STFT| and the noise iSTFT as wave-level 1920-point FFTs (fft.hip); 0 = the half-size real-DFT GEMMs below
+#endif
 #ifndef TVC_SPLIT_DFT
 #define TVC_SPLIT_DFT 1   // forward / inverse DFT GEMMs on the split-precision bf16 path
 #endif
@@ -61,6 +64,7 @@ static __global__ __launch_bounds__(256) void stft_fold_kernel(const float* __re
 int run_stft(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, float* spec, int B, int64_t L) {
     const int T = (int)(L / kHop);
     const int ncols = B * T;
+    if (TVC_FFT) return dry ? 0 : run_stft_fft(ctx, s, wav, spec, B, L);
     float* fe = ws.get<float>((size_t)960 * ncols);
     float* fo = ws.get<float>((size_t)960 * ncols);
     if (dry) return 0;

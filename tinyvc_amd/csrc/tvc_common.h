@@ -94,6 +94,9 @@ struct tvc_ctx {
     // constant tables
     tvc::PackedW stft_re, stft_im;   // windowed forward real DFT, even/odd halves (see build_dft_tables)
     tvc::PackedW istft_e, istft_o;   // inverse real DFT, even/odd halves, 1/N folded in
+    const float* fft_tw960 = nullptr;    // fft.hip tables: (cos, sin)(2 pi j / 960) [960], (cos, sin)(2 pi k / 1920) [961], periodic Hann [1920]
+    const float* fft_tw1920 = nullptr;
+    const float* fft_hann = nullptr;
     const float* pitch_freq = nullptr;  // [512]
 
     // encoder
@@ -202,6 +205,8 @@ inline int launch_check(tvc_ctx* ctx, const char* what) {
 
 // ---- stage drivers (each enqueues kernels on `s`; `dry` = measure workspace only) ----------
 int run_stft(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* spec, int B, int64_t L);
+int run_stft_fft(tvc_ctx*, hipStream_t, const float* wav, float* spec, int B, int64_t L);
+int run_noise_ifft(tvc_ctx*, hipStream_t, const float* kern, const float* angle, float* frames, int B, int T);
 int run_energy(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* energy, int B, int64_t L);
 int run_encoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* spec, float* ssl, float* f0,
                 float* logits, int B, int T);
