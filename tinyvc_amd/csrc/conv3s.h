@@ -827,7 +827,7 @@ __device__ __forceinline__ void tile_store_t(const f32x16 (&v)[TL::WM][TL::WN], 
 }
 
 template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false, bool CLAMP = false>
-__global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ? S_WPE_F : (TL::NW <= 8 ? S_WPE_G : S_WPE)))) void conv3s_kernel(ConvSArgs a, Epi ep) {
+__global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ? S_WPE_F : (Epi::kIgemm ? (TL::NW <= 8 ? S_WPE_G : 5) : S_WPE)))) void conv3s_kernel(ConvSArgs a, Epi ep) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, A_U4 = TL::a_u4(TAPS);
     constexpr bool TRANS = S_TRANS && !Epi::kIgemm;     // accumulators as [sample][channel]: direct 16-byte stores (tile_store_t)
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s[];
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 tile_store<TL, !(S_ABL & 32)>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
             }
         } else {
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (TL::NW <= 8 ? S_FB_G : S_FB), SCALED, LERP, CLAMP, TRANS>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (Epi::kIgemm ? S_FB_G : S_FB), SCALED, LERP, CLAMP, TRANS>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                                                                                                    load_next_tile, Ks, fT, fstride, a.cmax, a.lin, a.lscale);
             if constexpr (Epi::kIgemm) {
                 // plain GEMM use (B = 1, len = all columns): the igemm epilogue functors finish the element
