@@ -7,6 +7,9 @@
 #include "small_kernels.h"
 #include "tvc_common.h"
 
+#ifndef TVC_SPLIT_SRC
+#define TVC_SPLIT_SRC 1   // SourceNet's to_kernel 1x1 (128 -> 961) on the split-precision GEMM path
+#endif
 #ifndef TVC_FFT
 #define TVC_FFT 1   // filtered-noise iSTFT as wave-level FFTs (fft.hip); 0 = real-DFT GEMMs
 #endif
@@ -215,7 +218,10 @@ static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
     EpiBias<ACT_ELU1, false> ea{amps, ctx->src_to_amps.bias, nullptr, kHarm, T, ncols, (long)kHarm * T, 0};
     igemm_launch(s, ctx->src_to_amps.At, ctx->src_to_amps.Mpad, ctx->src_to_amps.Kpad, ncols, T, ld, ea);
     EpiBias<ACT_ELU1, false> ek{kern, ctx->src_to_kernel.bias, nullptr, kBins, T, ncols, (long)kBins * T, 0};
-    igemm_launch(s, ctx->src_to_kernel.At, ctx->src_to_kernel.Mpad, ctx->src_to_kernel.Kpad, ncols, T, ld, ek);
+    if (TVC_SPLIT_SRC && ctx->src_to_kernel.MT6 % 2 == 0)   // 128 -> 961 rows: the one sizeable contraction of the net, on the split path
+        TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_to_kernel, x, B, kSrcCh, T, 0, ek)));
+    else
+        igemm_launch(s, ctx->src_to_kernel.At, ctx->src_to_kernel.Mpad, ctx->src_to_kernel.Kpad, ncols, T, ld, ek);
     return launch_check(ctx, "source_net");
 }
 
