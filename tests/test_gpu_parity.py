@@ -189,6 +189,23 @@ def test_convert_live_oracle_ragged_lengths(models):
     assert rms(d) <= 1e-4
 
 
+@pytest.mark.parametrize("T,B", [(3, 1), (9, 2), (17, 1)])
+def test_convert_live_oracle_short_utterances(models, T, B):
+    """Utterances shorter than / straddling the tile widths of the persistent kernels (250-256 samples at the full rate, FFT
+    frame groups of 8): 3 frames is the shortest input whose reflect padding is defined."""
+    _enc, _dec, gen = models
+    enc_sd, dec_sd = state_dicts(0)
+    wf = synth.synth_wave(B, 480 * T, seed=100 + T)
+    tgt = synth.synth_index(37, seed=3)
+    angle = synth.synth_angle(B, T, 5)
+    ref = R.convert(enc_sd, dec_sd, wf, tgt, 0.0, angle)
+    wave = gen.convert(wf.to(DEV), tgt.to(DEV), 0.0, noise_angle=angle.to(DEV))
+    assert wave.shape == ref.shape
+    d = wave.cpu() - ref
+    _log(f"[parity] live convert T={T} B={B}: abs rms diff {rms(d):.3e}")
+    assert rms(d) <= 1e-4
+
+
 def test_batch_invariance_and_determinism(models):
     _enc, _dec, gen = models
     wf = synth.synth_wave(4, 14400, seed=5).to(DEV)
