@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtinyvc_hip.so")
-SOURCES = ["api.hip", "frontend.hip", "fft.hip", "encoder.hip", "knn.hip", "decoder.hip", "filter_fused.hip", "filter_up24.hip", "filter_up24s.hip", "sola.hip"]
+SOURCES = ["api.hip", "frontend.hip", "fft.hip", "encoder.hip", "knn.hip", "decoder.hip", "filter_fused.hip", "filter_up24.hip", "filter_up24s.hip", "conv48s.hip", "sola.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

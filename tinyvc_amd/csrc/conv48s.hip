@@ -1,0 +1,300 @@
+// 48-channel k3 dilated convs of FilterNet (ups.3's c1..c4 with their FiLM, Downsample 2's c1 / c2; decoder.py:143-190) with
+// the layer's weights RESIDENT in LDS.  At 48 channels a conv is only three 16-channel K slabs: the generic split kernel
+// (conv3s.h) restages 27 KiB of weights and passes two barriers per slab for 18 MFMAs per wave, and its matrix pipe sat idle
+// two thirds of the time.  Here a persistent 8-wave workgroup loads the conv's 54 weight pieces (and FiLM's 36) once, stages
+// the whole 48-channel halo tile of 128 samples in one go and then issues the tile's 54 (+36) MFMAs per wave back to back:
+// one staging round trip and two barriers per tile instead of per slab.
+//   weights   the same pre-split images as conv3s (PackedW::A6: [K16 step = slab*3 + tap][m-tile][part][lane][8 bf16];
+//             stacked FiLM image [slab][scale mt0, mt1, shift mt0, mt1][part]) - no new packing;
+//   input     Xs[part][8-channel group (6)][position][8 bf16]: lrelu (and, for c1, F.interpolate) applied while depositing;
+//   waves     wave w = m-tile (w >> 2) x 32-sample n-tile (w & 3); FiLM's cond fragments come from HBM straight into
+//             B-fragment order and are split in registers; (conv, scale, shift) combine in registers;
+//   epilogue  bias / FiLM / residual (direct, or F.interpolate of the low-rate tensor evaluated in place), 128-byte runs
+//             per row and store instruction; residual and cond are requested before the MFMAs.
+#include "conv3s.h"
+#include "small_kernels.h"
+#include "tvc_common.h"
+
+namespace tvc {
+
+namespace {
+
+constexpr int kC48 = 48, kBN48 = 128, kXP48 = kBN48 + 2 * 27, kNT48 = 512;
+typedef float f32x4s_t __attribute__((ext_vector_type(4)));
+
+struct Conv48Args {
+    const float* x;        // [B][48][len], or (LERP) the low-rate tensor [B][48][lin]
+    const float* cond;     // FILM: [B][48][len]
+    const float* res;      // RES 1: [B][48][len]; RES 2: low-rate [B][48][rlin], interpolated here
+    float* out;            // [B][48][len]
+    const u32x4* A6;       // conv image, 54 pieces
+    const u32x4* F6;       // stacked FiLM image, 36 pieces
+    const float* bias;     // [64]
+    const float* bsc;      // FiLM to_scale / to_shift biases [64]
+    const float* bsh;
+    int len, dil, lin, rlin, tiles_per_utt, ntiles;
+    float lscale, rscale;
+};
+
+// RES: 0 none, 1 direct, 2 interpolated
+template <bool FILM, bool LERP, int RES>
+__global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void conv48s_kernel(Conv48Args a) {
+    constexpr int C = kC48, BN = kBN48, XP = kXP48, NT = kNT48;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_q[];
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem_q);              // [3 parts][6 groups][XP]
+    u32x4* Wt = Xs + 18 * XP;                                  // 54 pieces
+    u32x4* Ft = Wt + 54 * 64;                                  // 36 pieces (FILM)
+    float* Bi = reinterpret_cast<float*>(Ft + (FILM ? 36 * 64 : 0));   // bias, bsc, bsh [64 each]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int mt = wave >> 2, nt = wave & 3;
+    const int len = a.len, dil = a.dil;
+    const int XW = BN + 2 * dil;
+    const int lin = LERP ? a.lin : len;
+
+    for (int i = tid; i < 54 * 64; i += NT) Wt[i] = a.A6[i];
+    if (FILM)
+        for (int i = tid; i < 36 * 64; i += NT) Ft[i] = a.F6[i];
+    if (tid < 64) {
+        Bi[tid] = a.bias[tid];
+        if (FILM) {
+            Bi[64 + tid] = a.bsc[tid];
+            Bi[128 + tid] = a.bsh[tid];
+        }
+    }
+
+    // staging items (8-channel group, column): 6 * XW <= 1092 of them, three per thread
+    constexpr int XPER = 3;
+    float xr0[XPER][8], xr1[LERP ? XPER : 1][8], lam[LERP ? XPER : 1];
+    int ig[XPER], ic[XPER];
+#pragma unroll
+    for (int i = 0; i < XPER; ++i) {
+        const int idx = tid + i * NT;
+        const int g = idx / XW;
+        ic[i] = idx - g * XW;
+        ig[i] = g;                                             // g >= 6: idle item (loads a valid address, never stores)
+    }
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+        const int b = tile / a.tiles_per_utt;
+        const int px0 = (tile - b * a.tiles_per_utt) * BN - dil;
+        const float* xb = a.x + (long)b * C * lin;
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) {
+            const int g = ig[i] > 5 ? 5 : ig[i];
+            int p = px0 + ic[i];
+            p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+            if (LERP) {
+                const Lerp lc = lerp_coord(p, a.lscale, lin);
+                lam[i] = lc.w1;
+                const unsigned o0 = 4u * (unsigned)(8 * g * lin + lc.i0), o1 = 4u * (unsigned)(8 * g * lin + lc.i1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xr0[i][j] = ldg_so(xb + (long)j * lin, o0);
+                    xr1[i][j] = ldg_so(xb + (long)j * lin, o1);
+                }
+            } else {
+                const unsigned o = 4u * (unsigned)(8 * g * lin + p);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xb + (long)j * lin, o);
+            }
+        }
+    };
+    auto deposit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) {
+            if (ig[i] > 5) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = LERP ? fmaf(1.f - lam[i], xr0[i][j], __fmul_rn(lam[i], xr1[i][j])) : xr0[i][j];   // = lerp_eval
+                v[j] = fmaxf(t, 0.1f * t);                                                                  // = leaky_relu(x, 0.1)
+            }
+            uint4 p1, p2, p3;
+            split8(v, p1, p2, p3);
+            Xs[(0 + ig[i]) * XP + ic[i]] = __builtin_bit_cast(u32x4, p1);
+            Xs[(6 + ig[i]) * XP + ic[i]] = __builtin_bit_cast(u32x4, p2);
+            Xs[(12 + ig[i]) * XP + ic[i]] = __builtin_bit_cast(u32x4, p3);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    fetch(tile);
+    deposit();
+    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+    slab_barrier();
+
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    for (; tile < a.ntiles; tile += gridDim.x) {
+        const int b = tile / a.tiles_per_utt;
+        const int t0 = (tile - b * a.tiles_per_utt) * BN;
+        const int next = tile + gridDim.x;
+        const int n = nt * 32 + l31;
+        const int t = t0 + n;
+        const int tc = t < len ? t : len - 1;
+        const unsigned oo = 4u * (unsigned)((32 * mt + 4 * lh) * len + tc);   // rows 32 mt + 8 g + 4 lh + q, sample t (the wave's m-tile lives in the lane offset: bases stay uniform)
+
+        // cond fragments of this wave's columns: K16 step s -> channels 16 s + 8 lh + j
+        float cr[FILM ? 3 : 1][8];
+        if (FILM) {
+            const float* cb = a.cond + (long)b * C * len;
+            const unsigned oc = 4u * (unsigned)(8 * lh * len + tc);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cr[s][j] = ldg_so(cb + (long)(16 * s + j) * len, oc);
+        }
+        // residual values of this lane's 16 rows
+        float rv[RES ? 4 : 1][4];
+        if (RES == 1) {
+            const float* rb = a.res + (long)b * C * len;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rv[g][q] = 32 * mt + 8 * g < C ? ldg_so(rb + (long)(8 * g + q) * len, oo) : 0.f;   // rows past 48 do not exist
+        } else if (RES == 2) {
+            const float* rb = a.res + (long)b * C * a.rlin;
+            const Lerp lc = lerp_coord(tc, a.rscale, a.rlin);
+            const unsigned o0 = 4u * (unsigned)((32 * mt + 4 * lh) * a.rlin + lc.i0), o1 = 4u * (unsigned)((32 * mt + 4 * lh) * a.rlin + lc.i1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x0 = 0.f, x1 = 0.f;
+                    if (32 * mt + 8 * g < C) {
+                        x0 = ldg_so(rb + (long)(8 * g + q) * a.rlin, o0);
+                        x1 = ldg_so(rb + (long)(8 * g + q) * a.rlin, o1);
+                    }
+                    rv[g][q] = fmaf(lc.w0, x0, __fmul_rn(lc.w1, x1));      // = lerp_eval
+                }
+        }
+
+        // ---- conv: 9 K16 steps (slab, tap), this wave's m-tile x n-tile ------------------------------------
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            bf16x8 af[2][3], bf[2][3];
+            auto frags = [&](int s, int fb) __attribute__((always_inline)) {
+                const int sl = s / 3, tap = s - sl * 3;
+                const int row = (2 * sl + lh) * XP + n + tap * dil;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    bf[fb][p] = __builtin_bit_cast(bf16x8, Xs[p * 6 * XP + row]);
+                    af[fb][p] = __builtin_bit_cast(bf16x8, Wt[((s * 2 + mt) * 3 + p) * 64 + lane]);
+                }
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const int fb = s & 1;
+                if (s + 1 < 9) frags(s + 1, fb ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][PA[q]], bf[fb][PB[q]], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- FiLM scale / shift over cond: 3 K16 steps ----------------------------------------------------
+        f32x16 asc, ash;
+        if (FILM) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asc[r] = ash[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                uint4 p1, p2, p3;
+                split8(cr[s], p1, p2, p3);
+                const bf16x8 cf[3] = {__builtin_bit_cast(bf16x8, p1), __builtin_bit_cast(bf16x8, p2), __builtin_bit_cast(bf16x8, p3)};
+                bf16x8 fa[2][3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    fa[0][p] = __builtin_bit_cast(bf16x8, Ft[((s * 4 + mt) * 3 + p) * 64 + lane]);
+                    fa[1][p] = __builtin_bit_cast(bf16x8, Ft[((s * 4 + 2 + mt) * 3 + p) * 64 + lane]);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    asc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][PA[q]], cf[PB[q]], asc, 0, 0, 0);
+                    ash = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][PA[q]], cf[PB[q]], ash, 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue ---------------------------------------------------------------------------------------
+        {
+            float* ob = a.out + (long)b * C * len;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (32 * mt + 8 * g >= C) continue;                                // uniform per wave
+                const f32x4s_t bv = *reinterpret_cast<const f32x4s_t*>(Bi + 32 * mt + 8 * g + 4 * lh);
+                f32x4s_t bs, bh;
+                if (FILM) {
+                    bs = *reinterpret_cast<const f32x4s_t*>(Bi + 64 + 32 * mt + 8 * g + 4 * lh);
+                    bh = *reinterpret_cast<const f32x4s_t*>(Bi + 128 + 32 * mt + 8 * g + 4 * lh);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[4 * g + q] + bv[q];
+                    if (FILM) v = __fadd_rn(__fmul_rn(v, asc[4 * g + q] + bs[q]), ash[4 * g + q] + bh[q]);
+                    if (RES) v = __fadd_rn(v, rv[g][q]);
+                    if (t < len) stg_so(ob + (long)(8 * g + q) * len, oo, v);
+                }
+            }
+        }
+        // ---- next tile's input: registers -> LDS, then request the one after --------------------------------
+        slab_barrier();                                   // every wave is done reading Xs
+        if (next < a.ntiles) {
+            deposit();
+            if (next + (int)gridDim.x < a.ntiles) fetch(next + gridDim.x);
+        }
+        slab_barrier();
+    }
+}
+
+template <bool FILM, bool LERP, int RES>
+int launch48(tvc_ctx* ctx, hipStream_t s, Conv48Args a, int B) {
+    static int ncu_dev[64] = {};
+    int& ncu = ncu_dev[ctx->device & 63];
+    constexpr size_t lds = (size_t)(18 * kXP48 + 54 * 64 + (FILM ? 36 * 64 : 0)) * 16 + 192 * 4;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv48s_kernel<FILM, LERP, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv48s setup: %s", hipGetErrorString(e));
+        ncu = prop.multiProcessorCount;
+    }
+    a.tiles_per_utt = (a.len + kBN48 - 1) / kBN48;
+    a.ntiles = a.tiles_per_utt * B;
+    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    hipLaunchKernelGGL((conv48s_kernel<FILM, LERP, RES>), dim3(grid), dim3(kNT48), lds, s, a);
+    return launch_check(ctx, "conv48s");
+}
+
+}  // namespace
+
+// mode bits: 1 = the input is the low-rate tensor [B][48][lin] (F.interpolate fused into the staging), 2 = FiLM over cond,
+// residual: rlin == 0 and res != nullptr -> direct, rlin > 0 -> F.interpolate(res low-rate)
+int run_conv48s(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int lin, float lscale, const PackedW* film, const float* bsc,
+                const float* bsh, const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil) {
+    if (w.cin != kC48 || w.M != kC48 || w.taps != 3 || w.MT6 != 2 || !w.A6) return fail(ctx, TVC_ERR_ARG, "conv48s: 48 -> 48 channel k3 convs only");
+    if (dil < 1 || dil > 27) return fail(ctx, TVC_ERR_ARG, "conv48s: dilation must be 1..27");
+    if ((long)len * kC48 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "conv48s: utterance too long for 32-bit byte offsets");
+    if (film && (film->MT6 != 4 || !film->A6 || !cond || !bsc || !bsh)) return fail(ctx, TVC_ERR_ARG, "conv48s: FiLM needs the stacked image, both biases and cond");
+    Conv48Args a{};
+    a.x = x; a.cond = cond; a.res = res; a.out = out;
+    a.A6 = reinterpret_cast<const u32x4*>(w.A6);
+    a.F6 = film ? reinterpret_cast<const u32x4*>(film->A6) : nullptr;
+    a.bias = w.bias; a.bsc = bsc; a.bsh = bsh;
+    a.len = len; a.dil = dil; a.lin = lin; a.rlin = rlin; a.lscale = lscale; a.rscale = rscale;
+    if (lin > 0) {
+        if (film || res) return fail(ctx, TVC_ERR_ARG, "conv48s: the interpolating variant is a plain conv");
+        return launch48<false, true, 0>(ctx, s, a, B);
+    }
+    if (film) {
+        if (!res) return fail(ctx, TVC_ERR_ARG, "conv48s: the FiLM variants carry a residual");
+        return rlin > 0 ? launch48<true, false, 2>(ctx, s, a, B) : launch48<true, false, 1>(ctx, s, a, B);
+    }
+    if (res) return fail(ctx, TVC_ERR_ARG, "conv48s: plain convs carry no residual");
+    return launch48<false, false, 0>(ctx, s, a, B);
+}
+
+}  // namespace tvc

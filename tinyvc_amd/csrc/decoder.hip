@@ -7,6 +7,9 @@
 #include "small_kernels.h"
 #include "tvc_common.h"
 
+#ifndef TVC_C48R
+#define TVC_C48R 1   // 48-channel k3 convs (ups.3, Downsample 2's c1 / c2) with LDS-resident weights (conv48s.hip); 0 = the generic split kernel
+#endif
 #ifndef TVC_SPLIT_SRC
 #define TVC_SPLIT_SRC 1   // SourceNet's to_kernel 1x1 (128 -> 961) on the split-precision GEMM path
 #endif
@@ -383,6 +386,9 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
             } else if (d.cin == 24 && TVC_USE_C48) {   // 24 output channels = two 16-row tiles, many small waves
                 conv3mt_launch<2, true>(s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
                 conv3mt_launch<2, true>(s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});
+            } else if (d.cin == 48 && TVC_C48R) {   // weights resident in LDS, one staging round trip per tile (conv48s.hip)
+                TVC_CHECK(run_conv48s(ctx, s, d.c1, xi, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h1, B, len, 1));
+                TVC_CHECK(run_conv48s(ctx, s, d.c2, h1, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h2, B, len, 2));
             } else if (d.cin == 48 && TVC_SPLIT48) {
                 TVC_CHECK(conv3s_launch<true>(ctx, s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len}));
                 TVC_CHECK(conv3s_launch<true>(ctx, s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len}));
@@ -458,6 +464,17 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 float* xout = half ? xu : x1;  // 2nd half writes over xu (its input and residual are x1)
                 const PackedW& wsc = half ? u.sc2 : u.sc1;
                 const PackedW& wsh = half ? u.sh2 : u.sh1;
+                if (split_level && C == 48 && TVC_C48R) {   // the 48-channel level with its weights resident in LDS (conv48s.hip)
+                    const PackedW& fw = half ? u.film2 : u.film1;
+                    if (half == 0 && lerp_fused) {
+                        TVC_CHECK(run_conv48s(ctx, s, ca, x, lin, lscale, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h, B, lo, da));
+                        TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, wsc.bias, wsh.bias, cond, x, lin, lscale, xout, B, lo, db));
+                    } else {
+                        TVC_CHECK(run_conv48s(ctx, s, ca, xin, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h, B, lo, da));
+                        TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, wsc.bias, wsh.bias, cond, xin, 0, 0.f, xout, B, lo, db));
+                    }
+                    continue;
+                }
                 if (split_level) {
                     const PackedW& fw = half ? u.film2 : u.film1;      // stacked [to_scale ; to_shift] rows, each group padded to whole 32-row tiles
                     if (half == 0 && lerp_fused) {
