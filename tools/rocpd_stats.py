@@ -7,6 +7,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void tvc::", "").replace("tvc::", "")
     return name[:150]
