@@ -562,6 +562,15 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
         pk.conv({p + ".c1"}, &d.c1, d.cin, 3);
         pk.conv({p + ".c2"}, &d.c2, d.cin, 3);
         pk.conv({p + ".c3"}, &d.c3, d.cin, 3);
+        {   // c3.bias + down_res.bias for the launches that accumulate both convs into one tile
+            const HostTensor* b3 = pk.find(p + ".c3.bias");
+            const HostTensor* br = pk.find(p + ".down_res.bias");
+            if (b3 && br && b3->data.size() == (size_t)d.cout && br->data.size() == (size_t)d.cout) {
+                std::vector<float> sum(d.c3.Mpad, 0.f);
+                for (int m = 0; m < d.cout; ++m) sum[m] = b3->data[m] + br->data[m];
+                pk.fix.push_back({&d.c3res_bias, pk.ab.put(sum)});
+            }
+        }
         if (d.cin == 24 && d.cout == 48) {
             pk.conv24s(&d.s24c1, p + ".c1", 24);
             pk.conv24s(&d.s24c2, p + ".c2", 24);

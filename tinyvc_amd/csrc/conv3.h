@@ -89,6 +89,12 @@ struct C3EpiFilm {
     }
 };
 
+// C3EpiBias whose launch also accumulates a 1x1 conv of a second tensor into the tile (conv3s.h wants_res_conv):
+// Downsample's c3 + down_res; `bias` = the two biases summed at pack time.
+struct C3EpiBiasResConv : C3EpiBias<false, 0> {
+    static constexpr bool kResConv = true;
+};
+
 // conv -> FiLM -> + residual with scale/shift computed in-kernel: store(b, t, m, h[4], sc[4], sh[4])
 struct C3EpiFilmFused {
     static constexpr bool kIgemm = false;

@@ -88,6 +88,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #endif
 
 
+// epilogues that ask for a second, 1x1 phase over another tensor accumulated into the SAME tile (Downsample: c3(h2) + down_res(xi))
+template <class E, class = void>
+struct wants_res_conv : std::false_type {};
+template <class E>
+struct wants_res_conv<E, std::void_t<decltype(E::kResConv)>> : std::bool_constant<E::kResConv> {};
+
 template <int MTB_, int WM_, int NWV_, int WN_ = 1, int KG_ = 1, int MAXD_ = 27>
 struct SplitTile {
     static constexpr int MTB = MTB_, WM = WM_, NWV = NWV_, WN = WN_;            // m-tiles per workgroup / per wave, waves along time, n-tiles per wave
@@ -964,6 +970,16 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 tile_store<TL, !(S_ABL & 32)>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
             }
         } else {
+            if constexpr (wants_res_conv<Epi>::value) {
+                // Downsample (decoder.py:148-157): out = c3(lrelu(h2)) + down_res(xi).  Both are linear into the same output tile:
+                // the 1x1 runs as a second K phase over xi (a.cond, a.Ccond channels, image a.sc6) on the same accumulators, so
+                // the residual tensor is never written or read back and its launch disappears (ep.bias = the two biases summed).
+                const float* cb = a.cond + (long)b * a.Ccond * len;
+                split_phase<TL, TAPS, A_U4, LRELU, S_FB, false, false, false, TRANS>(
+                    acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+                    [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0); });
+                split_phase<TL, 1, A_U4, false, S_FB, false, false, false, TRANS>(acc, regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile);
+            } else
             split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (Epi::kIgemm ? S_FB_G : S_FB), SCALED, LERP, CLAMP, TRANS>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                                                                                                    load_next_tile, Ks, fT, fstride, a.cmax, a.lin, a.lscale);
             if constexpr (Epi::kIgemm) {
@@ -1051,6 +1067,13 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
         B = 1;
     }
     a.tiles_per_utt = (a.len + TL::BN - 1) / TL::BN;
+    if (wants_res_conv<Epi>::value) {
+        if (FILM || !wsc || wsc->MT6 != w.MT6 || wsc->taps != 1 || Ccond % 16 != 0 || Ccond / 16 > wsc->S6 || !cond)
+            return fail(ctx, TVC_ERR_ARG, "conv3s: the residual 1x1 phase needs a matching 1x1 image and its input");
+        a.sc6 = reinterpret_cast<const uint4*>(wsc->A6);
+        a.cond = cond;
+        a.Ccond = Ccond;
+    }
     if (FILM) {
         if (wsc->MT6 != 2 * w.MT6) return fail(ctx, TVC_ERR_ARG, "conv3s: FiLM image must stack scale and shift rows");
         a.sc6 = reinterpret_cast<const uint4*>(wsc->A6);   // stacked [to_scale ; to_shift] image (wsh unused)

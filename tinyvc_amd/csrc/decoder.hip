@@ -7,6 +7,9 @@
 #include "small_kernels.h"
 #include "tvc_common.h"
 
+#ifndef TVC_RESCONV
+#define TVC_RESCONV 1   // Downsample 2-4: down_res(xi) accumulated by c3's launch as a second K phase (no residual tensor, no 1x1 launch)
+#endif
 #ifndef TVC_C48R
 #define TVC_C48R 1   // 48-channel k3 convs (ups.3, Downsample 2's c1 / c2) with LDS-resident weights (conv48s.hip); 0 = the generic split kernel
 #endif
@@ -371,7 +374,9 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 hipLaunchKernelGGL(lerp_resize_kernel, ll.grid, dim3(256), 0, s, skip[i - 1], xi, (long)B * d.cin, lin, len, (float)d.factor, ll.tx);
             }
             const int nc = B * len;
-            {
+            // c3 on the generic split kernel folds down_res(xi) in as a second K phase: no residual tensor, no launch for it
+            const bool resconv = TVC_RESCONV && TVC_SPLIT && d.cin % 16 == 0 && d.cout % 96 == 0 && d.res.MT6 == d.c3.MT6 && d.c3res_bias != nullptr;
+            if (!resconv) {
                 EpiBias<ACT_NONE, false> ep{res, d.res.bias, nullptr, d.cout, len, nc, (long)d.cout * len, 0};
                 if (TVC_SPLIT_1X1 && d.cin % 16 == 0 && d.res.MT6 % 3 == 0) {
                     TVC_CHECK((gemm_s_launch<3, 4, 1>(ctx, s, d.res, xi, B, d.cin, len, 0, ep)));
@@ -407,6 +412,12 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 TVC_CHECK(conv3s_launch<true>(ctx, s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len}));
             else if (d.cout == 48 && TVC_USE_C48)
                 conv3m48_launch<true>(s, d.c3, h2, B, d.cin, len, 4, C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len});
+            else if (resconv)
+                TVC_CHECK((conv3s_launch<true, C3EpiBiasResConv>(ctx, s, d.c3, h2, B, d.cin, len, 4,
+                                                                 C3EpiBiasResConv{{skip[i], d.c3res_bias, nullptr, d.cout, len,
+                                                                                   (i < 4 && xi_fused[i + 1]) ? xi_pre[i + 1] : nullptr,
+                                                                                   (i < 4 && xi_fused[i + 1]) ? ctx->downs[i].factor : 0}},
+                                                                 &d.res, nullptr, xi, d.cin)));
             else if (TVC_SPLIT && d.cin % 16 == 0 && d.cout % 96 == 0)
                 TVC_CHECK(conv3s_launch<true>(ctx, s, d.c3, h2, B, d.cin, len, 4,
                                               C3EpiBias<true>{skip[i], d.c3.bias, res, d.cout, len, (i < 4 && xi_fused[i + 1]) ? xi_pre[i + 1] : nullptr,

@@ -50,6 +50,7 @@ struct ConvNeXtW {
 
 struct DownW {
     PackedW res, c1, c2, c3;
+    const float* c3res_bias = nullptr;   // c3.bias + down_res.bias [c3.Mpad]: c3 launches that fold the residual 1x1 in as a second K phase
     const float* s24c1 = nullptr;   // cin == 24: weight blobs of conv24s_kernel (filter_up24s.hip)
     const float* s24c2 = nullptr;
     const float* s24c3 = nullptr;
