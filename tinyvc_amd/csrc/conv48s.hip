@@ -21,6 +21,23 @@ namespace {
 
 constexpr int kC48 = 48, kBN48 = 128, kXP48 = kBN48 + 2 * 27, kNT48 = 512;
 typedef float f32x4s_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// three bf16 parts of 4 fp32 values (8 bytes each)
+__device__ __forceinline__ void split4_48(const float (&v)[4], u32x2_t& p1, u32x2_t& p2, u32x2_t& p3) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f32x2 a = {v[2 * j], v[2 * j + 1]};
+        bf16x2 h1 = __builtin_convertvector(a, bf16x2);
+        f32x2 r = a - __builtin_convertvector(h1, f32x2);
+        bf16x2 h2 = __builtin_convertvector(r, bf16x2);
+        f32x2 r2 = r - __builtin_convertvector(h2, f32x2);
+        bf16x2 h3 = __builtin_convertvector(r2, bf16x2);
+        p1[j] = __builtin_bit_cast(unsigned, h1);
+        p2[j] = __builtin_bit_cast(unsigned, h2);
+        p3[j] = __builtin_bit_cast(unsigned, h3);
+    }
+}
 
 struct Conv48Args {
     const float* x;        // [B][48][len], or (LERP) the low-rate tensor [B][48][lin]
@@ -29,6 +46,9 @@ struct Conv48Args {
     float* out;            // [B][48][len]
     const u32x4* A6;       // conv image, 54 pieces
     const u32x4* F6;       // stacked FiLM image, 36 pieces
+    const u32x4* W5;       // C5: c5's image (1 m-tile, 3 K16 steps: 9 pieces) and bias [32]
+    const float* b5;
+    float* out5;           // C5: [B][24][len]
     const float* bias;     // [64]
     const float* bsc;      // FiLM to_scale / to_shift biases [64]
     const float* bsh;
@@ -36,15 +56,17 @@ struct Conv48Args {
     float lscale, rscale;
 };
 
-// RES: 0 none, 1 direct, 2 interpolated
-template <bool FILM, bool LERP, int RES>
+// RES: 0 none, 1 direct, 2 interpolated.  C5: Upsample.c5 (1x1, 48 -> 24, decoder.py:171,189) applied to the finished tile
+// before it leaves the CU: the 48-channel block output is never written, only c5's 24 rows are.
+template <bool FILM, bool LERP, int RES, bool C5 = false>
 __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void conv48s_kernel(Conv48Args a) {
     constexpr int C = kC48, BN = kBN48, XP = kXP48, NT = kNT48;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_q[];
     u32x4* Xs = reinterpret_cast<u32x4*>(smem_q);              // [3 parts][6 groups][XP]
     u32x4* Wt = Xs + 18 * XP;                                  // 54 pieces
     u32x4* Ft = Wt + 54 * 64;                                  // 36 pieces (FILM)
-    float* Bi = reinterpret_cast<float*>(Ft + (FILM ? 36 * 64 : 0));   // bias, bsc, bsh [64 each]
+    u32x4* W5t = Ft + (FILM ? 36 * 64 : 0);                   // 9 pieces (C5)
+    float* Bi = reinterpret_cast<float*>(W5t + (C5 ? 9 * 64 : 0));    // bias, bsc, bsh [64 each], b5 [32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int mt = wave >> 2, nt = wave & 3;
@@ -55,6 +77,10 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
     for (int i = tid; i < 54 * 64; i += NT) Wt[i] = a.A6[i];
     if (FILM)
         for (int i = tid; i < 36 * 64; i += NT) Ft[i] = a.F6[i];
+    if (C5) {
+        for (int i = tid; i < 9 * 64; i += NT) W5t[i] = a.W5[i];
+        if (tid < 32) Bi[192 + tid] = a.b5[tid];
+    }
     if (tid < 64) {
         Bi[tid] = a.bias[tid];
         if (FILM) {
@@ -220,8 +246,9 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         }
 
         // ---- epilogue ---------------------------------------------------------------------------------------
+        float xv[C5 ? 4 : 1][4];
         {
-            float* ob = a.out + (long)b * C * len;
+            float* ob = C5 ? nullptr : a.out + (long)b * C * len;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (32 * mt + 8 * g >= C) continue;                                // uniform per wave
@@ -236,7 +263,50 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
                     float v = acc[4 * g + q] + bv[q];
                     if (FILM) v = __fadd_rn(__fmul_rn(v, asc[4 * g + q] + bs[q]), ash[4 * g + q] + bh[q]);
                     if (RES) v = __fadd_rn(v, rv[g][q]);
-                    if (t < len) stg_so(ob + (long)(8 * g + q) * len, oo, v);
+                    if (C5) xv[g][q] = v;
+                    else if (t < len) stg_so(ob + (long)(8 * g + q) * len, oo, v);
+                }
+            }
+        }
+        if (C5) {
+            // the finished 48 x 128 tile goes back into the (now idle) input tile as c5's B operand: split, rows
+            // [part][group 4 mt + g][column], this lane's four channels are one 8-byte half of a row
+            slab_barrier();                               // every wave is done reading Xs
+            u32x2_t* xrow = reinterpret_cast<u32x2_t*>(Xs);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (32 * mt + 8 * g >= C) continue;
+                u32x2_t p1, p2, p3;
+                split4_48(xv[g], p1, p2, p3);
+                xrow[((0 + 4 * mt + g) * XP + n) * 2 + lh] = p1;
+                xrow[((6 + 4 * mt + g) * XP + n) * 2 + lh] = p2;
+                xrow[((12 + 4 * mt + g) * XP + n) * 2 + lh] = p3;
+            }
+            slab_barrier();
+            if (mt == 0) {                                // 24 output rows = one m-tile: the first four waves, one n-tile each
+                f32x16 a5;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a5[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    bf16x8 fa[3], fb[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        fb[p] = __builtin_bit_cast(bf16x8, Xs[(p * 6 + 2 * s + lh) * XP + n]);
+                        fa[p] = __builtin_bit_cast(bf16x8, W5t[(s * 3 + p) * 64 + lane]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) a5 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]], fb[PB[q]], a5, 0, 0, 0);
+                }
+                if (t < len) {
+                    float* o5 = a.out5 + (long)b * 24 * len;
+                    const unsigned o5o = 4u * (unsigned)(4 * lh * len + t);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        const f32x4s_t b5v = *reinterpret_cast<const f32x4s_t*>(Bi + 192 + 8 * g + 4 * lh);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) stg_so(o5 + (long)(8 * g + q) * len, o5o, a5[4 * g + q] + b5v[q]);
+                    }
                 }
             }
         }
@@ -250,22 +320,22 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
     }
 }
 
-template <bool FILM, bool LERP, int RES>
+template <bool FILM, bool LERP, int RES, bool C5 = false>
 int launch48(tvc_ctx* ctx, hipStream_t s, Conv48Args a, int B) {
     static int ncu_dev[64] = {};
     int& ncu = ncu_dev[ctx->device & 63];
-    constexpr size_t lds = (size_t)(18 * kXP48 + 54 * 64 + (FILM ? 36 * 64 : 0)) * 16 + 192 * 4;
+    constexpr size_t lds = (size_t)(18 * kXP48 + 54 * 64 + (FILM ? 36 * 64 : 0) + (C5 ? 9 * 64 : 0)) * 16 + 224 * 4;
     if (!ncu) {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv48s_kernel<FILM, LERP, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv48s_kernel<FILM, LERP, RES, C5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv48s setup: %s", hipGetErrorString(e));
         ncu = prop.multiProcessorCount;
     }
     a.tiles_per_utt = (a.len + kBN48 - 1) / kBN48;
     a.ntiles = a.tiles_per_utt * B;
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
-    hipLaunchKernelGGL((conv48s_kernel<FILM, LERP, RES>), dim3(grid), dim3(kNT48), lds, s, a);
+    hipLaunchKernelGGL((conv48s_kernel<FILM, LERP, RES, C5>), dim3(grid), dim3(kNT48), lds, s, a);
     return launch_check(ctx, "conv48s");
 }
 
@@ -274,7 +344,8 @@ int launch48(tvc_ctx* ctx, hipStream_t s, Conv48Args a, int B) {
 // mode bits: 1 = the input is the low-rate tensor [B][48][lin] (F.interpolate fused into the staging), 2 = FiLM over cond,
 // residual: rlin == 0 and res != nullptr -> direct, rlin > 0 -> F.interpolate(res low-rate)
 int run_conv48s(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int lin, float lscale, const PackedW* film, const float* bsc,
-                const float* bsh, const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil) {
+                const float* bsh, const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil, const PackedW* c5,
+                float* out5) {
     if (w.cin != kC48 || w.M != kC48 || w.taps != 3 || w.MT6 != 2 || !w.A6) return fail(ctx, TVC_ERR_ARG, "conv48s: 48 -> 48 channel k3 convs only");
     if (dil < 1 || dil > 27) return fail(ctx, TVC_ERR_ARG, "conv48s: dilation must be 1..27");
     if ((long)len * kC48 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "conv48s: utterance too long for 32-bit byte offsets");
@@ -291,6 +362,14 @@ int run_conv48s(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, i
     }
     if (film) {
         if (!res) return fail(ctx, TVC_ERR_ARG, "conv48s: the FiLM variants carry a residual");
+        if (c5) {   // FiLM2 + residual + c5: only c5's 24 rows leave the CU
+            if (rlin > 0 || !out5 || c5->M != 24 || c5->cin != kC48 || c5->taps != 1 || c5->MT6 != 1 || !c5->A6)
+                return fail(ctx, TVC_ERR_ARG, "conv48s: the fused c5 is the 48 -> 24 1x1 after the second FiLM");
+            a.W5 = reinterpret_cast<const u32x4*>(c5->A6);
+            a.b5 = c5->bias;
+            a.out5 = out5;
+            return launch48<true, false, 1, true>(ctx, s, a, B);
+        }
         return rlin > 0 ? launch48<true, false, 2>(ctx, s, a, B) : launch48<true, false, 1>(ctx, s, a, B);
     }
     if (res) return fail(ctx, TVC_ERR_ARG, "conv48s: plain convs carry no residual");

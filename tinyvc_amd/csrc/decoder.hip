@@ -7,6 +7,9 @@
 #include "small_kernels.h"
 #include "tvc_common.h"
 
+#ifndef TVC_C48_C5
+#define TVC_C48_C5 1   // ups.3: c5 (48 -> 24) applied inside the c4 + FiLM2 launch (conv48s.hip)
+#endif
 #ifndef TVC_RESCONV
 #define TVC_RESCONV 1   // Downsample 2-4: down_res(xi) accumulated by c3's launch as a second K phase (no residual tensor, no 1x1 launch)
 #endif
@@ -467,6 +470,7 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 const LerpLaunch ll = lerp_launch((long)B * C, lo);
                 hipLaunchKernelGGL(lerp_resize_kernel, ll.grid, dim3(256), 0, s, x, xu, (long)B * C, lin, lo, lscale, ll.tx);
             }
+            const bool c5_fused = TVC_C48R && TVC_C48_C5 && split_level && C == 48 && u.cout == 24 && u.c5.MT6 == 1;
             for (int half = 0; half < 2; ++half) {
                 const PackedW& ca = half ? u.c3 : u.c1;
                 const PackedW& cb = half ? u.c4 : u.c2;
@@ -482,7 +486,10 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                         TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, wsc.bias, wsh.bias, cond, x, lin, lscale, xout, B, lo, db));
                     } else {
                         TVC_CHECK(run_conv48s(ctx, s, ca, xin, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h, B, lo, da));
-                        TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, wsc.bias, wsh.bias, cond, xin, 0, 0.f, xout, B, lo, db));
+                        if (half == 1 && c5_fused)   // c4 + FiLM2 + residual + c5 in one launch: the level's output is written directly
+                            TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, wsc.bias, wsh.bias, cond, xin, 0, 0.f, nullptr, B, lo, db, &u.c5, xlev[i]));
+                        else
+                            TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, wsc.bias, wsh.bias, cond, xin, 0, 0.f, xout, B, lo, db));
                     }
                     continue;
                 }
@@ -527,7 +534,8 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                 }
             }
             EpiBias<ACT_NONE, false> ep{xlev[i], u.c5.bias, nullptr, u.cout, lo, nc, (long)u.cout * lo, 0};
-            if (TVC_SPLIT_1X1 && C % 16 == 0 && u.c5.MT6 % 3 == 0) {
+            if (c5_fused) {
+            } else if (TVC_SPLIT_1X1 && C % 16 == 0 && u.c5.MT6 % 3 == 0) {
                 TVC_CHECK((gemm_s_launch<3, 4, 1>(ctx, s, u.c5, xu, B, C, lo, 0, ep)));
             } else if (TVC_SPLIT_1X1 && C % 16 == 0 && u.c5.MT6 % 2 == 0) {
                 TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, u.c5, xu, B, C, lo, 0, ep)));

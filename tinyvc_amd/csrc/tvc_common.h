@@ -234,7 +234,8 @@ int run_up24_split(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const fl
 int run_down0_split(tvc_ctx*, hipStream_t, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len);
 int run_down24_split(tvc_ctx*, hipStream_t, const DownW& d, const float* xi, const float* res, float* h1, float* h2, float* out, float* y2, int B, int len);
 int run_conv48s(tvc_ctx*, hipStream_t, const PackedW& w, const float* x, int lin, float lscale, const PackedW* film, const float* bsc, const float* bsh,
-                const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil);
+                const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil, const PackedW* c5 = nullptr,
+                float* out5 = nullptr);
 int run_down0(tvc_ctx*, hipStream_t, const PackedW& w, const float* source, const float* energy, float* out, int B, int len);
 int run_out_conv7(tvc_ctx*, hipStream_t, const float* x, const float* w_raw, const float* bias, float* y, int B, int C, int len);
 
