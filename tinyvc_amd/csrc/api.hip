@@ -289,9 +289,11 @@ struct Packer {
     }
     // Weight blob of one 24-input-channel k3 conv for conv24s_kernel (filter_up24s.hip): pieces [step][m-tile][part]
     // (same (tap, group) K order as up24s_half), then 64 bias floats.  M = 24 (one m-tile) or 48 (two).
-    void conv24s(const float** slot, const std::string& name, int M) {
+    void conv24s(const float** slot, const std::string& name, int M, const std::string& extra_bias = "") {
         const HostTensor* w = find(name + ".weight");
         const HostTensor* b = find(name + ".bias");
+        const HostTensor* eb = extra_bias.empty() ? nullptr : find(extra_bias);
+        if (!extra_bias.empty() && (!eb || eb->data.size() != (size_t)M)) return;
         if (!w || !b) return;
         const int CI = 24, MT = (M + 31) / 32;
         if (w->data.size() != (size_t)M * CI * 3 || b->data.size() != (size_t)M) return;
@@ -325,7 +327,7 @@ struct Packer {
                         o[base + 512] = h2;
                         o[base + 1024] = h3;
                     }
-        for (int m = 0; m < M; ++m) img[(size_t)15 * MT * 256 + m] = b->data[m];
+        for (int m = 0; m < M; ++m) img[(size_t)15 * MT * 256 + m] = b->data[m] + (eb ? eb->data[m] : 0.f);
         fix.push_back({slot, ab.put(img)});
     }
     void convnext(const std::string& p, ConvNeXtW* w, int C, int dil) {
@@ -575,6 +577,7 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
             pk.conv24s(&d.s24c1, p + ".c1", 24);
             pk.conv24s(&d.s24c2, p + ".c2", 24);
             pk.conv24s(&d.s24c3, p + ".c3", 48);
+            pk.conv24s(&d.s24c3r, p + ".c3", 48, p + ".down_res.bias");
         }
     }
     for (int i = 0; i < 5; ++i) {

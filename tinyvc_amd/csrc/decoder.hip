@@ -378,7 +378,9 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
             }
             const int nc = B * len;
             // c3 on the generic split kernel folds down_res(xi) in as a second K phase: no residual tensor, no launch for it
-            const bool resconv = TVC_RESCONV && TVC_SPLIT && d.cin % 16 == 0 && d.cout % 96 == 0 && d.res.MT6 == d.c3.MT6 && d.c3res_bias != nullptr;
+            const bool d24s = TVC_DOWN24_SPLIT && d.cin == 24 && d.cout == 48;
+            const bool resconv = TVC_RESCONV && ((TVC_SPLIT && d.cin % 16 == 0 && d.cout % 96 == 0 && d.res.MT6 == d.c3.MT6 && d.c3res_bias != nullptr) ||
+                                                 (d24s && d.s24c3r != nullptr && d.res.MT6 == 2));
             if (!resconv) {
                 EpiBias<ACT_NONE, false> ep{res, d.res.bias, nullptr, d.cout, len, nc, (long)d.cout * len, 0};
                 if (TVC_SPLIT_1X1 && d.cin % 16 == 0 && d.res.MT6 % 3 == 0) {
@@ -388,9 +390,8 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
                     igemm_launch(s, d.res.At, d.res.Mpad, d.res.Kpad, nc, len, ld, ep);
                 }
             }
-            const bool d24s = TVC_DOWN24_SPLIT && d.cin == 24 && d.cout == 48;
             if (d24s) {   // the whole 24-channel block on the split-precision path; c3's epilogue adds res and writes the next block's 1/4-rate input
-                TVC_CHECK(run_down24_split(ctx, s, d, xi, res, h1, h2, skip[i], (i < 4 && xi_fused[i + 1]) ? xi_pre[i + 1] : nullptr, B, len));
+                TVC_CHECK(run_down24_split(ctx, s, d, xi, resconv ? nullptr : res, h1, h2, skip[i], (i < 4 && xi_fused[i + 1]) ? xi_pre[i + 1] : nullptr, B, len));
             } else if (d.cin == 24 && TVC_USE_C48) {   // 24 output channels = two 16-row tiles, many small waves
                 conv3mt_launch<2, true>(s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len});
                 conv3mt_launch<2, true>(s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len});

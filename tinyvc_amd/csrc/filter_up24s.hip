@@ -536,18 +536,21 @@ int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float*
 // One 24-input-channel k3 conv (Downsample 1's c1 / c2 / c3, decoder.py:143-158) on the same machinery: 24 -> 24 (one
 // m-tile) or 24 -> 48 (two), optional leaky_relu on the input, optional residual, optional 1/4-rate copy for the next
 // Downsample block (mean of samples 4 d + 1 and 4 d + 2, see C3EpiBias).  Persistent, double-buffered input tiles.
-template <int MT_, int DIL_, bool LRELU_, bool RES_>
+// RES: 0 none, 1 a residual tensor is added, 2 the residual is a 1x1 conv of a second 24-channel tensor (Downsample's
+// down_res(xi)), accumulated on the same tile from B fragments loaded straight from HBM
+template <int MT_, int DIL_, bool LRELU_, int RES_>
 struct C24S {
-    static constexpr int MT = MT_, DIL = DIL_;
-    static constexpr bool LRELU = LRELU_, RES = RES_;
+    static constexpr int MT = MT_, DIL = DIL_, RES = RES_;
+    static constexpr bool LRELU = LRELU_;
     static constexpr int XW = 256, XP = XW, W = (XW - 2 * DIL) / 4 * 4, NT = 512;
-    static constexpr int PIECES = 15 * MT, FL = 64;
-    static constexpr int LDS_BYTES = (2 * 9 * XP + PIECES * 64) * 16 + FL * 4;
+    static constexpr int PIECES = 15 * MT, RPIECES = RES == 2 ? 6 * MT : 0, FL = 64;
+    static constexpr int LDS_BYTES = (2 * 9 * XP + (PIECES + RPIECES) * 64) * 16 + FL * 4;
     static_assert(W % 4 == 0, "the 1/4-rate copy pairs samples inside a tile");
 };
 struct Conv24SArgs {
     const float* x;        // [B][24][len]
-    const float* res;      // [B][M][len] (RES)
+    const float* res;      // RES 1: [B][M][len]; RES 2: the second input xi [B][24][len]
+    const u32x4* rimg;     // RES 2: the 1x1's image (PackedW::A6 of a 24-input 1x1: [2 steps][MT][3 parts])
     float* out;            // [B][M][len]
     float* y2;             // optional [B][M][len / 4]
     const u32x4* img;      // 15 * MT weight pieces [step][m-tile][part], then 64 bias floats
@@ -560,11 +563,14 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) voi
     extern __shared__ __attribute__((aligned(16))) uint4 smem_c[];
     u32x4* Xs = reinterpret_cast<u32x4*>(smem_c);              // [2 buffers][3 parts][3 groups][XP]
     u32x4* Wt = Xs + 2 * 9 * XP;
-    float* Bi = reinterpret_cast<float*>(Wt + CF::PIECES * 64);
+    u32x4* Wr = Wt + CF::PIECES * 64;
+    float* Bi = reinterpret_cast<float*>(Wr + CF::RPIECES * 64);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int len = a.len, M = a.M;
-    for (int i = tid; i < CF::PIECES * 64 + CF::FL / 4; i += NT) Wt[i] = a.img[i];
+    for (int i = tid; i < CF::PIECES * 64; i += NT) Wt[i] = a.img[i];
+    for (int i = tid; i < CF::RPIECES * 64; i += NT) Wr[i] = a.rimg[i];
+    for (int i = tid; i < CF::FL; i += NT) Bi[i] = reinterpret_cast<const float*>(a.img + CF::PIECES * 64)[i];
 
     // staging items (group, column): 768 of them, thread -> item tid and (tid < 256) item tid + 512
     float xa[2][8];
@@ -618,9 +624,10 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) voi
         const int t = t0 + n;
         const bool live = n < W && t < len;
         const unsigned oo = 4u * (unsigned)(4 * lh * len + (t < len ? t : len - 1));
-        // residual rows of this lane, requested before the multiply
-        float rv[MT][4][4];
-        if (CF::RES) {
+        // residual rows of this lane (RES 1) or the second input's B fragments (RES 2), requested before the multiply
+        float rv[CF::RES == 1 ? MT : 1][4][4];
+        float xq0[8], xq1[8];
+        if (CF::RES == 1) {
             const float* rb = a.res + (long)b * M * len;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -632,6 +639,15 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) voi
                         m = m + 4 < M ? m : M - 5;                       // rows past M are never stored: any valid address
                         rv[mt][g][q] = ldg_so(rb + (long)m * len, oo);
                     }
+        } else if (CF::RES == 2) {
+            const float* xb2 = a.res + (long)b * 24 * len;
+            const int tc = t < len ? t : len - 1;
+            const unsigned o0 = 4u * (unsigned)(8 * lh * len + tc), o1 = 4u * (unsigned)tc;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xq0[j] = ldg_so(xb2 + (long)j * len, o0);                // K16 step 0: channels 8 lh + j
+                xq1[j] = ldg_so(xb2 + (long)(16 + j) * len, o1);         // step 1: channels 16 + j on lh = 0, the zero unit on lh = 1
+            }
         }
         f32x16 acc[MT];
 #pragma unroll
@@ -669,6 +685,26 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (CF::RES == 2) {   // + down_res(xi): two more K16 steps on the same accumulators
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                uint4 p1, p2, p3;
+                split8(st ? xq1 : xq0, p1, p2, p3);
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                const bool dead = st == 1 && lh;
+                const bf16x8 xf[3] = {__builtin_bit_cast(bf16x8, dead ? z : p1), __builtin_bit_cast(bf16x8, dead ? z : p2),
+                                      __builtin_bit_cast(bf16x8, dead ? z : p3)};
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    bf16x8 wf[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) wf[p] = __builtin_bit_cast(bf16x8, Wr[((st * MT + mt) * 3 + p) * 64 + lane]);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[PA[q]], xf[PB[q]], acc[mt], 0, 0, 0);
+                }
+            }
+        }
         {
             float* ob = a.out + (long)b * M * len;
             const bool pair = a.y2 != nullptr && (t & 3) == 1 && t + 1 < len;      // 1/4-rate copy: mean of samples 4 d + 1, 4 d + 2
@@ -681,7 +717,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) voi
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float v = acc[mt][4 * g + q] + bv[q];
-                        if (CF::RES) v += rv[mt][g][q];
+                        if (CF::RES == 1) v += rv[mt][g][q];
                         const float vn = __shfl_down(v, 1);                        // sample t + 1 (same tile: W % 4 == 0)
                         const int m = 32 * mt + 8 * g + 4 * lh + q;
                         if (live && m < M) {
@@ -725,11 +761,19 @@ int run_down24_split(tvc_ctx* ctx, hipStream_t s, const DownW& d, const float* x
     Conv24SArgs a{};
     a.len = len;
     a.x = xi; a.out = h1; a.M = 24; a.img = reinterpret_cast<const u32x4*>(d.s24c1);
-    TVC_CHECK((launch_conv24s<C24S<1, 1, true, false>>(ctx, s, a, B)));
+    TVC_CHECK((launch_conv24s<C24S<1, 1, true, 0>>(ctx, s, a, B)));
     a.x = h1; a.out = h2; a.img = reinterpret_cast<const u32x4*>(d.s24c2);
-    TVC_CHECK((launch_conv24s<C24S<1, 2, true, false>>(ctx, s, a, B)));
-    a.x = h2; a.out = out; a.res = res; a.y2 = y2; a.M = 48; a.img = reinterpret_cast<const u32x4*>(d.s24c3);
-    return launch_conv24s<C24S<2, 4, true, true>>(ctx, s, a, B);
+    TVC_CHECK((launch_conv24s<C24S<1, 2, true, 0>>(ctx, s, a, B)));
+    a.x = h2; a.out = out; a.y2 = y2; a.M = 48;
+    if (!res) {   // down_res(xi) folded in: the blob with the summed biases, the 1x1's image, xi as the second input
+        if (!d.s24c3r || !d.res.A6 || d.res.MT6 != 2) return fail(ctx, TVC_ERR_STATE, "conv24s: the residual 1x1's image is missing");
+        a.img = reinterpret_cast<const u32x4*>(d.s24c3r);
+        a.rimg = reinterpret_cast<const u32x4*>(d.res.A6);
+        a.res = xi;
+        return launch_conv24s<C24S<2, 4, true, 2>>(ctx, s, a, B);
+    }
+    a.res = res; a.img = reinterpret_cast<const u32x4*>(d.s24c3);
+    return launch_conv24s<C24S<2, 4, true, 1>>(ctx, s, a, B);
 }
 
 }  // namespace tvc

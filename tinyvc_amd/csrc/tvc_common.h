@@ -54,6 +54,7 @@ struct DownW {
     const float* s24c1 = nullptr;   // cin == 24: weight blobs of conv24s_kernel (filter_up24s.hip)
     const float* s24c2 = nullptr;
     const float* s24c3 = nullptr;
+    const float* s24c3r = nullptr;   // c3's blob with c3.bias + down_res.bias (the launch that folds the residual 1x1 in)
     int cin = 0, cout = 0, factor = 1;
 };
 struct UpW {
