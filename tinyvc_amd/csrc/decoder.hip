@@ -219,7 +219,10 @@ static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
         hipLaunchKernelGGL(window_max_kernel, dim3(grid_for((long)ncols * 64)), dim3(256), 0, s, energy, ef, (long)B, T, kHop);
         LoadPlain ld{content, kSslDim, T, (long)kSslDim * T};
         EpiSumCond ep{x, ctx->src_content_in.bias, ef, f0, ctx->src_e_w, ctx->src_e_b, ctx->src_f_w, ctx->src_f_b, kSrcCh, T, ncols};
-        igemm_launch(s, ctx->src_content_in.At, ctx->src_content_in.Mpad, ctx->src_content_in.Kpad, ncols, T, ld, ep);
+        if (TVC_SPLIT_SRC && ctx->src_content_in.MT6 % 2 == 0)
+            TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep)));
+        else
+            igemm_launch(s, ctx->src_content_in.At, ctx->src_content_in.Mpad, ctx->src_content_in.Kpad, ncols, T, ld, ep);
     }
     for (int i = 0; i < 3; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->src_mid[i], x, B, T));
     if (dry) return 0;
@@ -348,7 +351,10 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
         ProfScope ps(ctx, s, dry, "filter.in+down0");
         LoadPlain ld{content, kSslDim, T, (long)kSslDim * T};
         EpiSumCond ep{x, ctx->flt_content_in.bias, nullptr, f0, nullptr, nullptr, ctx->flt_f_w, ctx->flt_f_b, ch[0], T, B * T};
-        igemm_launch(s, ctx->flt_content_in.At, ctx->flt_content_in.Mpad, ctx->flt_content_in.Kpad, B * T, T, ld, ep);
+        if (TVC_SPLIT_SRC && ctx->flt_content_in.MT6 % 2 == 0)
+            TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep)));
+        else
+            igemm_launch(s, ctx->flt_content_in.At, ctx->flt_content_in.Mpad, ctx->flt_content_in.Kpad, B * T, T, ld, ep);
         if (TVC_DOWN0_SPLIT && (!xi_fused[1] || L % 5 == 0))   // downs[0] on the split-precision path; its epilogue also writes Downsample 1's 1/5-rate input
             TVC_CHECK(run_down0_split(ctx, s, ctx->flt_down0s, source, energy, skip[0], xi_fused[1] ? xi_pre[1] : nullptr, B, (int)L));
         else if (TVC_USE_C48)   // downs[0]: k3 conv over cat[source (16 ch), energy (1 ch)], read from the two tensors in place

@@ -237,6 +237,7 @@ struct EpiFilm {
 // content_in(content) + energy_in(e) + f0_in(log(relu(f0)+1e-6))   (decoder.py:128, :223)
 // e / lf0 are per-(b,t) scalars feeding 1->M 1x1 convs; `e` may be null (FilterNet has no energy).
 struct EpiSumCond {
+    static constexpr bool kIgemm = true;   // store(n, m, v[4]) interface (also usable from the split-precision kernel)
     float* y;
     const float* bias;
     const float* e;     // [B][T] or null
