@@ -428,20 +428,21 @@ template <class TL>
 __device__ __forceinline__ void film_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ F6, int MT, int mt0, int mtoff,
                                           const float* __restrict__ xb, int len, int s) {
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER;
-    constexpr int PIECES = 2 * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
-    static_assert(A_PER <= SlabRegs<TL>::A_MAX && TL::KG == 1, "FiLM weight pieces must fit the staging registers; FiLM kernels stage one channel group");
+    constexpr int KG = TL::KG, GP = 2 * MTB * 3, PIECES = KG * GP, A_PER = (PIECES + NW - 1) / NW;   // per 16-channel group: scale and shift pieces of MTB m-tiles
+    static_assert(A_PER <= SlabRegs<TL>::A_MAX, "FiLM weight pieces must fit the staging registers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (!(S_ABL & 2)) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int q = wave + i * NW;
             q = q < PIECES ? q : PIECES - 1;
-            const int grp = q / (MTB * 3), rem = q - grp * (MTB * 3);
-            r.ar[i] = ldg_so4(F6 + ((long)s * MT + mt0) * 192, 16u * (unsigned)(grp * mtoff * 192 + rem * 64 + lane));
+            const int kg = q / GP, q2 = q - kg * GP;
+            const int grp = q2 / (MTB * 3), rem = q2 - grp * (MTB * 3);
+            r.ar[i] = ldg_so4(F6 + ((long)s * KG * MT + mt0) * 192, 16u * (unsigned)((kg * MT + grp * mtoff) * 192 + rem * 64 + lane));
         }
     }
     if (S_ABL & 4) return;
-    const float* xc = xb + (long)s * 16 * len;
+    const float* xc = xb + (long)s * 16 * KG * len;
 #pragma unroll
     for (int i = 0; i < X_PER; ++i)
 #pragma unroll
@@ -459,13 +460,13 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
                                            int MT, int mt0, int mtoff, const float* __restrict__ xb, int Cin, int len, int t0, uint4* As, uint4* Xs,
                                            Next next) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
-    constexpr int PIECES = 2 * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
+    constexpr int KG = TL::KG, GP = 2 * MTB * 3, PIECES = KG * GP, A_PER = (PIECES + NW - 1) / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NWV, wn = wave - wm * NWV;
     SlabMap<TL> m;
     make_map<TL>(m, len, 0, t0);
-    const int nslab = Cin / 16;
+    const int nslab = Cin / (16 * KG);
     const uint4* as0 = As + wm * WM * 192 + lane;
     const uint4* xs0 = Xs + lh * XROW + wn * WN * 32 + l31;
     const int stg = TL::DB ? (int)(Xs - As) + TL::X_U4 : 0;      // u4 stride between the two staging buffers (same as the conv phase's)
@@ -517,34 +518,37 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
         }
         const uint4* as = as0 + (s & 1) * stg;
         const uint4* xs = xs0 + (s & 1) * stg;
-        bf16x8 fc[WM][3], fh[WM][3], bf[WN][3];
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int kg = 0; kg < KG; ++kg) {
+            bf16x8 fc[WM][3], fh[WM][3], bf[WN][3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[j][p] = __builtin_bit_cast(bf16x8, xs[2 * p * XROW + j * 32]);
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                fc[i][p] = __builtin_bit_cast(bf16x8, as[(i * 3 + p) * 64]);
-                fh[i][p] = __builtin_bit_cast(bf16x8, as[(MTB * 3 + i * 3 + p) * 64]);
-            }
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
+                for (int p = 0; p < 3; ++p) bf[j][p] = __builtin_bit_cast(bf16x8, xs[kg * TL::XG_U4 + 2 * p * XROW + j * 32]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    if (!(S_ABL & 1) || q == 0) {
-                        if (TRANS) {
-                            asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB[q]], fc[i][PA[q]], asc[i][j], 0, 0, 0);
-                            ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB[q]], fh[i][PA[q]], ash[i][j], 0, 0, 0);
-                        } else {
-                            asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[i][PA[q]], bf[j][PB[q]], asc[i][j], 0, 0, 0);
-                            ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i][PA[q]], bf[j][PB[q]], ash[i][j], 0, 0, 0);
+                for (int p = 0; p < 3; ++p) {
+                    fc[i][p] = __builtin_bit_cast(bf16x8, as[(kg * GP + i * 3 + p) * 64]);
+                    fh[i][p] = __builtin_bit_cast(bf16x8, as[(kg * GP + MTB * 3 + i * 3 + p) * 64]);
+                }
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        if (!(S_ABL & 1) || q == 0) {
+                            if (TRANS) {
+                                asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB[q]], fc[i][PA[q]], asc[i][j], 0, 0, 0);
+                                ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB[q]], fh[i][PA[q]], ash[i][j], 0, 0, 0);
+                            } else {
+                                asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[i][PA[q]], bf[j][PB[q]], asc[i][j], 0, 0, 0);
+                                ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i][PA[q]], bf[j][PB[q]], ash[i][j], 0, 0, 0);
+                            }
                         }
-                    }
+        }
         if (TL::DB) __builtin_amdgcn_sched_barrier(0);
         if (TL::DB && !early) stage_next();
     }
@@ -1034,7 +1038,7 @@ template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = fa
 inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
                            const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond, long xstride = 0, int bpc = S_BPC,
                            const float* kscale = nullptr, bool flat = false, int cmax = 0, int lin = 0, float lscale = 0.f) {
-    if (Cin % (16 * TL::KG) != 0 || (FILM && Ccond % 16 != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of the slab depth");
+    if (Cin % (16 * TL::KG) != 0 || (FILM && Ccond % (16 * TL::KG) != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of the slab depth");
     if (Cin / 16 > w.S6) return fail(ctx, TVC_ERR_ARG, "conv3s: weight image has fewer K16 steps than the launch walks");
     static bool ready_dev[64] = {};                 // the attribute is per (function, device): one flag per device of this process
     bool& ready = ready_dev[ctx->device & 63];
@@ -1118,6 +1122,9 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
 #ifndef TVC_SF_NWV
 #define TVC_SF_NWV 4
 #endif
+#ifndef TVC_SF_KG
+#define TVC_SF_KG 1   // FiLM-fused kernels: 16-channel groups per staged slab (conv and FiLM phases); 2 measured -0.03 ms with 48 B of scratch: not worth it
+#endif
 #ifndef TVC_SF_WN
 #define TVC_SF_WN 1
 #endif
@@ -1142,8 +1149,13 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
                                                                                                      nullptr, false, 0, lin, lscale);
     }
     if constexpr (FILM)
+    {
+        if (TVC_SF_KG == 2 && Cin % 32 == 0 && Ccond % 32 == 0)   // 32-channel slabs: half the staging round trips, twice the MFMAs per barrier pair
+            return conv3s_launch_t<SplitTile<3, TVC_SF_WM, TVC_SF_NWV, TVC_SF_WN, 2>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond,
+                                                                                                                       Ccond, 0, S_BPC, nullptr, false, 0, lin, lscale);
         return conv3s_launch_t<SplitTile<3, TVC_SF_WM, TVC_SF_NWV, TVC_SF_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0,
                                                                                                                 S_BPC, nullptr, false, 0, lin, lscale);
+    }
     else
         return conv3s_launch_t<SplitTile<3, TVC_S_WM, TVC_S_NWV, TVC_S_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC,
                                                                                                              nullptr, false, 0, lin, lscale);
