@@ -30,6 +30,9 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 #ifndef U24S_ABL
 #define U24S_ABL 0   // timing ablations (wrong results): 1 no S1 MFMA, 2 no S2 conv MFMA, 4 no FiLM MFMA, 8 no deposit, 16 no S1 epilogue, 32 no S4, 64 no fetch, 128 no S2 epilogue
 #endif
+#ifndef U24S_S4VEC
+#define U24S_S4VEC 1   // output conv reads its 10 activations per channel as three 16-byte LDS reads on interior tiles
+#endif
 #ifndef U24S_WPE
 #define U24S_WPE 2     // 8 waves per CU: 256 registers each
 #endif
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
             const int part = tid & 7;
             const int lo = -p20 > 0 ? -p20 : 0;
             const int hi = (len - 1 - p20) < (CF::W2 - 1) ? (len - 1 - p20) : (CF::W2 - 1);
+            const bool interior = lo == 0 && hi == CF::W2 - 1;      // no replicate padding inside this tile
             for (int g0 = 0; g0 < (W + 3) / 4; g0 += NT / 8) {      // uniform trip count: the shuffles need every lane
                 const int g = g0 + (tid >> 3);
                 float o4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -341,8 +345,16 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                     for (int cc = 0; cc < 3; ++cc) {
                         const int c = part * 3 + cc;
                         float xv[10], wv[7];
+                        if (U24S_S4VEC && E == 3 && interior) {   // columns 4 g .. 4 g + 11 of the row: three 16-byte reads instead of ten 4-byte ones
+                            const f32x4s* rp = reinterpret_cast<const f32x4s*>(R + c * PS + 4 * g);
+                            const f32x4s r0 = rp[0], r1 = rp[1], r2 = rp[2];
+                            xv[0] = r0[0]; xv[1] = r0[1]; xv[2] = r0[2]; xv[3] = r0[3];
+                            xv[4] = r1[0]; xv[5] = r1[1]; xv[6] = r1[2]; xv[7] = r1[3];
+                            xv[8] = r2[0]; xv[9] = r2[1];
+                        } else {
 #pragma unroll
-                        for (int i = 0; i < 10; ++i) xv[i] = R[c * PS + cols[i]];
+                            for (int i = 0; i < 10; ++i) xv[i] = R[c * PS + cols[i]];
+                        }
 #pragma unroll
                         for (int j = 0; j < 7; ++j) wv[j] = W7[c * 7 + j];
 #pragma unroll
