@@ -131,6 +131,16 @@ int tvc_decoder_stages_f32(tvc_ctx* ctx, void* stream, const float* content, con
                            float* wave, float* amps, float* kernel, float* source, int B, int T,
                            void* ws, size_t ws_bytes);
 
+/* FilterNet.forward (reference module/tinyvc/decoder.py:222-233): content [B,768,T], f0 [B,1,T], energy [B,1,L],
+ * source [B,16,L] (Decoder.dsp's output) -> wave [B, L].  For parity tests the block outputs can be copied out:
+ * skips[i] (i = 0..4, any entry or the array itself may be NULL) = the outputs of `downs[i]` (decoder.py:227-229):
+ * [B,24,L], [B,48,L/5], [B,96,L/20], [B,192,L/80], [B,384,L/240]; ups[i] (i = 0..3) = the outputs of `ups[i]`
+ * (decoder.py:231-232): [B,192,2T], [B,96,6T], [B,48,24T], [B,24,96T].  ups[4] does not exist in this implementation:
+ * its 1x1 (c5) is folded into output_layer's k7 conv when the weights are packed, and `wave` is what checks it. */
+int tvc_filter_net_f32(tvc_ctx* ctx, void* stream, const float* content, const float* f0, const float* energy,
+                       const float* source, float* wave, float* const* skips, float* const* ups, int B, int T,
+                       void* ws, size_t ws_bytes);
+
 /* Decoder.dsp (reference module/tinyvc/decoder.py:259-266): f0 [B,1,T], amps [B,15,T],
  * kernel [B,961,T], noise_angle as above -> source [B,16,L] (15 harmonics + filtered noise). */
 int tvc_dsp_f32(tvc_ctx* ctx, void* stream, const float* f0, const float* amps, const float* kernel,

@@ -215,8 +215,9 @@ def filter_upsample(sd, p, x, c, factor):
     return F.conv1d(x, sd[p + ".c5.weight"], sd[p + ".c5.bias"])
 
 
-def filter_net(sd, content, f0, energy, source, return_skips=False):
-    """reference module/tinyvc/decoder.py:222-233 -> [B, 1, L]."""
+def filter_net(sd, content, f0, energy, source, return_skips=False, return_blocks=False):
+    """reference module/tinyvc/decoder.py:222-233 -> [B, 1, L] (return_blocks: also the five Downsample
+    outputs `skips` and the five Upsample outputs `ups`, decoder.py:227-232)."""
     p = "filter_net"
     x = (F.conv1d(content, sd[p + ".content_in.weight"], sd[p + ".content_in.bias"])
          + F.conv1d(torch.log(F.relu(f0) + 1e-6), sd[p + ".f0_in.weight"], sd[p + ".f0_in.bias"]))
@@ -225,9 +226,13 @@ def filter_net(sd, content, f0, energy, source, return_skips=False):
     down_f = list(reversed(FILTER_FACTORS[1:]))
     for i, f in enumerate(down_f, start=1):
         skips.append(filter_downsample(sd, f"{p}.downs.{i}", skips[-1], f))
+    ups = []
     for i, f in enumerate(FILTER_FACTORS):
         x = filter_upsample(sd, f"{p}.ups.{i}", x, skips[len(skips) - 1 - i], f)
+        ups.append(x)
     out = conv1d_rep(x, sd[p + ".output_layer.weight"], sd[p + ".output_layer.bias"], 1)
+    if return_blocks:
+        return out, skips, ups
     if return_skips:
         return out, skips
     return out

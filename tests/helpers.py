@@ -17,7 +17,7 @@ def convert_inputs(g):
     """Inputs of a `convert_*` fixture, rebuilt from the seeds it records."""
     wf = synth.synth_wave(int(g["batch"]), int(g["wave_len"]), seed=int(g["wave_seed"]))
     tgt = synth.synth_index(int(g["index_size"]), seed=int(g["index_seed"]))
-    frames = g["spec"].shape[2]
+    frames = g["wave"].shape[1] // 480
     angle = synth.synth_angle(int(g["batch"]), frames, int(g["noise_seed"]))
     return wf, tgt, float(g["pitch_shift"]), angle
 
@@ -38,3 +38,21 @@ def rms(a):
 
 def rel_rms(a, ref):
     return rms(torch.as_tensor(a).double() - torch.as_tensor(ref).double()) / max(rms(ref), 1e-30)
+
+
+def stage(g, name):
+    """(tensor, time stride) of a stored stage output.  Round-1 fixtures keep the encoder-side tensors whole and
+    decimate the full-rate ones by `decim`; the headline-length fixtures (convert_cfg*) store `<name>_d` with its own
+    `<name>_stride` (tools/gen_golden.py)."""
+    if name in g:
+        return torch.from_numpy(np.asarray(g[name])), 1
+    if name + "_stride" in g:
+        return torch.from_numpy(np.asarray(g[name + "_d"])), int(g[name + "_stride"])
+    dm = int(g["decim"])
+    if name.startswith("skip"):
+        st = dm if int(name[4:]) < 2 else 1
+    elif name.startswith("up"):
+        st = dm if int(name[2:]) >= 3 else 1
+    else:
+        st = dm
+    return torch.from_numpy(np.asarray(g[name + "_d"])), st

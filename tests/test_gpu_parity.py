@@ -72,7 +72,7 @@ def test_front_end(models, case):
     wf, _tgt, _s, _a = convert_inputs(g)
     wfp = utils.autopad_waveform(wf.to(DEV))
     assert wfp.shape[1] % 480 == 0 and wfp.shape[1] == g["wave"].shape[1]
-    check("spectrogram", utils.spectrogram(wfp), g["spec"], 2e-6)
+    check("spectrogram", utils.spectrogram(wfp), g["spec"], 1.5e-6)       # measured 1.5e-7
     check("estimate_energy", utils.estimate_energy(wfp), g["energy"], 1e-7, atol=1e-6)
 
 
@@ -82,12 +82,12 @@ def test_encoder(models, case):
     g = load_golden(case)
     spec = _t(g["spec"]).to(DEV)
     ssl, logits = enc.forward(spec)
-    check("ssl", ssl, g["ssl"], 2e-5)
-    check("pitch logits", logits, g["logits"], 2e-5)
+    check("ssl", ssl, g["ssl"], 1e-5)                                   # measured 1.1e-6
+    check("pitch logits", logits, g["logits"], 3e-6)                   # measured 5e-8 .. 3e-7
     ssl2, f0 = enc.infer(spec)
     assert torch.equal(ssl, ssl2)
     # f0 decode on the oracle's own logits isolates the decode kernel from GEMM rounding
-    check("f0", f0, g["f0"], 1e-4)
+    check("f0", f0, g["f0"], 7e-6)                                      # measured 7e-7
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -151,14 +151,14 @@ def test_decoder_stages(models, case):
     content, f0s, energy = (_t(g[k]).to(DEV) for k in ("matched", "f0s", "energy"))
     eng = dec.engine(DEV)
     wave, amps, kern, source = eng.decoder(content, f0s, energy, angle.to(DEV), stages=True)
-    check("amps", amps, g["amps"], 2e-5)
-    check("kernel", kern, g["kernel"], 2e-5)
+    check("amps", amps, g["amps"], 2e-6)                                # measured 1.8e-7
+    check("kernel", kern, g["kernel"], 2e-6)                            # measured 2.1e-7
     # the DSP on the oracle's own amps / kernel: isolates the oscillator + iSTFT kernels
     src2 = dec.dsp(f0s, _t(g["amps"]).to(DEV), _t(g["kernel"]).to(DEV), angle.to(DEV))
-    check("harmonics*amps (oracle in)", src2[:, :15, ::dm], g["source_d"][:, :15], 2e-6, atol=2e-5)
-    check("noise (oracle in)", src2[:, 15], g["noise"], 5e-6)
-    check("source", source[:, :, ::dm], g["source_d"], 1e-4)
-    check("decoder wave", wave, g["wave"], 1e-3)
+    check("harmonics*amps (oracle in)", src2[:, :15, ::dm], g["source_d"][:, :15], 3.5e-7, atol=2.5e-6)   # measured 3.4e-8 / 2.4e-7
+    check("noise (oracle in)", src2[:, 15], g["noise"], 2e-6)            # measured 2.0e-7
+    check("source", source[:, :, ::dm], g["source_d"], 2e-6)             # measured 1.6e-7
+    check("decoder wave", wave, g["wave"], 2.5e-6, atol=2.5e-6)         # measured 2.4e-7 / 2.1e-7
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -170,7 +170,7 @@ def test_convert_end_to_end(models, case):
     ref = _t(g["wave"])
     d = (wave.cpu() - ref)
     _log(f"[parity] convert {case}: abs rms diff {rms(d):.3e} (north_star gate 1e-4), wave rms {rms(ref):.3e}")
-    check("convert wave", wave, ref, 1e-3)
+    check("convert wave", wave, ref, 7e-4)                                # = the 1e-4 absolute gate below at wave rms 0.16
     assert rms(d) <= 1e-4, f"waveform rms difference {rms(d):.3e} exceeds the 1e-4 gate"
 
 
@@ -236,11 +236,15 @@ def test_streaming(models, case, pv):
         shift = int(st.last_shift[0])
         _log(f"[parity] stream block {i}: shift {shift} (ref {int(g['shift'][i])})")
         assert shift == int(g["shift"][i])
-        check(f"stream block {i}", out, g["out"][i], 1e-2 if pv else 1e-3)   # phase vocoder: atan2 of near-empty bins
+        # end-to-end blocks carry the f0 conditioning of convert (measured <= 3.9e-4 rel = 5.5e-5 abs); the phase vocoder's first
+        # block cross-fades against an all-zero sola buffer (atan2 of empty bins): measured 2.3e-3
+        check(f"stream block {i}", out, g["out"][i], 1e-2 if (pv and i == 0) else 1e-3)
+        assert pv and i == 0 or rms(out.cpu() - _t(g["out"][i])) <= 1e-4
 
 
 def test_streaming_hip_graph_replay_matches_eager(models):
-    """Graph-captured per-block pipeline == eager pipeline, block for block (same torch CUDA RNG seed)."""
+    """Graph-captured per-block pipeline == eager pipeline, sample for sample: the noise phases are injected into a static
+    buffer the captured step reads, so both modes see identical inputs."""
     from tinyvc_amd.module.infer import BatchedStreamInfer
     _enc, _dec, gen = models
     tgt = synth.synth_index(500, seed=2).to(DEV)
@@ -250,19 +254,55 @@ def test_streaming_hip_graph_replay_matches_eager(models):
         st = BatchedStreamInfer(gen, n_streams=3, target=tgt, device=torch.device(DEV), block_size=1920, extra_size=3840,
                                 use_graph=use_graph)
         st.init_buffer()
-        torch.manual_seed(123)
         res, shifts = [], []
         for i in range(8):
-            res.append(st.audio_callback(blocks[:, i]).clone())
+            angle = synth.synth_angle(3, st.input_size // 480, 700 + i).to(DEV)
+            res.append(st.audio_callback(blocks[:, i], noise_angle=angle).clone())
             shifts.append(st.last_shift.clone())
         outs[use_graph] = (torch.stack(res), torch.stack(shifts))
-    # blocks 0-1 are eager in both runs; from block 2 on the second run replays the graph.  The noise
-    # phases come from torch's CUDA generator in both modes but at different philox offsets, so compare
-    # the deterministic part of the pipeline: SOLA lags and signal statistics must agree closely.
-    assert torch.equal(outs[False][0][:2], outs[True][0][:2])
-    assert torch.isfinite(outs[True][0]).all()
-    r0, r1 = rms(outs[False][0][2:]), rms(outs[True][0][2:])
-    assert abs(r0 - r1) / r0 < 0.05, (r0, r1)
+        if use_graph:
+            assert st._graph is not None and True in st._graph[1], "blocks 3.. must have replayed the captured graph"
+    assert torch.equal(outs[False][1], outs[True][1]), "SOLA lags differ between eager and graph replay"
+    assert torch.equal(outs[False][0], outs[True][0]), "graph replay is not sample-exact"
+    # default mode (phases drawn inside the graph from torch's CUDA generator): finite, same signal level
+    st = BatchedStreamInfer(gen, n_streams=3, target=tgt, device=torch.device(DEV), block_size=1920, extra_size=3840, use_graph=True)
+    st.init_buffer()
+    drawn = torch.stack([st.audio_callback(blocks[:, i]).clone() for i in range(8)])
+    assert torch.isfinite(drawn).all()
+    assert abs(rms(drawn[2:]) - rms(outs[False][0][2:])) / rms(outs[False][0][2:]) < 0.05
+
+
+def test_streaming_graph_is_recaptured_when_its_pointers_go_stale(models):
+    """A captured step bakes in the workspace and weight-arena addresses.  A bigger convert on the same Generator
+    re-allocates the workspace and a parameter edit re-packs (and frees) the arena: the next block must notice, capture
+    again and still equal the eager result."""
+    from tinyvc_amd.module.infer import BatchedStreamInfer, Generator
+    from tinyvc_amd.module.tinyvc import Decoder, Encoder
+    enc_sd, dec_sd = state_dicts(0)
+    enc, dec = Encoder(), Decoder()
+    enc.load_state_dict(enc_sd)
+    dec.load_state_dict(dec_sd)
+    gen = Generator(enc, dec).to(DEV)
+    tgt = synth.synth_index(300, seed=2).to(DEV)
+    blocks = synth.synth_wave(2, 10 * 1920, seed=60).view(2, 10, 1920).to(DEV)
+    runs = {}
+    for use_graph in (False, True):
+        dec.load_state_dict(dec_sd)
+        st = BatchedStreamInfer(gen, n_streams=2, target=tgt, device=torch.device(DEV), block_size=1920, extra_size=3840, use_graph=use_graph)
+        st.init_buffer()
+        res, keys = [], []
+        for i in range(10):
+            if i == 5:    # a much larger batch through the same engine: the workspace is re-allocated
+                gen.convert(synth.synth_wave(16, 48000, seed=1).to(DEV), tgt, 0.0)
+            if i == 7:    # in-place weight edit: weights re-packed, the old arena freed
+                with torch.no_grad():
+                    dec.filter_net.output_layer.bias.add_(0.01)
+            res.append(st.audio_callback(blocks[:, i], noise_angle=synth.synth_angle(2, st.input_size // 480, 800 + i).to(DEV)).clone())
+            keys.append(st._graph[0] if st._graph else None)
+        runs[use_graph] = torch.stack(res)
+        if use_graph:
+            assert keys[4] is not None and keys[5] != keys[4] and keys[7] != keys[6], "stale graph was not re-captured"
+    assert torch.equal(runs[False], runs[True])
 
 
 def test_cpu_tensor_to_gpu_model_and_errors(models):

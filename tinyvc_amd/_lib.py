@@ -34,6 +34,7 @@ SIGNATURES = {
     "tvc_shift_frequency_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float]),
     "tvc_decoder_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_decoder_stages_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
+    "tvc_filter_net_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_void_p, c_size_t]),
     "tvc_dsp_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_convert_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_uint64, c_void_p, c_int, c_int64, c_void_p, c_size_t]),
     "tvc_sola_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int]),

@@ -254,7 +254,10 @@ struct Packer {
         const HostTensor* b = find(name + ".bias");
         if (!w || !b) return;
         const int C = 24, CI = 17;
-        if (w->data.size() != (size_t)C * CI * 3 || b->data.size() != (size_t)C) return;
+        if (w->data.size() != (size_t)C * CI * 3 || b->data.size() != (size_t)C) {
+            if (missing.empty()) missing = name + " (unexpected shape for the split-precision downs.0 blob)";
+            return;
+        }
         std::vector<float> img(15 * 256 + 32, 0.f);
         uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
         auto to_bf16 = [](float f) -> uint16_t {
@@ -293,10 +296,16 @@ struct Packer {
         const HostTensor* w = find(name + ".weight");
         const HostTensor* b = find(name + ".bias");
         const HostTensor* eb = extra_bias.empty() ? nullptr : find(extra_bias);
-        if (!extra_bias.empty() && (!eb || eb->data.size() != (size_t)M)) return;
+        if (!extra_bias.empty() && (!eb || eb->data.size() != (size_t)M)) {
+            if (missing.empty()) missing = extra_bias + " (wrong size)";
+            return;
+        }
         if (!w || !b) return;
         const int CI = 24, MT = (M + 31) / 32;
-        if (w->data.size() != (size_t)M * CI * 3 || b->data.size() != (size_t)M) return;
+        if (w->data.size() != (size_t)M * CI * 3 || b->data.size() != (size_t)M) {
+            if (missing.empty()) missing = name + " (unexpected shape for the 24-channel split-precision blob)";
+            return;
+        }
         std::vector<float> img((size_t)15 * MT * 256 + 64, 0.f);
         uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
         auto to_bf16 = [](float f) -> uint16_t {
@@ -790,6 +799,19 @@ int tvc_decoder_stages_f32(tvc_ctx* ctx, void* stream, const float* content, con
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(run_decoder(ctx, s, ws, true, content, f0, energy, noise_angle, seed, wave, amps, kernel, source, B, T),
             run_decoder(ctx, s, ws, false, content, f0, energy, noise_angle, seed, wave, amps, kernel, source, B, T));
+}
+
+int tvc_filter_net_f32(tvc_ctx* ctx, void* stream, const float* content, const float* f0, const float* energy, const float* source,
+                       float* wave, float* const* skips, float* const* ups, int B, int T, void* wsp, size_t ws_bytes) {
+    TVC_CHECK(need_ready(ctx, NEED_DEC));
+    if (!content || !f0 || !energy || !source || !wave || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_filter_net_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    FilterTaps taps;
+    for (int i = 0; i < 5 && skips; ++i) taps.skips[i] = skips[i];
+    for (int i = 0; i < 4 && ups; ++i) taps.ups[i] = ups[i];
+    TVC_RUN(run_filter(ctx, s, ws, true, content, f0, energy, source, wave, B, T, nullptr),
+            run_filter(ctx, s, ws, false, content, f0, energy, source, wave, B, T, &taps));
 }
 
 int tvc_dsp_f32(tvc_ctx* ctx, void* stream, const float* f0, const float* amps, const float* kernel, const float* noise_angle,

@@ -322,8 +322,8 @@ static void conv_launch(hipStream_t s, const PackedW& w, const float* x, int cin
 #define TVC_SPLIT48 1   // 48-channel levels on the split path too (rows padded 48 -> 64; with the stacked FiLM phase ups.3 1.49 -> 1.25 ms)
 #endif
 
-static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
-                      const float* energy, const float* source, float* wave, int B, int T) {
+int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
+               const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps) {
     const long L = (long)T * kHop;
     static const int ch[5] = {384, 192, 96, 48, 24};
     // level lengths: skip i lives at len_dn[i]
@@ -557,6 +557,17 @@ static int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float
     if (!dry && !fused_out) {
         ProfScope ps(ctx, s, dry, "filter.out");
         TVC_CHECK(run_out_conv7(ctx, s, x, ctx->flt_out_w, ctx->flt_out_b, wave, B, 24, (int)L));
+    }
+    if (!dry && taps) {   // parity taps: the block outputs are still live in the workspace
+        for (int i = 0; i < 5; ++i)
+            if (taps->skips[i])
+                TVC_HIP(ctx, hipMemcpyAsync(taps->skips[i], skip[i], (size_t)B * ch[4 - i] * len_dn[i] * sizeof(float), hipMemcpyDeviceToDevice, s));
+        long l = T;
+        for (int i = 0; i < 4; ++i) {
+            l *= ctx->ups[i].factor;
+            if (taps->ups[i])
+                TVC_HIP(ctx, hipMemcpyAsync(taps->ups[i], xlev[i], (size_t)B * ctx->ups[i].cout * l * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
     }
     return dry ? 0 : launch_check(ctx, "filter_net");
 }

@@ -233,7 +233,10 @@ static __global__ __launch_bounds__(256) void pitch_decode_kernel(const float* _
     const float* p = logits + (long)b * kPitchClasses * T + t;
     PTop4 top;
     top.init();
-    for (int c = wave * (kPitchClasses / 4); c < (wave + 1) * (kPitchClasses / 4); ++c) top.insert(p[(long)c * T], c);
+    for (int c = wave * (kPitchClasses / 4); c < (wave + 1) * (kPitchClasses / 4); ++c) {
+        const float x = p[(long)c * T];
+        top.insert(x != x ? INFINITY : x, c);   // torch.topk orders NaN first; also keeps the list sentinel out of freq[]
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) { sv[wave][lane][e] = top.v[e]; si[wave][lane][e] = top.i[e]; }
     __syncthreads();
@@ -241,6 +244,8 @@ static __global__ __launch_bounds__(256) void pitch_decode_kernel(const float* _
     for (int w = 1; w < 4; ++w)
 #pragma unroll
         for (int e = 0; e < 4; ++e) top.insert(sv[w][lane][e], si[w][lane][e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) top.i[e] = (unsigned)top.i[e] < (unsigned)kPitchClasses ? top.i[e] : 0;
     const float v0 = top.v[0];
     float e0 = 1.f, e1 = expf(top.v[1] - v0), e2 = expf(top.v[2] - v0), e3 = expf(top.v[3] - v0);
     float den = ((e0 + e1) + e2) + e3;

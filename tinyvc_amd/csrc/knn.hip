@@ -112,6 +112,11 @@ static __global__ __launch_bounds__(256) void query_normalize_kernel(const float
     for (int k = k0; k < k1; ++k) q[(long)k * T] = p[(long)k * T] / den;
 }
 
+// torch.topk orders NaN above every number; a query column with NaN / Inf samples upstream makes every similarity NaN.
+// Mapping NaN to +inf keeps that order (ties -> lowest index, so such a column selects rows 0..3 like any all-equal
+// column) and, more to the point, keeps the 0x7fffffff list sentinel from ever reaching the row gather.
+__device__ __forceinline__ float nan_max(float x) { return x != x ? INFINITY : x; }
+
 struct Top4 {
     float v[4];
     int i[4];
@@ -217,7 +222,7 @@ static __global__ __launch_bounds__(KNN_WAVES * 64) void knn_topk_kernel(const f
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < N) top[j].insert(acc[i][j][r], row);
+                    if (row < N) top[j].insert(nan_max(acc[i][j][r]), row);
                 }
     }
 
@@ -364,7 +369,7 @@ static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const uint4*
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < N) top.insert(acc[i][r], row);
+                    if (row < N) top.insert(nan_max(acc[i][r]), row);
                     acc[i][r] = 0.f;
                 }
         }
@@ -402,7 +407,7 @@ static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const uint4*
 // gather the 4 raw rows per query (coalesced along the feature axis), average, and write
 // out[b][k][t] through an LDS transpose so stores run along t.
 static __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
-                                                                      int nsplit, int ncols, int T,
+                                                                      int nsplit, int ncols, int T, int N,
                                                                       const float* __restrict__ rows,
                                                                       float* __restrict__ out, int64_t* __restrict__ idx_out) {
     __shared__ int sel[32][4];
@@ -418,6 +423,7 @@ static __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const floa
                 long o = ((long)s * ncols + n) * 4;
                 for (int e = 0; e < 4; ++e) t4.insert(cand_v[o + e], cand_i[o + e]);
             }
+            for (int e = 0; e < 4; ++e) t4.i[e] = (unsigned)t4.i[e] < (unsigned)N ? t4.i[e] : 0;   // never gather through a sentinel
             if (idx_out)
                 for (int e = 0; e < 4; ++e) idx_out[(long)n * 4 + e] = (int64_t)t4.i[e];
         }
@@ -570,7 +576,7 @@ int run_knn(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, con
         hipLaunchKernelGGL(knn_topk_kernel, dim3((unsigned)(qtiles * nsplit)), dim3(KNN_WAVES * 64), 0, s, prepared, Npad, (int)N, qn,
                            ncols, T, nsplit, tps, cv, ci);
     }
-    hipLaunchKernelGGL(knn_merge_gather_kernel, dim3((ncols + 31) / 32), dim3(256), 0, s, cv, ci, nsplit, ncols, T,
+    hipLaunchKernelGGL(knn_merge_gather_kernel, dim3((ncols + 31) / 32), dim3(256), 0, s, cv, ci, nsplit, ncols, T, (int)N,
                        prepared + (size_t)KD * Npad, out, idx_out);
     return launch_check(ctx, "knn_match");
 }

@@ -222,6 +222,12 @@ int run_shift(tvc_ctx*, hipStream_t, const float* f0, float* out, int64_t n, flo
 int run_decoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* content, const float* f0,
                 const float* energy, const float* angle, uint64_t seed, float* wave, float* amps_out,
                 float* kernel_out, float* source_out, int B, int T);
+struct FilterTaps {   // optional copies of FilterNet's block outputs (tvc_filter_net_f32)
+    float* skips[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* ups[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+int run_filter(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* content, const float* f0, const float* energy,
+               const float* source, float* wave, int B, int T, const FilterTaps* taps = nullptr);
 int run_dsp(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* f0, const float* amps, const float* kern,
             const float* angle, uint64_t seed, float* source, int B, int T);
 int run_sola(tvc_ctx*, hipStream_t, const float* y, float* sola_buf, const float* fade_in, float* out, int32_t* shift_out,

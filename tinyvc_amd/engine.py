@@ -247,6 +247,34 @@ class Engine:
                                                  _ptr(amps), _ptr(kern), _ptr(source), B, T, p, n), "tvc_decoder_stages_f32")
         return wave, amps, kern, source
 
+    def filter_net(self, content, f0, energy, source, blocks=False):
+        """FilterNet.forward -> wave [B, L]; blocks=True also returns (skips[5], ups[4]): the Downsample / Upsample
+        block outputs of decoder.py:227-232 (ups[4] is folded into the output conv, see tvc_filter_net_f32)."""
+        content = _prep(content, "content", self.device)
+        f0 = _prep(f0, "f0", self.device)
+        energy = _prep(energy, "energy", self.device)
+        source = _prep(source, "source", self.device)
+        B, C, T = content.shape
+        L = T * spec.HOP
+        if C != spec.SSL_DIM or tuple(f0.shape) != (B, 1, T) or tuple(energy.shape) != (B, 1, L) or tuple(source.shape) != (B, 16, L):
+            raise ValueError("filter_net shapes: content [B,768,T], f0 [B,1,T], energy [B,1,T*480], source [B,16,T*480]")
+        wave = torch.empty(B, L, dtype=_F32, device=self.device)
+        p, n = self._wsargs(B, L)
+        skips, ups, sk, up = None, None, None, None
+        if blocks:
+            ch, fac = spec.FILTER_CHANNELS, spec.FILTER_FACTORS
+            dn = [L, L // 5, L // 20, L // 80, L // 240]
+            skips = [torch.empty(B, ch[4 - i], dn[i], dtype=_F32, device=self.device) for i in range(5)]
+            ups, l = [], T
+            for i in range(4):
+                l *= fac[i]
+                ups.append(torch.empty(B, ch[i + 1], l, dtype=_F32, device=self.device))
+            sk = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in skips])
+            up = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ups])
+        self._ok(self.lib.tvc_filter_net_f32(self.ctx, self._stream(), _ptr(content), _ptr(f0), _ptr(energy), _ptr(source), _ptr(wave),
+                                             sk, up, B, T, p, n), "tvc_filter_net_f32")
+        return (wave, skips, ups) if blocks else wave
+
     def dsp(self, f0, amps, kernel, noise_angle=None):
         f0 = _prep(f0, "f0", self.device)
         amps = _prep(amps, "amps", self.device)

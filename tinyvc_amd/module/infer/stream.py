@@ -55,27 +55,55 @@ class BatchedStreamInfer:
         return eng.sola(y, self.sola_buffer, self.fade_in_window, self.block_size,
                         self.use_phase_vocoder, want_shift=True)
 
+    def _graph_key(self):
+        """Everything a captured step bakes in as raw device pointers: the packed weights (re-packed - and the old arena
+        freed - when a parameter changes), the engine's scratch workspace (re-allocated when another call needs a bigger
+        one), the prepared index riding on `target`, plus the scalars captured by value."""
+        eng = self.generator.engine(self.device)          # re-packs the weights first if a parameter changed
+        ws, tgt = eng._ws, self.target
+        return (eng.weights_key, ws.data_ptr() if ws is not None else 0, ws.numel() if ws is not None else 0,
+                id(tgt), tgt._version, tgt.data_ptr(), float(self.pitch_shift), bool(self.use_phase_vocoder))
+
     @torch.no_grad()
     def audio_callback(self, blocks, noise_angle=None):
         """blocks [S, block_size] -> converted blocks [S, block_size]."""
         blocks = blocks.to(self.device)
         self._calls += 1
-        if not self.use_graph or noise_angle is not None or self._calls <= 2:
+        if not self.use_graph or self._calls <= 2:
             out, shift = self._step(blocks, noise_angle)
             self.last_shift = shift
             return out
+        key = self._graph_key()
+        if self._graph is not None and key != self._graph[0]:
+            self._graph = None        # stale pointers inside the captured graphs: drop them and capture again
         if self._graph is None:
+            self._graph = (key, {})
             self._g_in = torch.zeros(self.n_streams, self.block_size, device=self.device)
+            self._g_angle = torch.zeros(self.n_streams, 961, self.input_size // 480, device=self.device)
+        inject = noise_angle is not None      # injected phases replay from a static buffer; otherwise the draw is part of the graph
+        graphs = self._graph[1]
+        if inject not in graphs:
             self._g_in.copy_(blocks)
+            if inject:
+                self._g_angle.copy_(noise_angle)
+            # capture changes no state: the buffer roll, convert and SOLA are recorded, not run
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._g_out, self._g_shift = self._step(self._g_in, None)
-            self._graph = g          # capture does not execute: fall through to the first replay
+                res = self._step(self._g_in, self._g_angle if inject else None)
+            graphs[inject] = (g, res)
+            if self._graph_key() != key:      # the capture itself grew the workspace: what it recorded is already stale
+                self._graph = None
+                out, shift = self._step(blocks, noise_angle)
+                self.last_shift = shift
+                return out
         self._g_in.copy_(blocks)
-        self._graph.replay()
-        self.last_shift = self._g_shift
-        return self._g_out.clone()
+        if inject:
+            self._g_angle.copy_(noise_angle)
+        g, (g_out, g_shift) = graphs[inject]
+        g.replay()
+        self.last_shift = g_shift
+        return g_out.clone()
 
 
 class StreamInfer(BatchedStreamInfer):

@@ -78,6 +78,11 @@ class FilterNet(nn.Module):
         self.ups = nn.ModuleList([Upsample(c, n, c, f) for c, n, f in S.filter_up_plan()])
         self.output_layer = nn.Conv1d(channels[-1], 1, 7, 1, 3, padding_mode="replicate")
 
+    @torch.no_grad()
+    def forward(self, content, f0, energy, source):    # decoder.py:222-233 -> [B, 1, L]
+        dec = self.__dict__["_decoder"]
+        return dec.engine(content.device).filter_net(content, f0, energy, source).unsqueeze(1)
+
 
 class Decoder(HipModule):
     def __init__(self, sample_rate=24000, n_fft=1920, frame_size=480, num_harmonics=14):
@@ -91,6 +96,7 @@ class Decoder(HipModule):
         self.source_net = SourceNet(frame_size=frame_size, sample_rate=sample_rate, n_fft=n_fft)
         self.filter_net = FilterNet()
         self.source_net.__dict__["_decoder"] = self
+        self.filter_net.__dict__["_decoder"] = self
 
     @staticmethod
     def draw_noise_angle(batch, frames, device):

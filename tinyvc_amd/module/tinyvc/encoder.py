@@ -37,6 +37,9 @@ class PitchEstimator(_Estimator):
         _only_default("internal_channels", internal_channels, S.PITCH_CH)
         _only_default("num_layers", num_layers, S.PITCH_LAYERS)
         _only_default("num_classes", num_classes, S.PITCH_CLASSES)
+        # the class -> Hz table uploaded to the decode kernel and its 20 Hz voicing threshold are built from these two
+        _only_default("classes_per_octave", classes_per_octave, S.PITCH_CPO)
+        _only_default("min_frequency", float(min_frequency), float(S.PITCH_FMIN))
         super().__init__(n_fft // 2 + 1, internal_channels, [1] * num_layers, num_classes)
         self.num_classes = num_classes
         self.classes_per_octave = classes_per_octave
