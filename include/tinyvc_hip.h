@@ -79,6 +79,11 @@ int tvc_energy_f32(tvc_ctx* ctx, void* stream, const float* wav, float* energy, 
 int tvc_encoder_f32(tvc_ctx* ctx, void* stream, const float* spec, float* ssl, float* f0,
                     float* logits, int B, int T, void* ws, size_t ws_bytes);
 
+/* PitchEstimator.decode (reference module/tinyvc/encoder.py:61-67, with id2freq :48-54 as the uploaded table):
+ * logits [B,512,T] -> f0 [B,1,T] (top-4 classes, softmax over their logits, expectation of the class frequencies,
+ * <= 20 Hz -> 0).  tvc_encoder_f32 runs the same kernel on its own logits. */
+int tvc_pitch_decode_f32(tvc_ctx* ctx, void* stream, const float* logits, float* f0, int B, int T);
+
 /* kNN match ------------------------------------------------------------------------------- */
 /* Prepare an index for matching, once per index: index [768, N] (the [1,768,N] tensor of index.pt,
  * reference extract_index.py:58 / infer.py:49, or Generator.encode's output) -> `prepared`, a blob of

@@ -105,6 +105,18 @@ def test_headline_stages_on_reference_inputs():
     close("cfg1 ssl (ref spec)", ssl, g, "ssl", 1e-5)
     close("cfg1 logits (ref spec)", logits, g, "logits", 3e-6)
     r = close("cfg1 f0 (ref spec)", f0, g, "f0", 2e-6)          # VERDICT r1 gate: f0 rel <= 2e-6
+    # PitchEstimator.decode alone, on the reference's logits: top-4 / softmax / expectation with the transcendentals rounded
+    # the way ATen's are -> bit-identical on nearly every frame
+    f0d = enc.pitch_estimator.decode(_t(g["logits"]).to(DEV))
+    same = float((f0d.cpu() == _t(g["f0"])).float().mean())
+    _log(f"[headline] cfg1 decode(reference logits): {same * 100:.1f} % of frames bit-identical")
+    close("cfg1 decode (ref logits)", f0d, g, "f0", 5e-8)
+    assert same >= 0.9
+    f0s = eng.shift_frequency(_t(g["f0"]).to(DEV), shift)
+    same = float((f0s.cpu() == _t(g["f0s"])).float().mean())
+    _log(f"[headline] cfg1 shift_frequency(reference f0): {same * 100:.1f} % of frames bit-identical")
+    close("cfg1 shift_frequency (ref f0)", f0s, g, "f0s", 5e-8)
+    assert same >= 0.9
     m, idx = match_features(_t(g["ssl"]).to(DEV), tgt.to(DEV), return_indices=True)
     assert torch.equal(idx.cpu(), _t(g["knn_idx"]))
     assert torch.equal(m.cpu(), _t(g["matched"])), "matched rows must be bit-identical once the indices are"
@@ -178,7 +190,7 @@ def test_error_budget_at_4s(models):
     for name, v in rows:
         _log(f"[budget] T=200  {name:50s} abs rms diff {v:.3e}")
     _log(f"[budget] f0 rel error: pitch trunk alone {rel_rms(f0_ref_spec.cpu(), _t(g['f0'])):.3e}, with GPU |STFT| {rel_rms(f0_gpu_spec.cpu(), _t(g['f0'])):.3e}")
-    assert rows[0][1] <= 1e-6 and full <= 1e-4
+    assert rows[0][1] <= 1e-5 and full <= 1e-4
 
 
 def test_nan_and_inf_samples_do_not_fault(models):
@@ -211,3 +223,30 @@ def test_nan_and_inf_samples_do_not_fault(models):
     _ssl, f0, _ = eng.encoder(spec)
     torch.cuda.synchronize()
     assert torch.isnan(f0).all()
+
+
+def test_ten_seconds_against_the_host_cpu_spread(models):
+    """T = 500 (10 s), oracle run live on this box: the GPU-vs-CPU waveform difference next to the CPU's own
+    1-thread-vs-all-threads difference on the same input (tools/cpu_spread.py prints the same figures)."""
+    import os
+    from oracle import ref_cpu as R
+    _enc, _dec, gen = models
+    enc_sd, dec_sd = state_dicts(0)
+    T = 500
+    wf = synth.synth_wave(1, 480 * T, seed=100)
+    tgt = synth.synth_index(1000, seed=2)
+    angle = synth.synth_angle(1, T, 3)
+    n = torch.get_num_threads()
+    ref = R.convert(enc_sd, dec_sd, wf, tgt, 0.0, angle, return_stages=True)
+    torch.set_num_threads(1)
+    one = R.convert(enc_sd, dec_sd, wf, tgt, 0.0, angle)
+    torch.set_num_threads(n)
+    spread = rms(one - ref["wave"])
+    out = gen.convert(wf.to(DEV), tgt.to(DEV), 0.0, noise_angle=angle.to(DEV))
+    d = rms(out.cpu() - ref["wave"])
+    eng = gen.engine(DEV)
+    dec_only = rms(eng.decoder(ref["matched"].to(DEV), ref["f0s"].to(DEV), ref["energy"].to(DEV), angle.to(DEV)).cpu() - ref["wave"])
+    _log(f"[headline] T=500: GPU vs CPU({n} threads) {d:.3e}; CPU 1 thread vs {n} threads {spread:.3e}; ratio {d / spread:.2f}; "
+         f"decoder on the oracle's inputs {dec_only:.3e}")
+    assert dec_only <= 1e-6
+    assert d <= max(2.5e-4, 3 * spread)

@@ -139,7 +139,7 @@ def test_knn_ragged_index_sizes(models, n_index):
 def test_shift_frequency(models, shift):
     from tinyvc_amd.module import utils
     f0 = torch.tensor([[[0.0, 15.0, 20.0, 55.5, 110.0, 440.0, 1234.5, 8000.0]]])
-    check(f"shift {shift}", utils.shift_frequency(f0.to(DEV), shift), R.shift_frequency(f0, shift), 2e-6)   # 1 ulp of midi (~1e2) is 4e-7 in f
+    check(f"shift {shift}", utils.shift_frequency(f0.to(DEV), shift), R.shift_frequency(f0, shift), 3e-7)   # 1 ulp of midi is 2.2e-7 in f; the fp64-rounded transcendentals agree with ATen on ~99 % of inputs
 
 
 @pytest.mark.parametrize("case", CASES)

@@ -732,6 +732,13 @@ int tvc_encoder_f32(tvc_ctx* ctx, void* stream, const float* spec, float* ssl, f
     TVC_RUN(run_encoder(ctx, s, ws, true, spec, ssl, f0, logits, B, T), run_encoder(ctx, s, ws, false, spec, ssl, f0, logits, B, T));
 }
 
+int tvc_pitch_decode_f32(tvc_ctx* ctx, void* stream, const float* logits, float* f0, int B, int T) {
+    TVC_CHECK(need_ready(ctx, NEED_ENC));
+    if (!logits || !f0 || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_pitch_decode_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_pitch_decode(ctx, (hipStream_t)stream, logits, f0, B, T);
+}
+
 int64_t tvc_knn_prepared_elems(int64_t N) {
     if (N <= 0) return 0;
     int64_t npad = (N + 127) / 128 * 128;

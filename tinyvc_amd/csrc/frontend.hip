@@ -126,14 +126,20 @@ int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, 
 
 // ---- shift_frequency ----------------------------------------------------------------------------
 // midi = log2(relu(f/440) + 1e-6) * 12 + 69 + shift;  f' = 440 * 2^((midi - 69) / 12)
+// Every step is the fp32 op ATen runs, in ATen's order.  The two transcendentals are evaluated in fp64 and rounded
+// once: ATen's CPU log2 / pow (Sleef u10) return the correctly rounded fp32 value on ~99 % of inputs and differ by one
+// ulp otherwise, whereas two different <= 1 ulp approximations disagree on a large fraction - and one ulp of `midi`
+// is 2.2e-7 of f0, which the harmonic oscillator integrates over the whole utterance (measured: 4.5e-5 of the 7.1e-5
+// end-to-end rms difference at 4 s came from this function alone before the change).
 static __global__ void shift_kernel(const float* __restrict__ f0, float* __restrict__ out, long n, float shift) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float r = __fdiv_rn(f0[i], 440.f);
-        r = r > 0.f ? r : 0.f;
-        float midi = __fadd_rn(__fmul_rn(log2f(__fadd_rn(r, 1e-6f)), 12.f), 69.f);
+        r = r < 0.f ? 0.f : r;                       // relu; NaN stays NaN as in F.relu
+        const float lg = (float)log2((double)__fadd_rn(r, 1e-6f));
+        float midi = __fadd_rn(__fmul_rn(lg, 12.f), 69.f);
         midi = __fadd_rn(midi, shift);
         float e = __fdiv_rn(__fsub_rn(midi, 69.f), 12.f);
-        out[i] = __fmul_rn(440.f, exp2f(e));
+        out[i] = __fmul_rn(440.f, (float)exp2((double)e));
     }
 }
 

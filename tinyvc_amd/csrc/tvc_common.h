@@ -212,6 +212,7 @@ int run_noise_ifft(tvc_ctx*, hipStream_t, const float* kern, const float* angle,
 int run_energy(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* energy, int B, int64_t L);
 int run_encoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* spec, float* ssl, float* f0,
                 float* logits, int B, int T);
+int run_pitch_decode(tvc_ctx*, hipStream_t, const float* logits, float* f0, int B, int T);
 int run_knn(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* src, const float* prepared, int64_t N,
             float* out, int64_t* idx_out, int B, int T);
 int run_knn_topk(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* src, const float* prepared, int64_t N,

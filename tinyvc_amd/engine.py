@@ -156,6 +156,16 @@ class Engine:
         self._ok(self.lib.tvc_encoder_f32(self.ctx, self._stream(), _ptr(x), _ptr(ssl), _ptr(f0), _ptr(logits), B, T, p, n), "tvc_encoder_f32")
         return ssl, f0, logits
 
+    def pitch_decode(self, logits):
+        """PitchEstimator.decode: logits [B,512,T] -> f0 [B,1,T]."""
+        lg = _prep(logits, "logits", self.device)
+        B, C, T = lg.shape
+        if C != spec.PITCH_CLASSES:
+            raise ValueError(f"logits must have {spec.PITCH_CLASSES} classes")
+        f0 = torch.empty(B, 1, T, dtype=_F32, device=self.device)
+        self._ok(self.lib.tvc_pitch_decode_f32(self.ctx, self._stream(), _ptr(lg), _ptr(f0), B, T), "tvc_pitch_decode_f32")
+        return f0
+
     def knn_prepare(self, index):
         """index: [768, N] or [1, 768, N] -> prepared blob (1-D float tensor)."""
         idx = _prep(index, "index", self.device)

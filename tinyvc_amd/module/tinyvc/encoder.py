@@ -51,6 +51,13 @@ class PitchEstimator(_Estimator):
     def infer(self, spec):             # encoder.py:69-72 -> f0 [B, 1, T]
         return self._parent().infer(spec)[1]
 
+    @torch.no_grad()
+    def decode(self, logits, k=4):     # encoder.py:61-67 -> f0 [B, 1, T]
+        _only_default("k", k, 4)
+        enc = self._parent()
+        logits = enc._input_device(logits)
+        return enc.engine(logits.device).pitch_decode(logits)
+
     # small helpers kept for API parity (training-side utilities of the reference, torch ops)
     def freq2id(self, f):              # encoder.py:41-45
         x = self.classes_per_octave * torch.log2(f / self.min_frequency)
