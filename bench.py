@@ -1,22 +1,24 @@
 #!/usr/bin/env python3
 """Headline benchmark: end-to-end voice conversion throughput (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): a batch of 64 utterances x 4 s (96 000 samples @24 kHz each,
-i.e. "4 s 16 kHz wav" after the 24 kHz resample the reference applies on load), fp32, matched
-against a 10 000-vector speaker index, converted by one `Generator.convert` call per step.
-Inputs, index and weights are synthetic (tinyvc_amd.synth) and resident in HBM before timing.
+N = 1 (default) runs BASELINE.json configs[1]: a batch of 64 utterances x 4 s (96 000 samples @24 kHz each, i.e. a
+"4 s 16 kHz wav" after the 24 kHz resample the reference applies on load), fp32, matched against a 10 000-vector speaker
+index, one `Generator.convert` call per step (the shipped module path: autopad check, torch.rand phase draw on the device,
+cached prepared index, one tvc_convert_f32).  Inputs, index and weights are synthetic (tinyvc_amd.synth) and resident in
+HBM before timing.  The same JSON line also carries configs[2] (32 concurrent real-time streams, p50 / p95 block latency,
+measured after the timed region) under "stream".
+
+N > 1 runs configs[3]: 64 utterances per rank (512 at N = 8), a 100 000-vector index replicated per GPU, and an RCCL
+gather of every rank's [64, 96000] waveforms to rank 0 INSIDE each step (the path's only exchange); `gather_ms` is
+reported separately.  One process per GPU (weak scaling):
 
   python bench.py [--gpus N --steps K --warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One process per GPU; every rank converts its own 64 utterances (weak scaling: utterances are
-independent, so the path has no exchange step and a step issues no collective - each rank's
-waveforms stay on the GPU that produced them, as with one reference process per device;
-`--gather` adds `parallel.gather_waves` (RCCL gather to rank 0) to every step for callers who
-want the job's output in one place).  value = 16 kHz-equivalent audio samples converted per
-second by the whole job (audio seconds x 16 000 / wall seconds).
+value = 16 kHz-equivalent audio samples converted per second by the whole job (audio seconds x 16 000 / wall seconds).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -30,20 +32,22 @@ sys.path.insert(0, ROOT)
 from tinyvc_amd import synth  # noqa: E402
 
 SR = 24000
-FILTER_BYTES_PER_SAMPLE = 87.86e6 / SR      # layer-boundary activation bytes of FilterNet
+FILTER_BYTES_PER_SAMPLE = 87.86e6 / SR      # layer-boundary activation bytes of FilterNet per 24 kHz sample
 FILTER_FLOPS_PER_SAMPLE = 2.483e9 / SR       # FilterNet FLOPs per 24 kHz output sample
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
+BF16_MFMA_PEAK_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 MFMA peak
 FP32_MFMA_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_* peak = fp32 vector peak
+SPLIT_PRODUCTS = 6                         # bf16x3 split precision: six bf16 part-products per fp32 product
 
 
 def measured_filter_traffic(B, L):
-    """HBM bytes moved by one step's FilterNet launches, from the committed rocprofv3 PMC passes
-    (FETCH_SIZE / WRITE_SIZE, collected and corrected as MI355X_MICROARCH.md prescribes); only valid
-    for the workload it was measured on."""
-    p = os.path.join(ROOT, "profiles", "r01_filter_traffic_pmc.json")
-    if B == 64 and L == 96000 and os.path.exists(p):
-        return json.load(open(p)).get("traffic_bytes")
-    return None
+    """HBM bytes moved by one step's FilterNet launches, from the newest committed rocprofv3 PMC passes
+    (FETCH_SIZE / WRITE_SIZE, collected and corrected as MI355X_MICROARCH.md prescribes: tools/filter_traffic.py);
+    only valid for the workload and build it was measured on.  Returns (bytes, file name)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_filter_traffic_pmc.json")))
+    if B == 64 and L == 96000 and files:
+        return json.load(open(files[-1])).get("traffic_bytes"), os.path.basename(files[-1])
+    return None, None
 
 
 def build_generator(device):
@@ -55,15 +59,16 @@ def build_generator(device):
     return Generator(enc, dec).to(device).eval()
 
 
-def cpu_baseline(seconds, n_index, batch=4, reps=3):
-    """The oracle (CPU restatement of the reference path, torch CPU ops) on the host cores, on a
-    bounded sample of the same workload: `batch` utterances of the same length and index size."""
+def cpu_baseline(seconds, n_index, batch=8, reps=5):
+    """The oracle (CPU restatement of the reference path, torch CPU ops) on the host cores, on a bounded sample of the
+    same workload (a B = 8 slice of configs[1]; all host threads, and one utterance on ONE thread)."""
     from oracle import ref_cpu as R
     enc_sd, dec_sd = synth.synth_state_dict("encoder"), synth.synth_state_dict("decoder")
     L = int(seconds * SR)
     wf = synth.synth_wave(batch, L, seed=100)
     tgt = synth.synth_index(n_index, seed=4)
     angle = synth.synth_angle(batch, L // 480, 3)
+    threads = torch.get_num_threads()
     R.convert(enc_sd, dec_sd, wf[:1], tgt, 0.0, angle[:1])          # warm-up
     ts = []
     for _ in range(reps):
@@ -71,8 +76,42 @@ def cpu_baseline(seconds, n_index, batch=4, reps=3):
         R.convert(enc_sd, dec_sd, wf, tgt, 0.0, angle)
         ts.append(time.perf_counter() - t0)
     t = sorted(ts)[len(ts) // 2]
-    return {"value": batch * seconds * 16000 / t, "unit": "16kHz-samples/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{batch} of the 64 utterances ({seconds:g} s each, {n_index}-vector index), median of {reps} runs, oracle/ref_cpu.py on torch CPU ops"}
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    R.convert(enc_sd, dec_sd, wf[:1], tgt, 0.0, angle[:1])
+    t1 = time.perf_counter() - t0
+    torch.set_num_threads(threads)
+    return {"value": batch * seconds * 16000 / t, "unit": "16kHz-samples/s", "cores": threads, "kind": "port",
+            "value_1thread": seconds * 16000 / t1,
+            "sample": f"{batch} of the 64 utterances ({seconds:g} s each, {n_index}-vector index): 1 warm-up + median of {reps} runs on "
+                      f"{threads} threads; 1-thread figure = one utterance, one run; oracle/ref_cpu.py on torch CPU ops "
+                      f"(BASELINE.md §3 plans 3 warm-ups / median of 10: shortened to keep the default run within minutes)"}
+
+
+def stream_latency(gen, dev, streams=32, blocks=120, warmup=20, n_index=1000):
+    """BASELINE.json configs[2]: `streams` concurrent real-time streams, one 1920-sample block (80 ms) per stream and step,
+    13 440-sample rolling buffers, HIP-graph replay of the per-block pipeline; wall latency per block, blocks already on
+    the device."""
+    import numpy as np
+    from tinyvc_amd.module.infer import BatchedStreamInfer
+    st = BatchedStreamInfer(gen, n_streams=streams, target=synth.synth_index(n_index, seed=2).to(dev), device=dev,
+                            block_size=1920, extra_size=3840, use_graph=True)
+    st.init_buffer()
+    waves = torch.stack([synth.synth_wave(1, blocks * 1920, seed=200 + s)[0] for s in range(4)])
+    waves = waves[torch.arange(streams) % 4].to(dev).view(streams, blocks, 1920)
+    lat = []
+    for i in range(blocks):
+        blk = waves[:, i].contiguous()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        out = st.audio_callback(blk)
+        torch.cuda.synchronize(dev)
+        lat.append(time.perf_counter() - t0)
+    assert torch.isfinite(out).all()
+    l = np.sort(np.array(lat[warmup:])) * 1e3
+    return {"workload": f"infer_streaming.py {streams} concurrent streams, 13440-sample buffer, {n_index}-vector index (BASELINE.json configs[2])",
+            "streams": streams, "p50_ms": float(l[len(l) // 2]), "p95_ms": float(l[int(len(l) * 0.95)]), "max_ms": float(l[-1]),
+            "blocks": int(len(l)), "budget_ms": 80.0, "hip_graph": True}
 
 
 def main():
@@ -82,9 +121,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=4.0)
-    ap.add_argument("--index", type=int, default=10000)
+    ap.add_argument("--index", type=int, default=0, help="index vectors (default: 10 000 at N = 1 = configs[1], 100 000 at N > 1 = configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="N > 1: also gather every step's waveforms on rank 0 (not part of the path)")
+    ap.add_argument("--no-stream", action="store_true", help="skip the configs[2] latency measurement (N = 1)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave every rank's waveforms on its own GPU (not configs[3])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,20 +143,26 @@ def main():
 
     B, L = args.batch, int(args.seconds * SR)
     L -= L % 480
+    n_index = args.index or (10000 if world == 1 else 100000)
+    gather = world > 1 and not args.no_gather
     gen = build_generator(dev)
     eng = gen.engine(dev)
-    wf = synth.synth_wave(B, L, seed=100 + rank * B).to(dev)
-    tgt = synth.synth_index(args.index, seed=4).to(dev)
-    from tinyvc_amd.module.tinyvc.feature_retrieval import prepare_reference
-    blob, n_idx = prepare_reference(tgt)
-    out = torch.empty(B, L, device=dev)
+    wf = synth.synth_wave(B, L, seed=(100 if world == 1 else 1000) + rank * B).to(dev)      # SURVEY §8d seeds
+    tgt = synth.synth_index(n_index, seed=4 if world == 1 else 5).to(dev)
+    dest = torch.empty(world, B, L, device=dev) if gather and rank == 0 else None        # rank 0's landing buffer, allocated once
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup + 1))] if gather else None
+    state = {"i": 0, "out": None}
     from tinyvc_amd import parallel
 
     def step():
-        # on-device phase draw (library RNG): the reference draws fresh torch.rand phases per call too
-        eng.convert(wf, blob, n_idx, 0.0, None, out=out)
-        if world > 1 and args.gather:
-            parallel.gather_waves(out, world * B, dst=0)       # optional: the job's output collected on rank 0 (RCCL gather)
+        out = gen.convert(wf, tgt, 0.0)          # one Generator.convert per step (generator.py:26-34)
+        if gather:                               # configs[3]: the job's output collected on rank 0 (RCCL gather over xGMI)
+            a, b = ev[2 * state["i"]], ev[2 * state["i"] + 1]
+            a.record()
+            parallel.gather_into(out, dest, dst=0)
+            b.record()
+            state["i"] += 1
+        state["out"] = out
 
     # stage timers: hipEvent pairs recorded by the library on the launch stream.  They are switched on for
     # the warm-up too, so that the context's event pool is populated before the timed region
@@ -135,6 +181,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     fence()
+    first = state["i"]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -142,36 +189,71 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile(False)
+    gather_ms = None
+    if gather:
+        gather_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(first, state["i"])) / max(args.steps, 1)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, gather_ms or 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, gather_max = float(t[0].item()), float(t[1].item())
+    out = state["out"]
     assert os.environ.get("TVC_BENCH_NOCHECK") or torch.isfinite(out).all(), "non-finite output"
+    if gather and rank == 0:
+        assert torch.equal(dest[0], out), "rank 0's own slot of the gathered job output differs from its local result"
 
     if rank == 0:
         audio_s = world * B * (L / SR) * args.steps
         value = audio_s * 16000 / dt
         t_filter = prof.get("filter_net", 0.0) / 1e3 / max(args.steps, 1)
-        achieved = FILTER_BYTES_PER_SAMPLE * B * L / t_filter / 1e9 if t_filter > 0 else None
+        alg_bytes, flops = FILTER_BYTES_PER_SAMPLE * B * L, FILTER_FLOPS_PER_SAMPLE * B * L
+        traffic, traffic_src = measured_filter_traffic(B, L)
+        hbm = {"achieved": alg_bytes / t_filter / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / t_filter / 1e9 / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_launch": alg_bytes,
+               "moved_gbs": traffic / t_filter / 1e9 if traffic else None,
+               "moved_frac": traffic / t_filter / 1e9 / HBM_PEAK_GBS if traffic else None} if t_filter > 0 else None
+        mfma = {"achieved": SPLIT_PRODUCTS * flops / t_filter / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": SPLIT_PRODUCTS * flops / t_filter / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                "flops_per_launch": flops, "bf16_part_products_per_fp32_product": SPLIT_PRODUCTS,
+                "fp32_equiv_tflops": flops / t_filter / 1e12, "fp32_equiv_frac_of_fp32_mfma_peak": flops / t_filter / 1e12 / FP32_MFMA_PEAK_TFLOPS} if t_filter > 0 else None
+        # which roof binds, from the data: the pipe the kernels issue on (bf16 MFMA, 6 part-products per product) against the
+        # bytes that really crossed HBM (PMC); the layer-boundary byte model (north_star's 40 % target) stays in
+        # `hbm.frac` / `hbm_layer_boundary_frac` but is never what selects `bound` once blocks are fused.
+        roof = None
+        if t_filter > 0:
+            moved = hbm["moved_frac"]
+            bound = "mfma" if (moved is None or mfma["frac"] >= moved) else "hbm"
+            pick = mfma if bound == "mfma" else {"achieved": hbm["moved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved}
+            roof = {"bound": bound, "achieved": pick["achieved"], "peak": pick["peak"], "unit": pick["unit"], "frac": pick["frac"],
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": "FilterNet Conv1d stack = the filter_net launches of one step (split-precision bf16x3 MFMA: fused ups.4+output kernels, conv3s / conv48s for the 48..384-channel levels, conv24s / down0s for the 24-channel ones), hipEvent pair on the launch stream",
+                    "launch_ms": t_filter * 1e3,
+                    "hbm_layer_boundary_frac": hbm["frac"], "hbm_moved_frac": moved, "mfma_bf16_frac": mfma["frac"],
+                    "hbm": hbm, "mfma": mfma,
+                    "note": "neither roof is above 0.5: the stack is issue/latency-bound between them (DESIGN.md §4)"
+                            if max(mfma["frac"], moved or 0.0) < 0.5 else None}
+        cfg = "configs[1]" if world == 1 else "configs[3]"
         res = {
             "metric": "audio-samples/sec (16 kHz) end-to-end VC",
             "value": value, "unit": "16kHz-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"infer.py {B}-utterance batch fp32, {L / SR:g} s @24 kHz per utterance, {args.index}-vector index (BASELINE.json configs[1])",
-                       "global_batch": world * B, "utterance_samples_24k": L, "index_vectors": args.index,
+            "config": {"workload": (f"infer.py {B}-utterance batch fp32, {L / SR:g} s @24 kHz per utterance, {n_index}-vector index (BASELINE.json {cfg})" if world == 1 else
+                                    f"{world * B} synthetic utterances sharded across {world} MI355X ({B} per rank, {L / SR:g} s each), RCCL gather to rank 0, {n_index}-vector index replicated per GPU (BASELINE.json {cfg})"),
+                       "global_batch": world * B, "utterance_samples_24k": L, "index_vectors": n_index,
                        "parallelism": f"utterance-dp{world}", "x_realtime": audio_s / dt},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": measured_filter_traffic(B, L),
-                         "kernel": "FilterNet Conv1d stack = the filter_net launches of one step (split-precision bf16x3 MFMA everywhere: fused ups.4+output kernels, conv3s for the 48..384-channel levels, conv24s / down0s for the 24-channel ones), hipEvent pair on the launch stream",
-                         "algorithmic_bytes_per_launch": FILTER_BYTES_PER_SAMPLE * B * L,
-                         "launch_ms": t_filter * 1e3,
-                         "fp32_mfma_tflops": FILTER_FLOPS_PER_SAMPLE * B * L / t_filter / 1e12 if t_filter > 0 else None,
-                         "fp32_mfma_frac": FILTER_FLOPS_PER_SAMPLE * B * L / t_filter / 1e12 / FP32_MFMA_PEAK_TFLOPS if t_filter > 0 else None},
+            "roofline": roof,
             "stage_ms_per_step": {k: v / args.steps for k, v in sorted(prof.items())},
         }
+        if world > 1:
+            res["rccl_ranks"] = world
+            res["gather"] = "rccl gather -> rank 0, inside the step" if gather else "none"
+            res["gather_ms"] = gather_ms
+            res["gather_ms_max_over_ranks"] = gather_max if gather else None
+            res["gather_bytes_per_rank"] = B * L * 4 if gather else 0
+        if world == 1 and not args.no_stream:
+            res["stream"] = stream_latency(gen, dev)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(L / SR, args.index)
+            res["cpu_baseline"] = cpu_baseline(L / SR, n_index)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

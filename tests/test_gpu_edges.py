@@ -95,3 +95,34 @@ def test_full_bench_size_properties(gen):
     q = tgt[:, :, :512].contiguous()
     _m, idx = match_features(q, tgt, return_indices=True)
     assert torch.equal(idx[0, :, 0].cpu(), torch.arange(512))
+
+
+def test_thirty_two_concurrent_streams(gen):
+    """BASELINE configs[2]: 32 streams through one batched convert + one SOLA launch per block (HIP-graph replay).  Every
+    stream must equal the same stream run alone (streams do not interact), and a block must fit the 80 ms real-time budget."""
+    import time
+    from tinyvc_amd.module.infer import BatchedStreamInfer, StreamInfer
+    S, nblk = 32, 6
+    tgt = synth.synth_index(1000, seed=2).to(DEV)
+    blocks = torch.stack([synth.synth_wave(1, nblk * 1920, seed=200 + s)[0] for s in range(S)]).view(S, nblk, 1920).to(DEV)
+    st = BatchedStreamInfer(gen, n_streams=S, target=tgt, device=torch.device(DEV), block_size=1920, extra_size=3840, use_graph=True)
+    st.init_buffer()
+    outs, lat = [], []
+    for i in range(nblk):
+        angle = synth.synth_angle(S, st.input_size // 480, 900 + i).to(DEV)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs.append(st.audio_callback(blocks[:, i], noise_angle=angle).clone())
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    outs = torch.stack(outs, 1)                       # [S, nblk, 1920]
+    assert torch.isfinite(outs).all()
+    print(f"[edge] 32 streams: block latencies (ms) {[round(x, 2) for x in lat]}")
+    assert min(lat[3:]) < 80.0
+    for s in (0, 13, 31):                             # the same stream alone, eager, same phases
+        one = StreamInfer(gen, target=tgt, device=torch.device(DEV), block_size=1920, extra_size=3840)
+        one.init_buffer()
+        for i in range(nblk):
+            angle = synth.synth_angle(S, st.input_size // 480, 900 + i)[s:s + 1].to(DEV)
+            o = one.audio_callback(blocks[s, i], noise_angle=angle)
+            assert torch.equal(o, outs[s, i]), f"stream {s} block {i}: batched != alone"

@@ -59,6 +59,43 @@ def test_sharded_convert_matches_single_process(world, n_items):
     assert torch.equal(out, _fake_convert(waves, 1.5))
 
 
+def _worker_into(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # what bench.py does at N > 1 (configs[3]): equal shards gathered into one landing buffer allocated once on rank 0
+        dest = torch.full((world, 4, 960), -1.0) if rank == 0 else None
+        for step in range(3):
+            local = _fake_convert(torch.randn(4, 960, generator=torch.Generator().manual_seed(100 * step + rank)), 1.5)
+            got = parallel.gather_into(local, dest, dst=0)
+            if rank == 0:
+                assert got is dest
+                want = torch.stack([_fake_convert(torch.randn(4, 960, generator=torch.Generator().manual_seed(100 * step + r)), 1.5) for r in range(world)])
+                assert torch.equal(dest, want)
+            else:
+                assert got is None
+        if rank == 0:
+            q.put("ok")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_into_preallocated_landing_buffer(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_into, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    assert q.get() == "ok"
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+
 def test_shard_bounds_cover_everything():
     for n in (1, 5, 64, 512, 513):
         for w in (1, 2, 3, 8):

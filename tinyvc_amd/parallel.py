@@ -31,6 +31,15 @@ def gather_waves(local, n_items: int, dst: int = 0, group=None):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
 
 
+def gather_into(local, dest, dst: int = 0, group=None):
+    """Equal shards, no allocation: every rank's `local` [n, L] lands in `dest[r]` on rank `dst` (`dest` [world, n, L],
+    allocated once by the caller on `dst`, None elsewhere).  With the "nccl" backend this is RCCL's gather: world-1
+    point-to-point receives over xGMI into disjoint slices of one buffer."""
+    rank = dist.get_rank(group)
+    dist.gather(local, list(dest.unbind(0)) if rank == dst else None, dst=dst, group=group)
+    return dest if rank == dst else None
+
+
 def convert_sharded(convert_fn, waves, *args, dst: int = 0, group=None, **kwargs):
     """Every rank holds the same `waves` [n_items, L] (or builds its shard from the same recipe);
     each converts its own contiguous shard with `convert_fn(shard, *args, **kwargs)` and `dst`
