@@ -87,12 +87,21 @@ int tvc_pitch_decode_f32(tvc_ctx* ctx, void* stream, const float* logits, float*
 /* kNN match ------------------------------------------------------------------------------- */
 /* Prepare an index for matching, once per index: index [768, N] (the [1,768,N] tensor of index.pt,
  * reference extract_index.py:58 / infer.py:49, or Generator.encode's output) -> `prepared`, a blob of
- * tvc_knn_prepared_elems(N) floats holding the columns scaled by 1/(||r||+1e-6)
- * (feature_retrieval.py:25 recomputes that on every call), the raw vectors row-major for the
- * final gather, and the same normalised columns split into three bf16 parts per value in MFMA lane
- * order (the similarity GEMM's operand). The layout is private to the library. */
+ * tvc_knn_prepared_elems(N) floats: a 256-byte header, the raw vectors row-major (the final gather) and the vectors
+ * scaled by 1/(||r||+1e-6) (feature_retrieval.py:25 recomputes that on every call) split into three bf16 parts per
+ * value in MFMA lane order (the similarity GEMM's operand): 10 bytes per index element.  The layout is private to the
+ * library; the blob is self-describing, so every entry point below takes either kind of blob. */
 int64_t tvc_knn_prepared_elems(int64_t N);
 int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, float* prepared,
+                              int64_t N);
+/* fp16 index storage for very large indices (BASELINE.json configs[4]: 1 M vectors): `rows_f16` =
+ * [N, 768] IEEE binary16, one vector per row (index.pt's tensor transposed and cast to half) -> a blob of
+ * tvc_knn_prepared_elems_f16(N) floats holding the fp16 vectors in MFMA lane order and one fp32 inverse norm per
+ * vector: 2 bytes per index element (1.5 GB at N = 1 M).  Matching against it computes cos = dot(q_hat, r) / (||r||+1e-6)
+ * with r the fp16 values (exactly two bf16 parts each), fp32 accumulation; the k = 4 rows averaged are the fp16 values.
+ * Results equal the fp32-storage path run on the same (fp16-rounded) vectors up to fp32 rounding of the similarities. */
+int64_t tvc_knn_prepared_elems_f16(int64_t N);
+int tvc_knn_prepare_index_f16(tvc_ctx* ctx, void* stream, const void* rows_f16, float* prepared,
                               int64_t N);
 /* match_features(source, reference, k=4, alpha=0, metrics='cos')
  * (reference module/tinyvc/feature_retrieval.py:15-33): src [B,768,T] against one shared prepared

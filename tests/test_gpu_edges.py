@@ -126,3 +126,95 @@ def test_thirty_two_concurrent_streams(gen):
             angle = synth.synth_angle(S, st.input_size // 480, 900 + i)[s:s + 1].to(DEV)
             o = one.audio_callback(blocks[s, i], noise_angle=angle)
             assert torch.equal(o, outs[s, i]), f"stream {s} block {i}: batched != alone"
+
+
+@pytest.mark.parametrize("n_index", [4, 129, 1001, 10000])
+def test_fp16_index_storage_matches_oracle_on_the_rounded_vectors(gen, n_index):
+    """An index handed over as torch.float16 takes the fp16 storage (2 B per element).  Its results must equal the
+    reference's on the SAME fp16-rounded vectors: indices wherever fp32 can decide, and the mean of the four rows."""
+    from tinyvc_amd.module.tinyvc import match_features
+    g = torch.Generator().manual_seed(n_index)
+    index16 = torch.randn(1, 768, n_index, generator=g).half()
+    src = torch.randn(2, 768, 37, generator=g)
+    out, idx = match_features(src.to(DEV), index16.to(DEV), return_indices=True)
+    o_out, o_idx, sims = R.match_features(src, index16.float(), return_indices=True)
+    top = torch.topk(sims.double(), min(5, n_index), dim=2).values
+    decidable = (top[..., :-1] - top[..., 1:]).min(dim=2).values > 1e-5
+    assert decidable.float().mean() > 0.9
+    assert torch.equal(idx.cpu()[decidable], o_idx[decidable])
+    assert (idx.cpu() < n_index).all() and (idx.cpu() >= 0).all()
+    m = decidable[:, None, :].expand_as(o_out)
+    assert torch.equal(out.cpu()[m], o_out[m]), "mean of the four fp16 rows must be bit-identical once the indices are"
+    # and the fp32 storage on the rounded vectors selects the same rows
+    _o32, idx32 = match_features(src.to(DEV), index16.float().to(DEV), return_indices=True)
+    assert torch.equal(idx32.cpu()[decidable], idx.cpu()[decidable])
+
+
+def test_cfg5_five_minutes_against_a_million_vector_fp16_index(gen):
+    """BASELINE configs[4]: one 5-minute utterance (T = 15 000 frames), 1 000 000-vector index in fp16 storage.
+    The reference cannot run this size (its sims tensor would be 60 GB), so: (1) the kNN stage against the oracle on a
+    200-query slice; (2) fp16 storage vs fp32 storage on all 15 000 queries (mismatches only at near-ties); (3) the
+    workspace the library asks for; (4) the whole conversion, finite, timed, with the kNN stage's matrix-pipe fraction."""
+    import ctypes
+    import time
+    from tinyvc_amd.module import utils
+    from tinyvc_amd.module.tinyvc import match_features
+    eng = gen.engine(DEV)
+    T, N = 15000, 1_000_000
+    wf = synth.synth_wave(1, 480 * T, seed=6)
+    index16 = synth.synth_index(N, seed=7).half()                 # [1, 768, N] fp16: 1.5 GB
+    ssl, _f0 = gen.encode(wf.to(DEV))
+    d16 = index16.to(DEV)
+    blob16, n = eng.knn_prepare(d16)
+    assert blob16.numel() * 4 < 1.55e9, "fp16 storage must be 2 B per element"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sims16, idx16 = eng.knn_topk(ssl, blob16, n)
+    torch.cuda.synchronize()
+    t_knn = time.perf_counter() - t0
+    mfma = 5 * 2 * 768 * T * N / t_knn / 2.5e15
+    print(f"[cfg5] kNN T={T} x N={N}: {t_knn * 1e3:.1f} ms = {2 * 768 * T * N / t_knn / 1e12:.0f} TFLOP/s fp32-equivalent, "
+          f"{mfma:.2f} of the bf16 MFMA peak (5 part-products per product)")
+    # (1) oracle on a 200-query slice, on the same fp16-rounded vectors
+    q = ssl[:, :, 7000:7200].cpu()
+    ref = index16.float()
+    _o, o_idx, sims = R.match_features(q, ref, return_indices=True)
+    top = torch.topk(sims, 5, dim=2).values
+    decidable = (top[..., :-1] - top[..., 1:]).min(dim=2).values > 1e-5
+    got = idx16[:, 7000:7200].cpu()
+    print(f"[cfg5] oracle slice: {int(decidable.sum())} of 200 queries decidable at 1e-5; all equal: {torch.equal(got[decidable], o_idx[decidable])}")
+    assert decidable.float().mean() > 0.5 and torch.equal(got[decidable], o_idx[decidable])
+    del sims, top, _o
+    # (2) fp32 storage of the same vectors, all queries (split-N merge at this size: 9 index splits x 118 query tiles)
+    d32 = ref.to(DEV)
+    del ref
+    blob32, _ = eng.knn_prepare(d32)
+    sims32, idx32 = eng.knn_topk(ssl, blob32, n)
+    differ = (idx32 != idx16).any(dim=2)
+    gap = (sims32[..., :-1] - sims32[..., 1:]).abs().min(dim=2).values
+    rate = float(differ.float().mean())
+    print(f"[cfg5] fp16 vs fp32 storage: {int(differ.sum())} of {T} queries differ ({rate * 100:.3f} %); largest top-4 gap among them "
+          f"{float(gap[differ].max()) if differ.any() else 0.0:.2e}; similarity rms diff {float((sims32 - sims16).pow(2).mean().sqrt()):.2e}")
+    assert rate < 0.01
+    assert not differ.any() or float(gap[differ].max()) < 1e-5, "a mismatch away from a near-tie"
+    del blob32, d32, sims32, idx32
+    # (3) the workspace for the whole conversion at this size
+    need = ctypes.c_size_t()
+    assert eng.lib.tvc_workspace_bytes(eng.ctx, 1, 480 * T, N, ctypes.byref(need)) == 0
+    print(f"[cfg5] tvc_workspace_bytes(B=1, L={480 * T}, N={N}) = {need.value / 2**30:.2f} GiB")
+    assert need.value < 32 * 2**30
+    # (4) the whole path, one call
+    eng.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = gen.convert(wf.to(DEV), d16, 0.0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile(False)
+    assert out.shape == (1, 480 * T) and torch.isfinite(out).all()
+    print(f"[cfg5] 5-minute convert: {dt * 1e3:.0f} ms wall ({300 / dt:.0f}x real time); stages (ms): "
+          + ", ".join(f"{k} {v:.1f}" for k, v in sorted(prof.items()) if not k.startswith("filter.")))
+    # the staged kNN equals what convert used: same rows for the slice
+    m16, _ = match_features(ssl[:, :, 7000:7200].contiguous(), d16, return_indices=True)
+    assert torch.isfinite(m16).all()

@@ -27,6 +27,8 @@ SIGNATURES = {
     "tvc_encoder_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_pitch_decode_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "tvc_knn_prepared_elems": (c_int64, [c_int64]),
+    "tvc_knn_prepared_elems_f16": (c_int64, [c_int64]),
+    "tvc_knn_prepare_index_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "tvc_knn_prepare_index_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "tvc_knn_match_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_knn_topk_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),

@@ -365,83 +365,24 @@ struct Packer {
     }
 };
 
-// Real-DFT tables exploiting the symmetry about n = N/2 (cos even, sin odd; the periodic Hann window is
-// even too, so it stays folded into the matrices): each transform is two half-size real contractions.
-//   forward:  Re X[f] = sum_{n=1..960} c_n w[n] cos(2 pi f n/N) e[n],  e[n] = x[n] + x[N-n] (e[960] = x[960])
-//             Im X[f] = -sum_{n=1..959} w[n] sin(2 pi f n/N) o[n],     o[n] = x[n] - x[N-n]      (w[0] = 0)
-//   inverse:  E[n] = (1/N) sum_{f=0..960} c_f Re X[f] cos(2 pi f n/N),  O[n] = (2/N) sum_{f=1..959} Im X[f] sin(2 pi f n/N)
-//             x[n] = E[n] - O[n],  x[N-n] = E[n] + O[n]  (n = 1..959);  x[0] = E[0], x[960] = E[960]
-void build_dft_tables(Packer& pk, tvc_ctx* ctx) {
-    const int N = kNfft, Hn = N / 2;   // 1920, 960
+// Tables of the wave-level 1920-point FFTs (fft.hip), computed in fp64: (cos, sin)(2 pi j / 960), (cos, sin)(2 pi k / 1920),
+// periodic Hann window.
+void build_fft_tables(Packer& pk, tvc_ctx* ctx) {
+    const int N = kNfft;
     const double two_pi = 6.283185307179586476925286766559;
-    auto put = [&](PackedW& pw, int M, int K, std::vector<float>& At) {
-        pw.M = M;
-        pw.K = K;
-        pw.cin = K;
-        pw.taps = 1;
-        std::vector<float> bias(pw.Mpad, 0.f);
-        pk.fix.push_back({&pw.At, pk.ab.put(At)});
-        pk.fix.push_back({&pw.bias, pk.ab.put(bias)});
-        pk.a6(&pw, At);
-    };
-    {   // FFT tables (fft.hip)
-        std::vector<float> t960(2 * 960), t1920(2 * 961 + 2), hann(N);
-        for (int j = 0; j < 960; ++j) {
-            t960[2 * j] = (float)std::cos(two_pi * j / 960.0);
-            t960[2 * j + 1] = (float)std::sin(two_pi * j / 960.0);
-        }
-        for (int k = 0; k <= 960; ++k) {
-            t1920[2 * k] = (float)std::cos(two_pi * k / 1920.0);
-            t1920[2 * k + 1] = (float)std::sin(two_pi * k / 1920.0);
-        }
-        for (int n = 0; n < N; ++n) hann[n] = (float)(0.5 - 0.5 * std::cos(two_pi * n / N));
-        pk.fix.push_back({&ctx->fft_tw960, pk.ab.put(t960)});
-        pk.fix.push_back({&ctx->fft_tw1920, pk.ab.put(t1920)});
-        pk.fix.push_back({&ctx->fft_hann, pk.ab.put(hann)});
+    std::vector<float> t960(2 * 960), t1920(2 * 961 + 2), hann(N);
+    for (int j = 0; j < 960; ++j) {
+        t960[2 * j] = (float)std::cos(two_pi * j / 960.0);
+        t960[2 * j + 1] = (float)std::sin(two_pi * j / 960.0);
     }
-    auto ang = [&](long f, long n) { return two_pi * (double)((f * n) % N) / N; };
-    {   // forward real part: rows k = n-1 (n = 1..960), columns f = 0..960
-        PackedW& pw = ctx->stft_re;
-        pw.Mpad = pad_m(kBins);
-        pw.Kpad = Hn;
-        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f);
-        for (int n = 1; n <= Hn; ++n) {
-            double hann = 0.5 - 0.5 * std::cos(two_pi * n / N);
-            for (int f = 0; f < kBins; ++f) At[(size_t)(n - 1) * pw.Mpad + f] = (float)(std::cos(ang(f, n)) * hann);
-        }
-        put(pw, kBins, Hn, At);
+    for (int k = 0; k <= 960; ++k) {
+        t1920[2 * k] = (float)std::cos(two_pi * k / 1920.0);
+        t1920[2 * k + 1] = (float)std::sin(two_pi * k / 1920.0);
     }
-    {   // forward imaginary part: rows k = n-1 (n = 1..959)
-        PackedW& pw = ctx->stft_im;
-        pw.Mpad = pad_m(kBins);
-        pw.Kpad = Hn;
-        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f);
-        for (int n = 1; n < Hn; ++n) {
-            double hann = 0.5 - 0.5 * std::cos(two_pi * n / N);
-            for (int f = 0; f < kBins; ++f) At[(size_t)(n - 1) * pw.Mpad + f] = (float)(-std::sin(ang(f, n)) * hann);
-        }
-        put(pw, kBins, Hn - 1, At);
-    }
-    {   // inverse even part: rows k = f (0..960), columns n = 0..960
-        PackedW& pw = ctx->istft_e;
-        pw.Mpad = pad_m(kBins);
-        pw.Kpad = (kBins + 15) / 16 * 16;
-        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f);
-        for (int f = 0; f < kBins; ++f) {
-            double c = (f == 0 || f == Hn) ? 1.0 : 2.0;
-            for (int n = 0; n <= Hn; ++n) At[(size_t)f * pw.Mpad + n] = (float)(c * std::cos(ang(f, n)) / N);
-        }
-        put(pw, kBins, kBins, At);
-    }
-    {   // inverse odd part: rows k = f-1 (f = 1..959), columns m = n-1 (n = 1..959)
-        PackedW& pw = ctx->istft_o;
-        pw.Mpad = pad_m(Hn - 1);
-        pw.Kpad = Hn;
-        std::vector<float> At((size_t)pw.Kpad * pw.Mpad, 0.f);
-        for (int f = 1; f < Hn; ++f)
-            for (int n = 1; n < Hn; ++n) At[(size_t)(f - 1) * pw.Mpad + (n - 1)] = (float)(2.0 * std::sin(ang(f, n)) / N);
-        put(pw, Hn - 1, Hn - 1, At);
-    }
+    for (int n = 0; n < N; ++n) hann[n] = (float)(0.5 - 0.5 * std::cos(two_pi * n / N));
+    pk.fix.push_back({&ctx->fft_tw960, pk.ab.put(t960)});
+    pk.fix.push_back({&ctx->fft_tw1920, pk.ab.put(t1920)});
+    pk.fix.push_back({&ctx->fft_hann, pk.ab.put(hann)});
 }
 
 }  // namespace
@@ -457,9 +398,9 @@ int tvc_ctx_create(int hip_device, tvc_ctx** out) {
     if (hipGetDeviceCount(&count) != hipSuccess || hip_device < 0 || hip_device >= count) return TVC_ERR_HIP;
     tvc_ctx* c = new tvc_ctx();
     c->device = hip_device;
-    {   // constant tables (windowed forward DFT, inverse real DFT): independent of any checkpoint
+    {   // constant tables (FFT twiddles, Hann window): independent of any checkpoint
         Packer pk{c};
-        build_dft_tables(pk, c);
+        build_fft_tables(pk, c);
         if (hipSetDevice(hip_device) != hipSuccess ||
             hipMalloc((void**)&c->const_arena, pk.ab.buf.size() * sizeof(float)) != hipSuccess ||
             hipMemcpy(c->const_arena, pk.ab.buf.data(), pk.ab.buf.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
@@ -742,8 +683,15 @@ int tvc_pitch_decode_f32(tvc_ctx* ctx, void* stream, const float* logits, float*
 int64_t tvc_knn_prepared_elems(int64_t N) {
     if (N <= 0) return 0;
     int64_t npad = (N + 127) / 128 * 128;
-    // normalised columns [768][Npad] + raw rows [N][768] + split-precision image (3 bf16 per value = 1.5 floats)
-    return (int64_t)kSslDim * npad + N * (int64_t)kSslDim + (int64_t)kSslDim * npad * 3 / 2;
+    // header + raw rows [N][768] + split image of the normalised vectors (3 bf16 per value = 1.5 floats)
+    return 64 + N * (int64_t)kSslDim + (int64_t)kSslDim * npad * 3 / 2;
+}
+
+int64_t tvc_knn_prepared_elems_f16(int64_t N) {
+    if (N <= 0) return 0;
+    int64_t npad = (N + 127) / 128 * 128;
+    // header + inverse norms [Npad] + fp16 image (half a float per value)
+    return 64 + npad + (int64_t)kSslDim * npad / 2;
 }
 
 int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, float* prepared, int64_t N) {
@@ -751,6 +699,13 @@ int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, fl
     if (!index || !prepared || N <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_prepare_index_f32: bad argument");
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     return run_prepare_index(ctx, (hipStream_t)stream, index, prepared, N);
+}
+
+int tvc_knn_prepare_index_f16(tvc_ctx* ctx, void* stream, const void* rows_f16, float* prepared, int64_t N) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!rows_f16 || !prepared || N <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_prepare_index_f16: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_prepare_index_f16(ctx, (hipStream_t)stream, rows_f16, prepared, N);
 }
 
 int tvc_knn_match_f32(tvc_ctx* ctx, void* stream, const float* src, const float* prepared, int64_t N, float* out,

@@ -21,7 +21,7 @@
 // drains vmcnt, i.e. it would wait for exactly that prefetch.
 #pragma once
 #include <type_traits>
-#include "conv3.h"
+#include "conv_epi.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
 

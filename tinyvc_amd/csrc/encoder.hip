@@ -6,15 +6,6 @@
 
 namespace tvc {
 
-#ifndef TVC_SPLIT_ENC_IN
-#define TVC_SPLIT_ENC_IN 1
-#endif
-#ifndef TVC_ENC_FORK
-#define TVC_ENC_FORK 1    // pitch estimator on the side stream, beside the SSL chain
-#endif
-#ifndef TVC_SPLIT_ENC
-#define TVC_SPLIT_ENC 1   // ConvNeXt 1x1 contractions and the output projections on the split-precision bf16 path
-#endif
 #ifndef ENC_NWV
 #define ENC_MTB 2
 #define ENC_NWV 4
@@ -154,12 +145,7 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     }
     {
         EpiBias<ACT_GELU, false> ep{h, w.c2.bias, nullptr, C2, T, ncols, (long)C2 * T, 0};
-        if (TVC_SPLIT_ENC && C % 16 == 0 && w.c2.MT6 % ENC_MTB == 0) {
-            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, w.c2, y, B, C, T, 0, ep)));
-        } else {
-            LoadPlain ld{y, C, T, (long)C * T};
-            igemm_launch(s, w.c2.At, w.c2.Mpad, w.c2.Kpad, ncols, T, ld, ep);
-        }
+        TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, w.c2, y, B, C, T, 0, ep)));
     }
     {
         hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)B * C2 * 64)), dim3(256), 0, s, h, gx, (long)B * C2, T);
@@ -167,12 +153,7 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     }
     {
         EpiBias<ACT_NONE, true> ep{x, w.c3_bias_grn, x, C, T, ncols, (long)C * T, (long)C * T};
-        if (TVC_SPLIT_ENC && C2 % 16 == 0 && C2 <= 768 && w.c3.MT6 % ENC_MTB == 0) {
-            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC, EpiBias<ACT_NONE, true>, true>(ctx, s, w.c3, h, B, C2, T, 0, ep, nx)));
-        } else {
-            LoadScaled ld{h, nx, C2, T};
-            igemm_launch(s, w.c3.At, w.c3.Mpad, w.c3.Kpad, ncols, T, ld, ep);
-        }
+        TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC, EpiBias<ACT_NONE, true>, true>(ctx, s, w.c3, h, B, C2, T, 0, ep, nx)));
     }
     return launch_check(ctx, "convnext");
 }
@@ -272,13 +253,8 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     float* lg = logits ? logits : ws.get<float>((size_t)B * kPitchClasses * T);
     if (!dry) {
         EpiSplit ep{xs, xp, ctx->enc_in.bias, kSslCh, kPitchCh, T, ncols};
-        if (TVC_SPLIT_ENC && TVC_SPLIT_ENC_IN && ctx->enc_in.MT6 % ENC_MTB == 0) {
-            // 961 input rows: the last slab is clamped to row 960 (zero weights beyond)
-            TVC_CHECK((gemm_s_launch_ragged<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->enc_in, spec, B, kBins, T, (long)kBins * T, ep)));
-        } else {
-            LoadPlain ld{spec, kBins, T, (long)kBins * T};
-            igemm_launch(s, ctx->enc_in.At, ctx->enc_in.Mpad, ctx->enc_in.Kpad, ncols, T, ld, ep);
-        }
+        // 961 input rows: the last slab is clamped to row 960 (zero weights beyond)
+        TVC_CHECK((gemm_s_launch_ragged<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->enc_in, spec, B, kBins, T, (long)kBins * T, ep)));
         TVC_CHECK(run_layernorm(ctx, s, xs, ctx->ssl_ln_g, ctx->ssl_ln_b, B, kSslCh, T));
         TVC_CHECK(run_layernorm(ctx, s, xp, ctx->pit_ln_g, ctx->pit_ln_b, B, kPitchCh, T));
     }
@@ -290,7 +266,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     char* ssl_blk = ws.get<char>(ssl_scratch);
     Ws wssl(ssl_blk, ssl_scratch, dry);
     hipStream_t sp = s;
-    const bool fork = TVC_ENC_FORK && !dry && ctx->side;
+    const bool fork = !dry && ctx->side;
     if (fork) {
         TVC_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
         TVC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
@@ -299,12 +275,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     for (int i = 0; i < 4; ++i) TVC_CHECK(run_convnext(ctx, sp, ws, dry, ctx->pit_mid[i], xp, B, T));
     if (!dry) {
         EpiBias<ACT_NONE, false> ep{lg, ctx->pit_out.bias, nullptr, kPitchClasses, T, ncols, (long)kPitchClasses * T, 0};
-        if (TVC_SPLIT_ENC) {
-            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep)));
-        } else {
-            LoadPlain ld{xp, kPitchCh, T, (long)kPitchCh * T};
-            igemm_launch(sp, ctx->pit_out.At, ctx->pit_out.Mpad, ctx->pit_out.Kpad, ncols, T, ld, ep);
-        }
+        TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep)));
         hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(256), 0, sp, lg, ctx->pitch_freq, f0, B, T);
     }
     if (fork) TVC_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
@@ -313,12 +284,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     if (dry) return 0;
     {
         EpiBias<ACT_NONE, false> ep{ssl, ctx->ssl_out.bias, nullptr, kSslDim, T, ncols, (long)kSslDim * T, 0};
-        if (TVC_SPLIT_ENC) {
-            TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep)));
-        } else {
-            LoadPlain ld{xs, kSslCh, T, (long)kSslCh * T};
-            igemm_launch(s, ctx->ssl_out.At, ctx->ssl_out.Mpad, ctx->ssl_out.Kpad, ncols, T, ld, ep);
-        }
+        TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep)));
     }
     if (fork) TVC_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     return launch_check(ctx, "encoder");

@@ -1,91 +1,15 @@
 // Front end: |STFT| (spectrogram.py:8-15), energy envelope (energy_estimation.py:9-14),
 // semitone shift (pitch_shift.py:5-15).
-#include "conv3s.h"
-#include "igemm.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
 
 namespace tvc {
 
-#ifndef DFT_MTB   // workgroup of the DFT GEMMs: DFT_MTB x DFT_NWV waves of 32 x 32, DFT_BPC persistent workgroups per CU
-#define DFT_MTB 2
-#define DFT_NWV 4
-#define DFT_BPC 2   // measured best of {4x4x1, 2x4x2, 2x4x1, 4x2x2, 2x8x1, 4x3x1}
-#endif
-#ifndef TVC_FFT
-#define TVC_FFT 1   // |STFT| and the noise iSTFT as wave-level 1920-point FFTs (fft.hip); 0 = the half-size real-DFT GEMMs below
-#endif
-#ifndef TVC_SPLIT_DFT
-#define TVC_SPLIT_DFT 1   // forward / inverse DFT GEMMs on the split-precision bf16 path
-#endif
-
-// ---- |STFT| as two half-size windowed real-DFT contractions on the fp32 matrix pipe ---------------
-// spec[b][f][t] = | sum_n hann[n] x_b[(t+1)*480 + n - 960 (reflected)] e^{-2 pi i f n / 1920} |
-// Each 1920-sample frame is folded about its centre once (fold kernel: e[n] = x[n] + x[N-n],
-// o[n] = x[n] - x[N-n], stored k-major [960][B*T] so the GEMM's lanes read contiguous columns);
-// Re and Im are then [961 x 960] real GEMMs over columns (b, t): 3.7 MFLOP per frame instead of 7.4.
-// grid (15, ceil(ncols/32)): a workgroup folds 64 consecutive n of 32 frames.  Reads run along n
-// (contiguous in the waveform), the k-major stores run along the frame index: LDS transposes.
-static __global__ __launch_bounds__(256) void stft_fold_kernel(const float* __restrict__ wav, float* __restrict__ fe,
-                                                               float* __restrict__ fo, int L, int T, int ncols) {
-    __shared__ float te[64][33], to[64][33];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k0 = blockIdx.x * 64, col0 = blockIdx.y * 32;
-    for (int c = wave; c < 32; c += 4) {
-        int col = col0 + c;
-        float e = 0.f, o = 0.f;
-        if (col < ncols) {
-            int b = col / T, t = col - b * T;
-            const float* wb = wav + (long)b * L;
-            int n = k0 + lane + 1;
-            int start = (t + 1) * 480 - 960;               // frame t+1 of the centred STFT (frame 0 is dropped)
-            int p0 = start + n, p1 = start + 1920 - n;
-            if (p0 < 0) p0 = -p0;
-            if (p0 >= L) p0 = 2 * (L - 1) - p0;
-            if (p1 < 0) p1 = -p1;
-            if (p1 >= L) p1 = 2 * (L - 1) - p1;
-            float a = wb[p0], d = wb[p1];
-            e = n == 960 ? a : a + d;
-            o = n == 960 ? 0.f : a - d;
-        }
-        te[lane][c] = e;
-        to[lane][c] = o;
-    }
-    __syncthreads();
-    const int cl = tid & 31;
-    if (col0 + cl < ncols)
-        for (int kk = tid >> 5; kk < 64; kk += 8) {
-            long i = (long)(k0 + kk) * ncols + col0 + cl;
-            fe[i] = te[kk][cl];
-            fo[i] = to[kk][cl];
-        }
-}
-
+// |STFT| (spectrogram.py:8-15): one wavefront per 1920-sample frame, a 960-point complex FFT on the packed real frame
+// (fft.hip).  Needs no scratch.
 int run_stft(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, float* spec, int B, int64_t L) {
-    const int T = (int)(L / kHop);
-    const int ncols = B * T;
-    if (TVC_FFT) return dry ? 0 : run_stft_fft(ctx, s, wav, spec, B, L);
-    float* fe = ws.get<float>((size_t)960 * ncols);
-    float* fo = ws.get<float>((size_t)960 * ncols);
-    if (dry) return 0;
-    hipLaunchKernelGGL(stft_fold_kernel, dim3(15, (ncols + 31) / 32), dim3(256), 0, s, wav, fe, fo, (int)L, T, ncols);
-#if TVC_SPLIT_DFT
-    // both half-size DFT GEMMs on the split-precision path: fe/fo [960][ncols] are one "utterance" of ncols samples
-    TVC_CHECK((gemm_s_launch<DFT_MTB, DFT_NWV, DFT_BPC>(ctx, s, ctx->stft_re, fe, 1, 960, ncols, 0, EpiStftPart<false>{spec, T, ncols})));
-    TVC_CHECK((gemm_s_launch<DFT_MTB, DFT_NWV, DFT_BPC>(ctx, s, ctx->stft_im, fo, 1, 960, ncols, 0, EpiStftPart<true>{spec, T, ncols})));
-#else
-    {
-        LoadMatrix ld{fe, 960, ncols};
-        EpiStftPart<false> ep{spec, T, ncols};
-        igemm_launch(s, ctx->stft_re.At, ctx->stft_re.Mpad, ctx->stft_re.Kpad, ncols, T, ld, ep);
-    }
-    {
-        LoadMatrix ld{fo, 959, ncols};
-        EpiStftPart<true> ep{spec, T, ncols};
-        igemm_launch(s, ctx->stft_im.At, ctx->stft_im.Mpad, ctx->stft_im.Kpad, ncols, T, ld, ep);
-    }
-#endif
-    return launch_check(ctx, "stft");
+    (void)ws;
+    return dry ? 0 : run_stft_fft(ctx, s, wav, spec, B, L);
 }
 
 // ---- energy -------------------------------------------------------------------------------------

@@ -1,92 +1,135 @@
 // kNN feature match (feature_retrieval.py:15-33, metrics='cos', k=4, alpha=0).
 //
-// The reference materialises sims[T][N] and calls torch.topk; here the index streams through the
-// fp32 matrix pipe in 128-vector tiles and every lane keeps a running top-4 for the query column it
-// owns in the MFMA accumulator layout (index vectors are the M axis, queries the N axis, so the 16
-// accumulator registers of a lane are 16 index vectors against ONE query: the reduction is
-// lane-local).  The index is split across workgroups for occupancy; a second kernel merges the
-// per-split candidates, emits int64 indices and gathers + averages the 4 raw index vectors.
+// The reference materialises sims[T][N] and calls torch.topk; here the index streams through the matrix pipe in
+// 128-vector tiles and every lane keeps a running top-4 for the query column it owns in the MFMA accumulator layout
+// (index vectors are the M axis, queries the N axis, so the 16 accumulator registers of a lane are 16 index vectors
+// against ONE query: the reduction is lane-local).  The index is split across workgroups for occupancy; a second kernel
+// merges the per-split candidates, emits int64 indices and gathers + averages the 4 raw index vectors.
 //
+// Similarities run on the split-precision path (conv3s.h): bf16 part-products, fp32 accumulation, error below an fp32
+// FMA chain's.  Two index storages share the kernels (the prepared blob is self-describing, so every entry point - and a
+// captured HIP graph - works with either):
+//   kind 0, fp32 storage: raw rows [N][768] fp32 (the final gather) + the cosine-normalised vectors as three bf16 parts
+//           per value in MFMA lane order (10 B per element); six part-products per product; bit-exact indices on the
+//           gap-checked fixtures.
+//   kind 1, fp16 storage (BASELINE configs[4]: a 1 M-vector index): the raw vectors as fp16 in MFMA lane
+//           order + one fp32 inverse norm per vector (2 B per element: 1.5 GB at N = 1 M).  An fp16 value is exactly two
+//           bf16 parts, split while a tile is staged into LDS; five part-products per product; the similarity is
+//           dot(q_hat, r) * inv_norm; the gather reads the same image.
 // Tie-break: equal similarities -> lower index first (torch.topk leaves it unspecified).
+#include <hip/hip_fp16.h>
+
 #include "conv3s.h"
-#include "igemm.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
 
 namespace tvc {
 
-constexpr int KD = kSslDim;  // 768
-#ifndef KNN_BK
-#define KNN_BK 16      // K-slab depth of the similarity GEMM (deeper slabs cost occupancy: measured slower)
-#endif
-#ifndef KNN_SPLIT
-#define KNN_SPLIT 1    // similarity GEMM on the split-precision bf16 path (0: exact-fp32 MFMA kernel)
-#endif
+constexpr int KD = kSslDim;        // 768
+constexpr int STEPS = KD / 16;     // 48 K16 steps per index tile
+constexpr int HDR = 64;            // blob header, floats: [0] magic, [1] kind, [2] N (low 32 bits), [3] N (high)
+constexpr int KIND_F32 = 0, KIND_F16 = 1;
+constexpr int BLOB_MAGIC = 0x54564B4E;
 #ifndef KNN_BLOCKS
 #define KNN_BLOCKS 1024   // target workgroup count (query tiles x index splits)
-#endif
-#ifndef KNN_PIN
-#define KNN_PIN 0
-#endif
-#ifndef KNN_WAVES
-#define KNN_WAVES 8    // waves per workgroup: 8 -> each wave owns 64 x 32 (32 accumulator registers)
 #endif
 
 static inline int64_t npad128(int64_t N) { return (N + 127) / 128 * 128; }
 
-// prepared index blob: [768][Npad] cosine-normalised columns, then [N][768] raw rows
-static __global__ void index_prepare_kernel(const float* __restrict__ index, float* __restrict__ normT,
-                                            float* __restrict__ rows, long N, long Npad) {
-    long n = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (n >= Npad) return;
-    if (n >= N) {
-        for (int k = 0; k < KD; ++k) normT[(long)k * Npad + n] = 0.f;
-        return;
-    }
-    float s = 0.f;
-    for (int k = 0; k < KD; ++k) {
-        float v = index[(long)k * N + n];
-        s = fmaf(v, v, s);
-    }
-    float den = sqrtf(s) + 1e-6f;
-    for (int k = 0; k < KD; ++k) {
-        float v = index[(long)k * N + n];
-        normT[(long)k * Npad + n] = v / den;
-        rows[n * KD + k] = v;
+// element (vector n, channel k) of a 128-vector-tiled MFMA-ordered image with P parts per (m-tile, step): the index of
+// part 0's 8-value piece row; row = lane & 31, k = 16 step + 8 (lane >> 5) + j
+__device__ __forceinline__ long img_elem(long n, int k, int parts) {
+    const long tile = n >> 7;
+    const int mt = (int)(n & 127) >> 5, l31 = (int)(n & 31);
+    const int step = k >> 4, lh = (k >> 3) & 1, j = k & 7;
+    return ((((tile * STEPS + step) * 4 + mt) * parts) * 64 + (lh * 32 + l31)) * 8 + j;
+}
+
+// raw vector value (n, k) of either blob kind (the gathers)
+__device__ __forceinline__ float blob_row_value(const float* __restrict__ blob, int kind, long N, long Npad, long n, int k) {
+    if (kind == KIND_F16) return __half2float(reinterpret_cast<const __half*>(blob + HDR + Npad)[img_elem(n, k, 1)]);
+    return blob[HDR + n * KD + k];
+}
+
+static __global__ void blob_header_kernel(float* blob, int kind, long N) {
+    int* h = reinterpret_cast<int*>(blob);
+    if (threadIdx.x < HDR) h[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        h[0] = BLOB_MAGIC;
+        h[1] = kind;
+        h[2] = (int)(N & 0xffffffffL);
+        h[3] = (int)(N >> 32);
     }
 }
 
-// Split-precision image of the normalised index for knn_topk_split_kernel: every value as three bf16 parts
-// (v = p1 + p2 + p3, residuals exact), laid out [128-vector tile][K16 step][m-tile][part][lane][8] so that a
-// (tile, step) is 12 contiguous 1 KiB pieces already in MFMA lane order (row = lane & 31, k = 8 (lane >> 5) + j).
-static __global__ void index_split_kernel(const float* __restrict__ normT, unsigned short* __restrict__ img, long Npad) {
+// fp32 storage.  index [768][N] (the [1,768,N] tensor of index.pt) -> raw rows + the bf16x3 image of v / (||v|| + 1e-6)
+// (feature_retrieval.py:25 recomputes that normalisation on every call).  One thread per vector; reads run along n.
+static __global__ void index_prepare_kernel(const float* __restrict__ index, float* __restrict__ rows,
+                                            unsigned short* __restrict__ img, long N, long Npad) {
     long n = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (n >= Npad) return;
-    const long tile = n >> 7;
-    const int mt = (int)(n & 127) >> 5, l31 = (int)(n & 31);
+    float den = 1.f;
+    if (n < N) {
+        float s = 0.f;
+        for (int k = 0; k < KD; ++k) {
+            float v = index[(long)k * N + n];
+            s = fmaf(v, v, s);
+        }
+        den = sqrtf(s) + 1e-6f;
+    }
     for (int k = 0; k < KD; ++k) {
-        float v = normT[(long)k * Npad + n];
+        float raw = n < N ? index[(long)k * N + n] : 0.f;
+        if (n < N) rows[n * KD + k] = raw;
+        float v = raw / den;
         __bf16 h1 = (__bf16)v;
         float r = v - (float)h1;
         __bf16 h2 = (__bf16)r;
         float r2 = r - (float)h2;
         __bf16 h3 = (__bf16)r2;
-        const int step = k >> 4, lh = (k >> 3) & 1, j = k & 7;
-        long base = ((((tile * (KD / 16) + step) * 4 + mt) * 3) * 64 + (lh * 32 + l31)) * 8 + j;
+        const long base = img_elem(n, k, 3);
         img[base] = __builtin_bit_cast(unsigned short, h1);
         img[base + 512] = __builtin_bit_cast(unsigned short, h2);
         img[base + 1024] = __builtin_bit_cast(unsigned short, h3);
     }
 }
 
-// prepared blob: [768][Npad] normalised columns | [N][768] raw rows | split image (Npad * 768 * 3 bf16)
+// fp16 storage.  rows16 [N][768] IEEE half (row-major: one vector per row) -> inverse norms + the fp16 image.
+// One wavefront per vector: lanes run along k (coalesced 128-byte reads), the norm is a fixed-order wave reduction.
+static __global__ __launch_bounds__(256) void index_prepare_f16_kernel(const __half* __restrict__ rows16, float* __restrict__ inv,
+                                                                       __half* __restrict__ img, long N, long Npad) {
+    const int lane = threadIdx.x & 63;
+    const long n = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    if (n >= Npad) return;
+    float s = 0.f;
+    for (int k = lane; k < KD; k += 64) {
+        const __half h = n < N ? rows16[n * KD + k] : __float2half(0.f);
+        const float v = __half2float(h);
+        s = fmaf(v, v, s);
+        img[img_elem(n, k, 1)] = h;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) inv[n] = n < N ? 1.f / (sqrtf(s) + 1e-6f) : 0.f;
+}
+
 int run_prepare_index(tvc_ctx* ctx, hipStream_t s, const float* index, float* prepared, int64_t N) {
-    long Npad = npad128(N);
-    hipLaunchKernelGGL(index_prepare_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, s, index, prepared,
-                       prepared + (size_t)KD * Npad, (long)N, Npad);
-    unsigned short* img = reinterpret_cast<unsigned short*>(prepared + (size_t)KD * Npad + (size_t)N * KD);
-    hipLaunchKernelGGL(index_split_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, s, prepared, img, Npad);
+    const long Npad = npad128(N);
+    hipLaunchKernelGGL(blob_header_kernel, dim3(1), dim3(64), 0, s, prepared, KIND_F32, (long)N);
+    float* rows = prepared + HDR;
+    unsigned short* img = reinterpret_cast<unsigned short*>(rows + (size_t)N * KD);
+    hipLaunchKernelGGL(index_prepare_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, s, index, rows, img, (long)N, Npad);
     return launch_check(ctx, "knn_prepare_index");
+}
+
+int run_prepare_index_f16(tvc_ctx* ctx, hipStream_t s, const void* rows16, float* prepared, int64_t N) {
+    const long Npad = npad128(N);
+    hipLaunchKernelGGL(blob_header_kernel, dim3(1), dim3(64), 0, s, prepared, KIND_F16, (long)N);
+    float* inv = prepared + HDR;
+    __half* img = reinterpret_cast<__half*>(inv + Npad);
+    hipLaunchKernelGGL(index_prepare_f16_kernel, dim3((unsigned)((Npad * 64 + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const __half*>(rows16), inv, img, (long)N, Npad);
+    return launch_check(ctx, "knn_prepare_index_f16");
 }
 
 // qn[b][k][t] = src[b][k][t] / (||src[b][:][t]|| + 1e-6).  One workgroup = 64 consecutive columns;
@@ -138,139 +181,37 @@ struct Top4 {
     }
 };
 
-// grid = qtiles * nsplit ; workgroup = 128 queries x (tiles_per_split index tiles of 128)
-static __global__ __launch_bounds__(KNN_WAVES * 64) void knn_topk_kernel(const float* __restrict__ normT, long Npad, int N,
-                                                              const float* __restrict__ qn, int ncols, int T,
-                                                              int nsplit, int tiles_per_split,
-                                                              float* __restrict__ cand_v, int* __restrict__ cand_i) {
-    constexpr int BM = 128, BN = 128, BK = KNN_BK, TM = 2, TN = KNN_WAVES == 8 ? 1 : 2;
-    constexpr int NTHR = KNN_WAVES * 64, BRS = NTHR / 128;   // B staging: thread owns column tid % 128, rows tid / 128 + BRS * j
-    __shared__ __attribute__((aligned(16))) float smem[BK * BM + BK * BN];
-    float* As = smem;
-    float* Bs = smem + BK * BM;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = KNN_WAVES == 8 ? wave >> 2 : wave >> 1, wn = KNN_WAVES == 8 ? wave & 3 : wave & 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int split = blockIdx.x % nsplit;
-    const int qtile = blockIdx.x / nsplit;
-    const int n0 = qtile * BN;
-    const int mtiles = (int)(Npad / BM);
-    const int mt_lo = split * tiles_per_split;
-    const int mt_hi = min(mtiles, mt_lo + tiles_per_split);
-
-    LoadPlain ld{qn, KD, T, (long)KD * T};
-    const LoadPlain::Ctx col = ld.ctx(n0 + (tid & 127), ncols, T);
-    const int brow0 = tid >> 7;
-
-    Top4 top[TN];
+// two bf16 parts of 8 fp16 values (exact: 11 significant bits fit in 8 + 8), packed for one 16-byte LDS row each
+__device__ __forceinline__ void split8_half(const u32x4& h8, uint4& p1, uint4& p2) {
+    unsigned o1[4], o2[4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) top[j].init();
-
-    for (int mt = mt_lo; mt < mt_hi; ++mt) {
-        const int m0 = mt * BM;
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-        constexpr int AP = BK * BM / 4 / NTHR, BP = BK * BN / NTHR;   // per-thread float4 / float staging counts
-        float4 areg[AP];
-        float breg[BP];
-        auto load_slab = [&](int k0) {
-#pragma unroll
-            for (int i = 0; i < AP; ++i) {
-                int idx = tid + i * NTHR;
-                int kk = idx >> 5, c4 = idx & 31;
-                areg[i] = *reinterpret_cast<const float4*>(normT + (long)(k0 + kk) * Npad + m0 + c4 * 4);
-            }
-#pragma unroll
-            for (int j = 0; j < BP; ++j) breg[j] = ld.get(col, k0 + brow0 + BRS * j);
-        };
-        load_slab(0);
-        for (int kt = 0; kt < KD / BK; ++kt) {
-#pragma unroll
-            for (int i = 0; i < AP; ++i) *reinterpret_cast<float4*>(As + (tid + i * NTHR) * 4) = areg[i];
-#pragma unroll
-            for (int j = 0; j < BP; ++j) Bs[(brow0 + BRS * j) * BN + (tid & 127)] = breg[j];
-            __syncthreads();
-            if (kt + 1 < KD / BK) load_slab((kt + 1) * BK);
-#pragma unroll
-            for (int ks = 0; ks < BK / 2; ++ks) {
-                const int k = 2 * ks + lh;
-                float a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = As[k * BM + (wm * TM + i) * 32 + l31];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = Bs[k * BN + (wn * TN + j) * 32 + l31];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-            __syncthreads();
-        }
-        // running top-4: this lane's 16 registers are 16 index vectors against its own query
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < N) top[j].insert(nan_max(acc[i][j][r]), row);
-                }
+    for (int j = 0; j < 4; ++j) {
+        const __half2 hh = __builtin_bit_cast(__half2, h8[j]);
+        f32x2 a = {__low2float(hh), __high2float(hh)};
+        bf16x2 h1 = __builtin_convertvector(a, bf16x2);
+        f32x2 r = a - __builtin_convertvector(h1, f32x2);
+        bf16x2 h2 = __builtin_convertvector(r, bf16x2);
+        o1[j] = __builtin_bit_cast(unsigned, h1);
+        o2[j] = __builtin_bit_cast(unsigned, h2);
     }
-
-    // merge the 4 partial lists (wm in {0,1} x lh in {0,1}) of every query through LDS
-    __shared__ float mv[128][16];
-    __shared__ int mi[128][16];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int q = (wn * TN + j) * 32 + l31;
-        int slot = (wm * 2 + lh) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            mv[q][slot + e] = top[j].v[e];
-            mi[q][slot + e] = top[j].i[e];
-        }
-    }
-    __syncthreads();
-    if (tid < 128) {
-        Top4 t4;
-        t4.init();
-        for (int e = 0; e < 16; ++e) t4.insert(mv[tid][e], mi[tid][e]);
-        int n = n0 + tid;
-        if (n < ncols) {
-            long o = ((long)split * ncols + n) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                cand_v[o + e] = t4.v[e];
-                cand_i[o + e] = t4.i[e];
-            }
-        }
-    }
+    p1 = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+    p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
 }
 
-// Same search on the split-precision path (conv3s.h): sims from six bf16 part-products per K16 block, fp32
-// accumulation, error below the fp32 MFMA chain's (so the top-4 decisions are at least as faithful).
+// grid = qtiles * nsplit; workgroup = 128 queries x (tiles_per_split index tiles of 128).
 // 8 waves of 64 (index) x 32 (queries); the (tile, step) sequence is one flat pipeline: registers hold step g+1,
-// LDS is double-buffered, one raw barrier per step.
-static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const uint4* __restrict__ img, long Npad, int N,
-                                                                    const float* __restrict__ qn, int ncols, int T,
-                                                                    int nsplit, int tiles_per_split,
-                                                                    float* __restrict__ cand_v, int* __restrict__ cand_i) {
-    constexpr int STEPS = KD / 16;                       // 48
-    constexpr int A_U4 = 12 * 64, X_U4 = 3 * 2 * 128;    // one buffer each: 12 KiB + 12 KiB
-    __shared__ __attribute__((aligned(16))) uint4 smem[2 * (A_U4 + X_U4)];
-    __shared__ float mv[128][16];
-    __shared__ int mi[128][16];
+// LDS is double-buffered, one raw barrier per step.  NP = bf16 parts per index value (3: fp32 storage, 2: fp16 storage).
+constexpr int KNN_A_U4 = 12 * 64, KNN_X_U4 = 3 * 2 * 128;    // one LDS buffer each: 12 KiB + 12 KiB
+template <bool F16>
+__device__ __forceinline__ void knn_topk_body(const float* __restrict__ blob, long Npad, int N, const float* __restrict__ qn, int ncols, int T,
+                                              int nsplit, int tiles_per_split, float* __restrict__ cand_v, int* __restrict__ cand_i,
+                                              uint4* smem, float (*mv)[16], int (*mi)[16]) {
+    constexpr int NP = F16 ? 2 : 3;                    // parts per index value in LDS
+    constexpr int GP = F16 ? 4 : 12;                   // 1 KiB pieces per (tile, step) in the global image
     uint4* As = smem;
-    uint4* Xs = smem + 2 * A_U4;
+    uint4* Xs = smem + 2 * KNN_A_U4;
+    const uint4* img = F16 ? reinterpret_cast<const uint4*>(blob + HDR + Npad) : reinterpret_cast<const uint4*>(blob + HDR + (size_t)N * KD);
+    const float* inv = blob + HDR;                     // fp16 storage only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -283,8 +224,9 @@ static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const uint4*
     const int mt_hi = min(mtiles, mt_lo + tiles_per_split);
     const int G = (mt_hi - mt_lo) * STEPS;               // flat (tile, step) sequence
 
-    // staging roles: threads 0..255 own one query item (8 channels of one column) + weight piece tid / 64;
-    // threads 256..511 own weight pieces 4.. (two each)
+    // staging roles: threads 0..255 own one query item (8 channels of one column); the index pieces of a (tile, step) go
+    // to threads 0..255 (piece tid / 64) and 256..511 (two pieces each) for fp32 storage, to threads 256..511 (one fp16
+    // piece each, split into its two bf16 parts on the way into LDS) for fp16 storage
     const bool xrole = tid < 256;
     const float* qp = qn;
     int xdst = 0;
@@ -296,27 +238,36 @@ static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const uint4*
         qp = qn + ((long)b * KD + 8 * g) * T + t;
         xdst = g * 128 + pos;
     }
-    const int pa = xrole ? wave : 4 + 2 * (wave - 4);    // first weight piece of this thread
+    const int pa = F16 ? wave - 4 : (xrole ? wave : 4 + 2 * (wave - 4));    // first index piece of this thread
     float xr[8];
     u32x4 ar[2];
     auto gload = [&](int g) __attribute__((always_inline)) {
         const int mt = mt_lo + g / STEPS, st = g - (g / STEPS) * STEPS;
-        const uint4* src = img + ((long)mt * STEPS + st) * (12 * 64) + lane;
-        ar[0] = *reinterpret_cast<const u32x4*>(src + pa * 64);
-        if (!xrole) ar[1] = *reinterpret_cast<const u32x4*>(src + (pa + 1) * 64);
+        const uint4* src = img + ((long)mt * STEPS + st) * (GP * 64) + lane;
+        if (!F16 || !xrole) ar[0] = *reinterpret_cast<const u32x4*>(src + pa * 64);
+        if (!F16 && !xrole) ar[1] = *reinterpret_cast<const u32x4*>(src + (pa + 1) * 64);
         if (xrole) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) xr[j] = qp[(long)(st * 16 + j) * T];
         }
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
-        uint4* ab = As + buf * A_U4;
-        *reinterpret_cast<u32x4*>(ab + pa * 64 + lane) = ar[0];
-        if (!xrole) *reinterpret_cast<u32x4*>(ab + (pa + 1) * 64 + lane) = ar[1];
+        uint4* ab = As + buf * KNN_A_U4;
+        if (F16) {
+            if (!xrole) {
+                uint4 p1, p2;
+                split8_half(ar[0], p1, p2);
+                ab[(pa * 2) * 64 + lane] = p1;
+                ab[(pa * 2 + 1) * 64 + lane] = p2;
+            }
+        } else {
+            *reinterpret_cast<u32x4*>(ab + pa * 64 + lane) = ar[0];
+            if (!xrole) *reinterpret_cast<u32x4*>(ab + (pa + 1) * 64 + lane) = ar[1];
+        }
         if (xrole) {
             uint4 p1, p2, p3;
             split8(xr, p1, p2, p3);
-            uint4* xb = Xs + buf * X_U4;
+            uint4* xb = Xs + buf * KNN_X_U4;
             xb[xdst] = p1;
             xb[256 + xdst] = p2;
             xb[512 + xdst] = p3;
@@ -343,23 +294,24 @@ static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const uint4*
             lstore(cur ^ 1);                        // step g+1 (its buffer was last read in step g-1, behind the barrier)
             if (g + 2 < G) gload(g + 2);            // flies across this step's MFMAs and the next barrier
         }
-        const uint4* as = As + cur * A_U4 + wm * (6 * 64) + lane;
-        const uint4* xs = Xs + cur * X_U4 + lh * 128 + wn * 32 + l31;
-        bf16x8 af[2][3], bf[3];
+        const uint4* as = As + cur * KNN_A_U4 + wm * (2 * NP * 64) + lane;
+        const uint4* xs = Xs + cur * KNN_X_U4 + lh * 128 + wn * 32 + l31;
+        bf16x8 af[2][NP], bf[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(bf16x8, xs[p * 256]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[i][p] = __builtin_bit_cast(bf16x8, as[(i * 3 + p) * 64]);
-#if KNN_PIN
-        __builtin_amdgcn_sched_barrier(0);          // all nine reads, then the twelve MFMAs
-#endif
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+            for (int p = 0; p < NP; ++p) af[i][p] = __builtin_bit_cast(bf16x8, as[(i * NP + p) * 64]);
+        // part-products, least significant first: (index part, query part)
+        constexpr int NQ = F16 ? 5 : 6;
+        constexpr int PA3[6] = {2, 1, 0, 1, 0, 0}, PB3[6] = {0, 1, 2, 0, 1, 0};
+        constexpr int PA2[5] = {1, 0, 1, 0, 0}, PB2[5] = {1, 2, 0, 1, 0};
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[PB[q]], acc[i], 0, 0, 0);
+            for (int i = 0; i < 2; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][F16 ? PA2[q < 5 ? q : 0] : PA3[q]], bf[F16 ? PB2[q < 5 ? q : 0] : PB3[q]], acc[i], 0, 0, 0);
         const int st = g - (g / STEPS) * STEPS;
         if (st == STEPS - 1) {
             // running top-4: this lane's 16 registers are 16 index vectors against its own query
@@ -369,7 +321,11 @@ static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const uint4*
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < N) top.insert(nan_max(acc[i][r]), row);
+                    if (row < N) {
+                        float v = acc[i][r];
+                        if (F16) v *= inv[row];
+                        top.insert(nan_max(v), row);
+                    }
                     acc[i][r] = 0.f;
                 }
         }
@@ -403,17 +359,30 @@ static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const uint4*
     }
 }
 
+static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const float* __restrict__ blob, long Npad, int N,
+                                                                    const float* __restrict__ qn, int ncols, int T,
+                                                                    int nsplit, int tiles_per_split,
+                                                                    float* __restrict__ cand_v, int* __restrict__ cand_i) {
+    __shared__ __attribute__((aligned(16))) uint4 smem[2 * (KNN_A_U4 + KNN_X_U4)];
+    __shared__ float mv[128][16];
+    __shared__ int mi[128][16];
+    const int kind = reinterpret_cast<const int*>(blob)[1];      // uniform: which storage this prepared index uses
+    if (kind == KIND_F16) knn_topk_body<true>(blob, Npad, N, qn, ncols, T, nsplit, tiles_per_split, cand_v, cand_i, smem, mv, mi);
+    else knn_topk_body<false>(blob, Npad, N, qn, ncols, T, nsplit, tiles_per_split, cand_v, cand_i, smem, mv, mi);
+}
+
 // One workgroup = 32 consecutive query columns: merge split candidates -> top-4, write indices,
 // gather the 4 raw rows per query (coalesced along the feature axis), average, and write
 // out[b][k][t] through an LDS transpose so stores run along t.
 static __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
-                                                                      int nsplit, int ncols, int T, int N,
-                                                                      const float* __restrict__ rows,
+                                                                      int nsplit, int ncols, int T, int N, long Npad,
+                                                                      const float* __restrict__ blob,
                                                                       float* __restrict__ out, int64_t* __restrict__ idx_out) {
     __shared__ int sel[32][4];
     __shared__ float tile[32][193];
     const int tid = threadIdx.x;
     const int n0 = blockIdx.x * 32;
+    const int kind = reinterpret_cast<const int*>(blob)[1];
     if (tid < 32) {
         int n = n0 + tid;
         Top4 t4;
@@ -434,15 +403,13 @@ static __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const floa
     for (int kc = 0; kc < KD; kc += 192) {
         // gather: wave handles queries wave, wave+4, ...; lanes run along k (3 x 64 = 192)
         for (int q = wave; q < 32; q += 4) {
-            const float* r0 = rows + (long)sel[q][0] * KD + kc;
-            const float* r1 = rows + (long)sel[q][1] * KD + kc;
-            const float* r2 = rows + (long)sel[q][2] * KD + kc;
-            const float* r3 = rows + (long)sel[q][3] * KD + kc;
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-                int k = lane + 64 * u;
-                float sum = __fadd_rn(__fadd_rn(__fadd_rn(r0[k], r1[k]), r2[k]), r3[k]);
-                tile[q][k] = sum * 0.25f;
+                const int k = kc + lane + 64 * u;
+                const float r0 = blob_row_value(blob, kind, N, Npad, sel[q][0], k), r1 = blob_row_value(blob, kind, N, Npad, sel[q][1], k);
+                const float r2 = blob_row_value(blob, kind, N, Npad, sel[q][2], k), r3 = blob_row_value(blob, kind, N, Npad, sel[q][3], k);
+                float sum = __fadd_rn(__fadd_rn(__fadd_rn(r0, r1), r2), r3);
+                tile[q][lane + 64 * u] = sum * 0.25f;
             }
         }
         __syncthreads();
@@ -477,13 +444,18 @@ static __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __re
     }
 }
 // slots[n][e][:] = raw row idx[n][e] of this shard, or zeros where idx < 0 (the row lives on another rank)
-static __global__ __launch_bounds__(192) void knn_slot_gather_kernel(const float* __restrict__ rows, const int64_t* __restrict__ idx, long nslots,
-                                                                     long N, float* __restrict__ slots) {
+static __global__ __launch_bounds__(192) void knn_slot_gather_kernel(const float* __restrict__ blob, const int64_t* __restrict__ idx, long nslots,
+                                                                     long N, long Npad, float* __restrict__ slots) {
     const long sl = blockIdx.x;
     if (sl >= nslots) return;
+    const int kind = reinterpret_cast<const int*>(blob)[1];
     const int64_t i = idx[sl];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i >= 0 && i < N) v = reinterpret_cast<const float4*>(rows + i * KD)[threadIdx.x];
+    if (i >= 0 && i < N) {
+        const int k = 4 * threadIdx.x;
+        v = make_float4(blob_row_value(blob, kind, N, Npad, i, k), blob_row_value(blob, kind, N, Npad, i, k + 1),
+                        blob_row_value(blob, kind, N, Npad, i, k + 2), blob_row_value(blob, kind, N, Npad, i, k + 3));
+    }
     reinterpret_cast<float4*>(slots + sl * KD)[threadIdx.x] = v;
 }
 // out[b][k][t] = (((s0 + s1) + s2) + s3) * 0.25 from slots [B*T][4][768] (the same order as the single-GPU gather),
@@ -516,32 +488,52 @@ static __global__ __launch_bounds__(256) void knn_finish_kernel(const float* __r
     }
 }
 
-int run_knn_topk(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, const float* prepared, int64_t N,
-                 float* sims_out, int64_t* idx_out, int B, int T) {
-    const int ncols = B * T;
-    const long Npad = npad128(N);
-    const int qtiles = (ncols + 127) / 128;
-    const int mtiles = (int)(Npad / 128);
-    int nsplit = (KNN_BLOCKS + qtiles - 1) / qtiles;
+struct KnnPlan {
+    int ncols, qtiles, nsplit, tps;
+    long Npad;
+};
+static KnnPlan knn_plan(int B, int T, int64_t N) {
+    KnnPlan p;
+    p.ncols = B * T;
+    p.Npad = npad128(N);
+    p.qtiles = (p.ncols + 127) / 128;
+    const int mtiles = (int)(p.Npad / 128);
+    int nsplit = (KNN_BLOCKS + p.qtiles - 1) / p.qtiles;
     if (nsplit > mtiles) nsplit = mtiles;
     if (nsplit < 1) nsplit = 1;
-    const int tps = (mtiles + nsplit - 1) / nsplit;
-    nsplit = (mtiles + tps - 1) / tps;
+    p.tps = (mtiles + nsplit - 1) / nsplit;
+    p.nsplit = (mtiles + p.tps - 1) / p.tps;
+    return p;
+}
+
+// query normalisation + the per-split top-4 candidates of every query; shared by the whole-index match and the
+// index-sharded variant
+static int knn_candidates(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, const float* prepared, int64_t N, int B, int T,
+                          const KnnPlan& p, float** cv, int** ci) {
     float* qn = ws.get<float>((size_t)B * KD * T);
-    float* cv = ws.get<float>((size_t)nsplit * ncols * 4);
-    int* ci = ws.get<int>((size_t)nsplit * ncols * 4);
+    *cv = ws.get<float>((size_t)p.nsplit * p.ncols * 4);
+    *ci = ws.get<int>((size_t)p.nsplit * p.ncols * 4);
     if (dry) return 0;
     if (N > 0x7fffff00L) return fail(ctx, TVC_ERR_ARG, "index too large");
-    hipLaunchKernelGGL(query_normalize_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, src, qn, B, T);
-    const uint4* img = reinterpret_cast<const uint4*>(prepared + (size_t)KD * Npad + (size_t)N * KD);
-    hipLaunchKernelGGL(knn_topk_split_kernel, dim3((unsigned)(qtiles * nsplit)), dim3(512), 0, s, img, Npad, (int)N, qn, ncols, T, nsplit, tps, cv, ci);
-    hipLaunchKernelGGL(knn_merge_kernel, dim3((ncols + 255) / 256), dim3(256), 0, s, cv, ci, nsplit, ncols, sims_out, idx_out);
+    hipLaunchKernelGGL(query_normalize_kernel, dim3((p.ncols + 63) / 64), dim3(256), 0, s, src, qn, B, T);
+    hipLaunchKernelGGL(knn_topk_split_kernel, dim3((unsigned)(p.qtiles * p.nsplit)), dim3(512), 0, s, prepared, p.Npad, (int)N, qn, p.ncols, T,
+                       p.nsplit, p.tps, *cv, *ci);
+    return 0;
+}
+
+int run_knn_topk(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, const float* prepared, int64_t N,
+                 float* sims_out, int64_t* idx_out, int B, int T) {
+    const KnnPlan p = knn_plan(B, T, N);
+    float* cv;
+    int* ci;
+    TVC_CHECK(knn_candidates(ctx, s, ws, dry, src, prepared, N, B, T, p, &cv, &ci));
+    if (dry) return 0;
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((p.ncols + 255) / 256), dim3(256), 0, s, cv, ci, p.nsplit, p.ncols, sims_out, idx_out);
     return launch_check(ctx, "knn_topk");
 }
 
 int run_knn_slots(tvc_ctx* ctx, hipStream_t s, const float* prepared, int64_t N, const int64_t* idx, float* slots, int64_t nslots) {
-    const float* rows = prepared + (size_t)KD * npad128(N);
-    hipLaunchKernelGGL(knn_slot_gather_kernel, dim3((unsigned)nslots), dim3(192), 0, s, rows, idx, (long)nslots, (long)N, slots);
+    hipLaunchKernelGGL(knn_slot_gather_kernel, dim3((unsigned)nslots), dim3(192), 0, s, prepared, idx, (long)nslots, (long)N, (long)npad128(N), slots);
     return launch_check(ctx, "knn_slots");
 }
 
@@ -553,31 +545,13 @@ int run_knn_finish(tvc_ctx* ctx, hipStream_t s, const float* slots, float* out, 
 
 int run_knn(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, const float* prepared, int64_t N,
             float* out, int64_t* idx_out, int B, int T) {
-    const int ncols = B * T;
-    const long Npad = npad128(N);
-    const int qtiles = (ncols + 127) / 128;
-    const int mtiles = (int)(Npad / 128);
-    int nsplit = (KNN_BLOCKS + qtiles - 1) / qtiles;
-    if (nsplit > mtiles) nsplit = mtiles;
-    if (nsplit < 1) nsplit = 1;
-    const int tps = (mtiles + nsplit - 1) / nsplit;
-    nsplit = (mtiles + tps - 1) / tps;
-    float* qn = ws.get<float>((size_t)B * KD * T);
-    float* cv = ws.get<float>((size_t)nsplit * ncols * 4);
-    int* ci = ws.get<int>((size_t)nsplit * ncols * 4);
+    const KnnPlan p = knn_plan(B, T, N);
+    float* cv;
+    int* ci;
+    TVC_CHECK(knn_candidates(ctx, s, ws, dry, src, prepared, N, B, T, p, &cv, &ci));
     if (dry) return 0;
-    if (N > 0x7fffff00L) return fail(ctx, TVC_ERR_ARG, "index too large");
-    hipLaunchKernelGGL(query_normalize_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, src, qn, B, T);
-    if (KNN_SPLIT) {
-        const uint4* img = reinterpret_cast<const uint4*>(prepared + (size_t)KD * Npad + (size_t)N * KD);
-        hipLaunchKernelGGL(knn_topk_split_kernel, dim3((unsigned)(qtiles * nsplit)), dim3(512), 0, s, img, Npad, (int)N, qn, ncols, T,
-                           nsplit, tps, cv, ci);
-    } else {
-        hipLaunchKernelGGL(knn_topk_kernel, dim3((unsigned)(qtiles * nsplit)), dim3(KNN_WAVES * 64), 0, s, prepared, Npad, (int)N, qn,
-                           ncols, T, nsplit, tps, cv, ci);
-    }
-    hipLaunchKernelGGL(knn_merge_gather_kernel, dim3((ncols + 31) / 32), dim3(256), 0, s, cv, ci, nsplit, ncols, T, (int)N,
-                       prepared + (size_t)KD * Npad, out, idx_out);
+    hipLaunchKernelGGL(knn_merge_gather_kernel, dim3((p.ncols + 31) / 32), dim3(256), 0, s, cv, ci, p.nsplit, p.ncols, T, (int)N, p.Npad,
+                       prepared, out, idx_out);
     return launch_check(ctx, "knn_match");
 }
 

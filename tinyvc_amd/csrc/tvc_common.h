@@ -89,13 +89,11 @@ struct tvc_ctx {
     std::map<std::string, tvc::HostTensor> host;  // staged checkpoint tensors
     std::vector<float> pitch_table;
     float* arena = nullptr;        // packed checkpoint weights, one allocation per finalize
-    float* const_arena = nullptr;  // DFT tables, built at ctx_create
+    float* const_arena = nullptr;  // FFT tables, built at ctx_create
     size_t arena_floats = 0;
     char err[512] = {0};
 
     // constant tables
-    tvc::PackedW stft_re, stft_im;   // windowed forward real DFT, even/odd halves (see build_dft_tables)
-    tvc::PackedW istft_e, istft_o;   // inverse real DFT, even/odd halves, 1/N folded in
     const float* fft_tw960 = nullptr;    // fft.hip tables: (cos, sin)(2 pi j / 960) [960], (cos, sin)(2 pi k / 1920) [961], periodic Hann [1920]
     const float* fft_tw1920 = nullptr;
     const float* fft_hann = nullptr;
@@ -234,18 +232,15 @@ int run_dsp(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* f0, const float* 
 int run_sola(tvc_ctx*, hipStream_t, const float* y, float* sola_buf, const float* fade_in, float* out, int32_t* shift_out,
              int S, int64_t Ly, int block, int use_pv);
 int run_prepare_index(tvc_ctx*, hipStream_t, const float* index, float* prepared, int64_t N);
+int run_prepare_index_f16(tvc_ctx*, hipStream_t, const void* rows_f16, float* prepared, int64_t N);
 
-// fused FilterNet kernels (filter_fused.hip)
-int run_up24_fused(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len,
-                   const float* w7, const float* b7);
+// fused FilterNet kernels (filter_up24s.hip, conv48s.hip)
 int run_up24_split(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len);
 int run_down0_split(tvc_ctx*, hipStream_t, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len);
 int run_down24_split(tvc_ctx*, hipStream_t, const DownW& d, const float* xi, const float* res, float* h1, float* h2, float* out, float* y2, int B, int len);
 int run_conv48s(tvc_ctx*, hipStream_t, const PackedW& w, const float* x, int lin, float lscale, const PackedW* film, const float* bsc, const float* bsh,
                 const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil, const PackedW* c5 = nullptr,
                 float* out5 = nullptr);
-int run_down0(tvc_ctx*, hipStream_t, const PackedW& w, const float* source, const float* energy, float* out, int B, int len);
-int run_out_conv7(tvc_ctx*, hipStream_t, const float* x, const float* w_raw, const float* bias, float* y, int B, int C, int len);
 
 // ConvNeXt-v2 layer on x [B, C, T] in place (convnext.py:49-58); tmp buffers from ws.
 int run_convnext(tvc_ctx*, hipStream_t, Ws&, bool dry, const ConvNeXtW& w, float* x, int B, int T);

@@ -167,8 +167,12 @@ class Engine:
         return f0
 
     def knn_prepare(self, index):
-        """index: [768, N] or [1, 768, N] -> prepared blob (1-D float tensor)."""
-        idx = _prep(index, "index", self.device)
+        """index: [768, N] or [1, 768, N] -> (prepared blob (1-D float tensor), N).  An fp32 index gets the fp32 storage
+        (bit-exact indices on gap-checked inputs); a torch.float16 index gets the fp16 storage (2 B per element: the
+        1 M-vector case).  The blob is self-describing: knn_match / convert take either."""
+        _check_dev(index, "index", self.device)
+        half = index.dtype == torch.float16
+        idx = index if half else _prep(index, "index", self.device)
         if idx.dim() == 3:
             if idx.shape[0] != 1:
                 raise ValueError("knn_prepare takes one index ([1, 768, N])")
@@ -178,6 +182,11 @@ class Engine:
         N = idx.shape[1]
         if N < 4:
             raise RuntimeError("selected index k out of range")  # what torch.topk raises in the reference
+        if half:
+            rows = idx.t().contiguous()          # [N, 768] half, one vector per row
+            blob = torch.empty(self.lib.tvc_knn_prepared_elems_f16(N), dtype=_F32, device=self.device)
+            self._ok(self.lib.tvc_knn_prepare_index_f16(self.ctx, self._stream(), _ptr(rows), _ptr(blob), N), "tvc_knn_prepare_index_f16")
+            return blob, N
         blob = torch.empty(self.lib.tvc_knn_prepared_elems(N), dtype=_F32, device=self.device)
         self._ok(self.lib.tvc_knn_prepare_index_f32(self.ctx, self._stream(), _ptr(idx.contiguous()), _ptr(blob), N), "tvc_knn_prepare_index_f32")
         return blob, N
