@@ -182,12 +182,13 @@ struct Top4 {
 };
 
 // two bf16 parts of 8 fp16 values (exact: 11 significant bits fit in 8 + 8), packed for one 16-byte LDS row each
-__device__ __forceinline__ void split8_half(const u32x4& h8, uint4& p1, uint4& p2) {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8_half(const u32x4 h8, uint4& p1, uint4& p2) {
+    const f16x8 hv = __builtin_bit_cast(f16x8, h8);
     unsigned o1[4], o2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const __half2 hh = __builtin_bit_cast(__half2, h8[j]);
-        f32x2 a = {__low2float(hh), __high2float(hh)};
+        f32x2 a = {(float)hv[2 * j], (float)hv[2 * j + 1]};
         bf16x2 h1 = __builtin_convertvector(a, bf16x2);
         f32x2 r = a - __builtin_convertvector(h1, f32x2);
         bf16x2 h2 = __builtin_convertvector(r, bf16x2);
