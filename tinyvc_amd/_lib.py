@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinyvc_hip.so")
+LIB_PATH = os.environ.get("TVC_LIB_PATH") or os.path.join(_HERE, "libtinyvc_hip.so")   # TVC_LIB_PATH: same-box A/B runs of two builds
 
 _lib = None
 
