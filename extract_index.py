@@ -18,7 +18,6 @@ import torch
 from tinyvc_amd import audio_io
 from tinyvc_amd.module import utils
 from tinyvc_amd.module.tinyvc import Encoder
-from tinyvc_amd.resample import resample
 
 
 def main(argv=None):
@@ -30,6 +29,7 @@ def main(argv=None):
     p.add_argument("-d", "--device", default="cuda")
     p.add_argument("--stride", default=4, type=int)
     p.add_argument("--seed", default=None, type=int, help="fix the shuffle (the reference does not seed it)")
+    p.add_argument("--half", action="store_true", help="store the index in half precision (matched with the fp16 index storage: 2 B per element)")
     args = p.parse_args(argv)
 
     device = torch.device(args.device)
@@ -44,7 +44,7 @@ def main(argv=None):
     feats, total = [], 0
     for i in order:
         wf, sr = audio_io.load(files[i])
-        wf = resample(wf, sr, 24000).mean(dim=0, keepdim=True).to(device)
+        wf = enc.engine(device).resample(wf.to(device), sr, 24000).mean(dim=0, keepdim=True)
         spec = utils.spectrogram(utils.autopad_waveform(wf), enc.n_fft, enc.hop_size)
         z, _f0 = enc.infer(spec)
         z = z.cpu()[:, :, ::args.stride]
@@ -55,6 +55,8 @@ def main(argv=None):
     feats = torch.cat(feats, dim=2)
     perm = torch.randperm(feats.shape[2], generator=gen)
     tgt = feats.index_select(2, perm)[:, :, :args.size].contiguous()
+    if args.half:
+        tgt = tgt.half()
     print(f"Extracted {tgt.shape[2]} vectors")
     os.makedirs(os.path.dirname(os.path.abspath(args.output)), exist_ok=True)
     torch.save(tgt, args.output)

@@ -72,6 +72,21 @@ int tvc_stft_mag_f32(tvc_ctx* ctx, void* stream, const float* wav, float* spec, 
 int tvc_energy_f32(tvc_ctx* ctx, void* stream, const float* wav, float* energy, int B, int64_t L,
                    void* ws, size_t ws_bytes);
 
+/* front door ------------------------------------------------------------------------------- */
+/* torchaudio.functional.resample(waveform, orig_freq, new_freq) as the entry scripts call it (reference infer.py:46,63;
+ * infer_streaming.py:70): x [rows, n] -> y [rows, tvc_resample_out_len(n, ...)] with torchaudio's default Hann-windowed
+ * sinc polyphase filter (lowpass_filter_width 6, rolloff 0.99).  torchaudio itself is not available to pin this against
+ * (SURVEY.md 8c): the parity reference is this repository's host restatement tinyvc_amd/resample.py. */
+int64_t tvc_resample_out_len(int64_t n, int orig_freq, int new_freq);
+int tvc_resample_f32(tvc_ctx* ctx, void* stream, const float* x, float* y, int rows, int64_t n, int orig_freq,
+                     int new_freq);
+/* The streaming loop's sample conversions (reference infer_streaming.py:85-94): int16 PCM -> float / 32768 ->
+ * torchaudio.functional.gain(gain_db) on the way in; gain(gain_db) -> * 32768 -> numpy's float32 -> int16 cast
+ * (truncation toward zero, wrap-around outside int16) on the way out.  gain_db == 0 skips the gain multiply, as
+ * torchaudio does. */
+int tvc_pcm16_to_f32(tvc_ctx* ctx, void* stream, const int16_t* pcm, float* y, int64_t n, float gain_db);
+int tvc_f32_to_pcm16(tvc_ctx* ctx, void* stream, const float* x, int16_t* pcm, int64_t n, float gain_db);
+
 /* encoder --------------------------------------------------------------------------------- */
 /* Encoder.infer (reference module/tinyvc/encoder.py:113-116): spec [B,961,T] ->
  * ssl [B,768,T], f0 [B,1,T]; `logits` [B,512,T] is optional (NULL to skip): Encoder.forward's

@@ -8,9 +8,15 @@ reference infer.py:17-29) driving the HIP path.
 Differences from the reference, all at the edges of the path: files are read/written with the
 package's own WAV I/O and resampler (torchaudio is not a dependency; ogg/mp3 need a codec and are
 skipped with a message); `-d` defaults to `cuda` and must be a GPU (there is no CPU path);
-all inputs of equal padded length are converted as one batch.  `--chunk-size / --buffer-size /
---no-chunking` are accepted and, as in the reference (infer.py:27-29,40-41,66), do not change the
-computation: every file is converted whole.
+all inputs of equal padded length are converted as one batch; resampling to 24 kHz runs on the GPU
+(tvc_resample_f32); an index.pt stored in half precision is matched with the fp16 index storage.
+
+`--chunk-size / --buffer-size / --no-chunking`: the reference parses them and then converts every file
+whole (infer.py:27-29,40-41,66), so that is the default here too (identical output).  `--chunked` makes
+them real: the file is fed through the streaming converter in blocks of --chunk-size
+samples with --buffer-size blocks of extra left context, SOLA-aligned and cross-faded (sin^2, or the
+phase vocoder with --phase-vocoder) exactly as StreamInfer does, so memory stays bounded for
+hour-long inputs.  `--no-chunking True` overrides `--chunked`.
 """
 import argparse
 import glob
@@ -22,7 +28,6 @@ import torch
 from tinyvc_amd import audio_io
 from tinyvc_amd.module.infer import Generator
 from tinyvc_amd.module.tinyvc import Decoder, Encoder
-from tinyvc_amd.resample import resample
 
 SAMPLE_RATE = 24000
 
@@ -41,6 +46,8 @@ def build_parser():
     p.add_argument("-c", "--chunk-size", default=1920, type=int)
     p.add_argument("-b", "--buffer-size", default=4, type=int)
     p.add_argument("-nc", "--no-chunking", default=False, type=bool)
+    p.add_argument("--chunked", action="store_true", help="honour --chunk-size / --buffer-size: block-wise conversion with SOLA cross-fades (bounded memory)")
+    p.add_argument("--phase-vocoder", action="store_true", help="--chunked: phase-vocoder cross-fade (StreamInfer's use_phase_vocoder) instead of sin^2")
     return p
 
 
@@ -55,10 +62,31 @@ def load_target(gen, args, device):
     """Speaker target: features of a target utterance, or a prebuilt index.pt [1, 768, N]."""
     if args.index == "NONE":
         wf, sr = audio_io.load(args.target)
-        wf = resample(wf, sr, SAMPLE_RATE).to(device)
+        wf = gen.engine(device).resample(wf.to(device), sr, SAMPLE_RATE)
         tgt, _f0 = gen.encode(wf.mean(dim=0, keepdim=True) if wf.shape[0] > 1 else wf)
         return tgt
-    return torch.load(args.index, map_location="cpu").to(device)
+    return torch.load(args.index, map_location="cpu").to(device)     # fp32 [1,768,N], or half: fp16 index storage
+
+
+SOLA_LATENCY = 1920 + 3840 + 960     # cross-fade + last delay + half the search range: nominal lag of StreamInfer's output
+
+
+@torch.no_grad()
+def convert_chunked(gen, batch, tgt, pitch_shift, chunk_size, buffer_blocks, use_phase_vocoder=False):
+    """Block-wise conversion of `batch` [B, L] with bounded memory: every utterance is a stream of `chunk_size`-sample
+    blocks through BatchedStreamInfer (rolling buffer with `buffer_blocks` blocks of extra context, full convert per
+    block, SOLA alignment + cross-fade: reference module/infer/stream.py:68-96).  The streaming output lags its input by
+    ~SOLA_LATENCY samples; the lag is flushed with silence and trimmed so the result has the input's length."""
+    from tinyvc_amd.module.infer import BatchedStreamInfer
+    B, L = batch.shape
+    st = BatchedStreamInfer(gen, n_streams=B, target=tgt, pitch_shift=pitch_shift, device=batch.device, block_size=chunk_size,
+                            extra_size=buffer_blocks * chunk_size, use_phase_vocoder=use_phase_vocoder, use_graph=True)
+    st.init_buffer()
+    nblk = -(-(L + SOLA_LATENCY) // chunk_size)
+    padded = torch.zeros(B, nblk * chunk_size, device=batch.device)
+    padded[:, :L] = batch
+    outs = [st.audio_callback(padded[:, i * chunk_size:(i + 1) * chunk_size]) for i in range(nblk)]
+    return torch.cat(outs, dim=1)[:, SOLA_LATENCY:SOLA_LATENCY + L]
 
 
 def main(argv=None):
@@ -79,7 +107,7 @@ def main(argv=None):
             print(f"Skipping {path}: no decoder for this container in this build")
             continue
         wf, sr = audio_io.load(path)
-        wf = resample(wf, sr, SAMPLE_RATE).mean(dim=0, keepdim=True)       # mono, 24 kHz (infer.py:63-64)
+        wf = gen.engine(device).resample(wf.to(device), sr, SAMPLE_RATE).mean(dim=0, keepdim=True)       # mono, 24 kHz (infer.py:63-64), on the GPU
         jobs.append((path, wf))
 
     # group equal-length inputs so each group is one batched convert
@@ -89,7 +117,10 @@ def main(argv=None):
     for length, group in by_len.items():
         print(f"Converting {len(group)} file(s) of {length} samples ...")
         batch = torch.cat([wf for _p, wf in group], dim=0).to(device)
-        out = gen.convert(batch, tgt, args.pitch_shift).cpu()
+        if args.chunked and not args.no_chunking:
+            out = convert_chunked(gen, batch, tgt, args.pitch_shift, args.chunk_size, args.buffer_size, args.phase_vocoder).cpu()
+        else:
+            out = gen.convert(batch, tgt, args.pitch_shift).cpu()
         for (path, _wf), y in zip(group, out):
             name = os.path.splitext(os.path.basename(path))[0]
             audio_io.save(os.path.join(args.outputs, f"{name}.wav"), y[None], SAMPLE_RATE)

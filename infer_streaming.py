@@ -72,7 +72,7 @@ def main(argv=None):
                                 extra_size=args.extra, f0_estimation=args.f0_estimation)
     if args.index == "NONE":
         wf, sr = audio_io.load(args.target)
-        wf = resample(wf, sr, 24000).to(device)
+        wf = gen.engine(device).resample(wf.to(device), sr, 24000)
         tgt, _ = gen.encode(wf.mean(dim=0, keepdim=True))
     else:
         tgt = torch.load(args.index, map_location="cpu").to(device)
@@ -81,11 +81,10 @@ def main(argv=None):
 
     def process(chunk_i16):
         """One pass of the reference's loop body (infer_streaming.py:84-94) for S streams."""
-        x = torch.from_numpy(chunk_i16.astype(np.float32)).to(device) / 32768
-        x = gain(x, args.input_gain)
+        eng = gen.engine(device)
+        x = eng.pcm16_to_f32(torch.from_numpy(np.ascontiguousarray(chunk_i16)).to(device), args.input_gain)      # / 32768, gain: on the GPU
         y = stream.audio_callback(x.expand(S, -1) if x.dim() == 1 else x)
-        y = gain(y, args.output_gain)
-        return (y.cpu().numpy() * 32768).astype(np.int16)
+        return eng.f32_to_pcm16(y, args.output_gain).cpu().numpy()                                                # gain, * 32768, int16: on the GPU
 
     if args.input_wav is None:
         try:

@@ -24,6 +24,10 @@ SIGNATURES = {
     "tvc_workspace_bytes": (c_int, [c_void_p, c_int, c_int64, c_int64, POINTER(c_size_t)]),
     "tvc_stft_mag_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_size_t]),
     "tvc_energy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_size_t]),
+    "tvc_resample_out_len": (c_int64, [c_int64, c_int, c_int]),
+    "tvc_resample_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int]),
+    "tvc_pcm16_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float]),
+    "tvc_f32_to_pcm16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float]),
     "tvc_encoder_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_pitch_decode_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "tvc_knn_prepared_elems": (c_int64, [c_int64]),

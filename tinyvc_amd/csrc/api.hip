@@ -431,6 +431,7 @@ void tvc_ctx_destroy(tvc_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    frontdoor_release(ctx);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->const_arena) (void)hipFree(ctx->const_arena);
     delete ctx;
@@ -655,6 +656,29 @@ int tvc_stft_mag_f32(tvc_ctx* ctx, void* stream, const float* wav, float* spec, 
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(run_stft(ctx, s, ws, true, wav, spec, B, L), run_stft(ctx, s, ws, false, wav, spec, B, L));
+}
+
+int64_t tvc_resample_out_len(int64_t n, int orig_freq, int new_freq) { return resample_out_len(n, orig_freq, new_freq); }
+
+int tvc_resample_f32(tvc_ctx* ctx, void* stream, const float* x, float* y, int rows, int64_t n, int orig_freq, int new_freq) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!x || !y || rows <= 0 || n <= 0 || orig_freq <= 0 || new_freq <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_resample_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_resample(ctx, (hipStream_t)stream, x, y, rows, n, orig_freq, new_freq);
+}
+
+int tvc_pcm16_to_f32(tvc_ctx* ctx, void* stream, const int16_t* pcm, float* y, int64_t n, float gain_db) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!pcm || !y || n <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_pcm16_to_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_pcm16_to_f32(ctx, (hipStream_t)stream, pcm, y, n, gain_db);
+}
+
+int tvc_f32_to_pcm16(tvc_ctx* ctx, void* stream, const float* x, int16_t* pcm, int64_t n, float gain_db) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!x || !pcm || n <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_f32_to_pcm16: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_f32_to_pcm16(ctx, (hipStream_t)stream, x, pcm, n, gain_db);
 }
 
 int tvc_energy_f32(tvc_ctx* ctx, void* stream, const float* wav, float* energy, int B, int64_t L, void* wsp, size_t ws_bytes) {

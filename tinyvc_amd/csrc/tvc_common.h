@@ -231,6 +231,11 @@ int run_dsp(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* f0, const float* 
             const float* angle, uint64_t seed, float* source, int B, int T);
 int run_sola(tvc_ctx*, hipStream_t, const float* y, float* sola_buf, const float* fade_in, float* out, int32_t* shift_out,
              int S, int64_t Ly, int block, int use_pv);
+int64_t resample_out_len(int64_t n, int orig_freq, int new_freq);
+int run_resample(tvc_ctx*, hipStream_t, const float* x, float* y, int rows, int64_t n, int orig_freq, int new_freq);
+int run_pcm16_to_f32(tvc_ctx*, hipStream_t, const int16_t* pcm, float* y, int64_t n, float gain_db);
+int run_f32_to_pcm16(tvc_ctx*, hipStream_t, const float* x, int16_t* pcm, int64_t n, float gain_db);
+void frontdoor_release(tvc_ctx*);
 int run_prepare_index(tvc_ctx*, hipStream_t, const float* index, float* prepared, int64_t N);
 int run_prepare_index_f16(tvc_ctx*, hipStream_t, const void* rows_f16, float* prepared, int64_t N);
 

@@ -144,6 +144,39 @@ class Engine:
         self._ok(self.lib.tvc_energy_f32(self.ctx, self._stream(), _ptr(wav), _ptr(out), B, L, p, n), "tvc_energy_f32")
         return out
 
+    # ------------------------------------------------------------------ front door (entry scripts)
+    def resample(self, wav, orig_freq, new_freq):
+        """torchaudio.functional.resample on the device: wav [..., n] -> [..., ceil(n * new / orig)]."""
+        orig_freq, new_freq = int(orig_freq), int(new_freq)
+        wav = _prep(wav, "wave", self.device)
+        if orig_freq == new_freq:
+            return wav
+        shape = wav.shape
+        x = wav.reshape(-1, shape[-1])
+        n_out = self.lib.tvc_resample_out_len(x.shape[1], orig_freq, new_freq)
+        y = torch.empty(x.shape[0], n_out, dtype=_F32, device=self.device)
+        self._ok(self.lib.tvc_resample_f32(self.ctx, self._stream(), _ptr(x), _ptr(y), x.shape[0], x.shape[1], orig_freq, new_freq), "tvc_resample_f32")
+        return y.reshape(shape[:-1] + (n_out,))
+
+    def pcm16_to_f32(self, pcm, gain_db=0.0):
+        """int16 PCM -> float in [-1, 1) (x / 32768), then torchaudio.functional.gain(gain_db) (infer_streaming.py:85-89)."""
+        _check_dev(pcm, "pcm", self.device)
+        if pcm.dtype != torch.int16:
+            raise ValueError("pcm must be int16")
+        pcm = pcm.contiguous()
+        y = torch.empty(pcm.shape, dtype=_F32, device=self.device)
+        if pcm.numel():
+            self._ok(self.lib.tvc_pcm16_to_f32(self.ctx, self._stream(), _ptr(pcm), _ptr(y), pcm.numel(), float(gain_db)), "tvc_pcm16_to_f32")
+        return y
+
+    def f32_to_pcm16(self, x, gain_db=0.0):
+        """gain(gain_db) -> * 32768 -> int16 (numpy's cast: truncation toward zero) (infer_streaming.py:91-94)."""
+        x = _prep(x, "wave", self.device)
+        pcm = torch.empty(x.shape, dtype=torch.int16, device=self.device)
+        if x.numel():
+            self._ok(self.lib.tvc_f32_to_pcm16(self.ctx, self._stream(), _ptr(x), _ptr(pcm), x.numel(), float(gain_db)), "tvc_f32_to_pcm16")
+        return pcm
+
     def encoder(self, spec_t, want_logits=False):
         x = _prep(spec_t, "spec", self.device)
         B, C, T = x.shape
