@@ -37,8 +37,8 @@ def test_infer_py_with_index(workdir):
         assert sr == 24000 and y.shape == (1, 12000) and torch.isfinite(y).all() and float(y.abs().max()) > 1e-3
         outs[name] = y
     # same computation through the module API, same seed -> identical samples
-    from tinyvc_amd.resample import resample
     gen = infer.load_generator(str(workdir / "encoder.pt"), str(workdir / "decoder.pt"), torch.device("cuda:0"))
+    resample = lambda w, a, b: gen.engine("cuda:0").resample(w.to("cuda:0"), a, b)      # the device resampler infer.py uses
     tgt = torch.load(workdir / "index.pt").to("cuda:0")
     wa, sr = audio_io.load(str(workdir / "inputs" / "a.wav"))
     wb, _ = audio_io.load(str(workdir / "inputs" / "b.wav"))
