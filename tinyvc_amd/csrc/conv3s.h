@@ -1166,7 +1166,7 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
 template <int MTB, int NWV, int BPC, int KG, class Epi, bool SCALED, bool CLAMP>
 inline int gemm_s_launch_k(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
                            const float* kscale, int cmax) {
-    using TL = SplitTile<MTB, 1, NWV, 1, KG, 0>;
+    using TL = SplitTile<MTB, (MTB >= 4 ? 2 : 1), NWV, 1, KG, 0>;     // MTB >= 4: a wave owns two m-tiles (64 x 32), 8 waves cover 128 x 128
     // flat column tiles unless a tile could touch more than two utterances of a SCALED launch (factors of two are staged)
     // or the element offsets would not fit 32 bits
     const long xs = xstride ? xstride : (long)Cin * len;

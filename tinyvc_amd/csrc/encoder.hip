@@ -7,7 +7,7 @@
 namespace tvc {
 
 #ifndef ENC_NWV
-#define ENC_MTB 2
+#define ENC_MTB 4
 #define ENC_NWV 4
 #define ENC_BPC 2
 #endif
