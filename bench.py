@@ -167,7 +167,8 @@ def main():
     # stage timers: hipEvent pairs recorded by the library on the launch stream.  They are switched on for
     # the warm-up too, so that the context's event pool is populated before the timed region
     # (creating events mid-stream stalls it).
-    eng.profile(True)
+    timers = not os.environ.get("TVC_BENCH_NOTIMERS")     # diagnostic: run without the library's hipEvent stage timers (no roofline then)
+    eng.profile(timers)
     step()
     eng.profile_read()
     for _ in range(args.warmup):
@@ -219,7 +220,7 @@ def main():
         # bytes that really crossed HBM (PMC); the layer-boundary byte model (north_star's 40 % target) stays in
         # `hbm.frac` / `hbm_layer_boundary_frac` but is never what selects `bound` once blocks are fused.
         roof = None
-        if t_filter > 0:
+        if t_filter > 0 and timers:
             moved = hbm["moved_frac"]
             bound = "mfma" if (moved is None or mfma["frac"] >= moved) else "hbm"
             pick = mfma if bound == "mfma" else {"achieved": hbm["moved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved}

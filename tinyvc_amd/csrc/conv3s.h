@@ -14,11 +14,13 @@
 //             Xs[part][channel-group][position][8 bf16]; a tap is a row offset, so every ds_read_b128 of
 //             the MFMA loop is a contiguous 1 KiB wave access.
 //   tile      a wave owns all MTB m-tiles of the workgroup for one 32-sample n-tile.
-// Pipeline.  At this MFMA rate a slab's compute (1.7 k cycles per wave) is shorter than the HBM latency
-// (~5 k cycles measured), so the latency is hidden by occupancy, not inside one workgroup: small
-// workgroups (4 waves, 45 KB LDS) run three to a CU, each with the next slab's loads in flight in
-// registers across its own compute.  Barriers are raw s_barrier + lgkmcnt(0): __syncthreads() also
-// drains vmcnt, i.e. it would wait for exactly that prefetch.
+// Pipeline.  Persistent workgroups: conv launches run ONE 12-wave workgroup per CU (3 m-tiles x 4 column groups, 96 x 128
+// or 96 x 256 output tile, ~100 KB of LDS, dominated by the parked output tile), GEMM launches two 8-wave workgroups per
+// CU at a 128-register budget.  Per slab: barrier, registers -> LDS (weights copied, activations split), request the next
+// slab (its loads fly across this slab's MFMAs; the first slab of the next phase / tile is requested behind the last
+// one), barrier, MFMAs.  Barriers are raw s_barrier + lgkmcnt(0): __syncthreads() also drains vmcnt, i.e. it would wait
+// for exactly that prefetch.  Measured alternatives (double-buffered LDS staging, two slabs in flight, transposed
+// accumulators, producer / consumer waves, more workgroups per CU): DESIGN.md section 4.
 #pragma once
 #include <type_traits>
 #include "conv_epi.h"
