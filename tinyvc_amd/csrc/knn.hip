@@ -199,14 +199,18 @@ __device__ __forceinline__ void split8_half(const u32x4 h8, uint4& p1, uint4& p2
     p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
 }
 
-// grid = qtiles * nsplit; workgroup = 128 queries x (tiles_per_split index tiles of 128).
-// 8 waves of 64 (index) x 32 (queries); the (tile, step) sequence is one flat pipeline: registers hold step g+1,
-// LDS is double-buffered, one raw barrier per step.  NP = bf16 parts per index value (3: fp32 storage, 2: fp16 storage).
-constexpr int KNN_A_U4 = 12 * 64, KNN_X_U4 = 3 * 2 * 128;    // one LDS buffer each: 12 KiB + 12 KiB
+// grid = qtiles * nsplit; workgroup = KNN_QT queries x (tiles_per_split index tiles of 128).
+// 8 waves as 2 (index halves) x 4 (query quarters); a wave owns 64 index vectors x 64 queries = 2 x 2 MFMA tiles, so every
+// A and B fragment read from LDS feeds two MFMAs (0.5 KiB of LDS reads per MFMA; the 64 x 32 wave tile of round 1 read
+// 0.75) and a (tile, step) carries 24 MFMAs per wave between barriers.  The (tile, step) sequence is one flat pipeline:
+// registers hold step g+1, LDS is double-buffered, one raw barrier per step.
+// NP = bf16 parts per index value in LDS (3: fp32 storage, 2: fp16 storage).
+constexpr int KNN_QT = 256;                                      // queries per workgroup
+constexpr int KNN_A_U4 = 12 * 64, KNN_X_U4 = 3 * 2 * KNN_QT;    // one LDS buffer each: 12 KiB + 24 KiB
 template <bool F16>
 __device__ __forceinline__ void knn_topk_body(const float* __restrict__ blob, long Npad, int N, const float* __restrict__ qn, int ncols, int T,
                                               int nsplit, int tiles_per_split, float* __restrict__ cand_v, int* __restrict__ cand_i,
-                                              uint4* smem, float (*mv)[16], int (*mi)[16]) {
+                                              uint4* smem) {
     constexpr int NP = F16 ? 2 : 3;                    // parts per index value in LDS
     constexpr int GP = F16 ? 4 : 12;                   // 1 KiB pieces per (tile, step) in the global image
     uint4* As = smem;
@@ -219,69 +223,68 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ blob, lo
     const int l31 = lane & 31, lh = lane >> 5;
     const int split = blockIdx.x % nsplit;
     const int qtile = blockIdx.x / nsplit;
-    const int n0 = qtile * 128;
+    const int n0 = qtile * KNN_QT;
     const int mtiles = (int)(Npad >> 7);
     const int mt_lo = split * tiles_per_split;
     const int mt_hi = min(mtiles, mt_lo + tiles_per_split);
     const int G = (mt_hi - mt_lo) * STEPS;               // flat (tile, step) sequence
 
-    // staging roles: threads 0..255 own one query item (8 channels of one column); the index pieces of a (tile, step) go
-    // to threads 0..255 (piece tid / 64) and 256..511 (two pieces each) for fp32 storage, to threads 256..511 (one fp16
-    // piece each, split into its two bf16 parts on the way into LDS) for fp16 storage
-    const bool xrole = tid < 256;
-    const float* qp = qn;
-    int xdst = 0;
-    if (xrole) {
-        const int g = tid >> 7, pos = tid & 127;
+    // staging roles: every thread owns one query item (8 channels of one column: 2 halves x 256 columns); the index pieces of
+    // a (tile, step) go to waves p % 8 (fp32 storage: 12 pieces, waves 0..3 take two) or to waves 0..3 (fp16 storage: one
+    // fp16 piece each, split into its two bf16 parts on the way into LDS)
+    const float* qp;
+    int xdst;
+    {
+        const int g = tid >> 8, pos = tid & 255;
         int n = n0 + pos;
         n = n < ncols ? n : ncols - 1;
         const int b = n / T, t = n - b * T;
         qp = qn + ((long)b * KD + 8 * g) * T + t;
-        xdst = g * 128 + pos;
+        xdst = g * KNN_QT + pos;
     }
-    const int pa = F16 ? wave - 4 : (xrole ? wave : 4 + 2 * (wave - 4));    // first index piece of this thread
+    const bool a2 = !F16 && wave < 4;                  // this wave stages a second piece (wave + 8)
+    const bool a1 = !F16 || wave < 4;
     float xr[8];
     u32x4 ar[2];
     auto gload = [&](int g) __attribute__((always_inline)) {
         const int mt = mt_lo + g / STEPS, st = g - (g / STEPS) * STEPS;
         const uint4* src = img + ((long)mt * STEPS + st) * (GP * 64) + lane;
-        if (!F16 || !xrole) ar[0] = *reinterpret_cast<const u32x4*>(src + pa * 64);
-        if (!F16 && !xrole) ar[1] = *reinterpret_cast<const u32x4*>(src + (pa + 1) * 64);
-        if (xrole) {
+        if (a1) ar[0] = *reinterpret_cast<const u32x4*>(src + wave * 64);
+        if (a2) ar[1] = *reinterpret_cast<const u32x4*>(src + (wave + 8) * 64);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xr[j] = qp[(long)(st * 16 + j) * T];
-        }
+        for (int j = 0; j < 8; ++j) xr[j] = qp[(long)(st * 16 + j) * T];
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
         uint4* ab = As + buf * KNN_A_U4;
         if (F16) {
-            if (!xrole) {
+            if (a1) {
                 uint4 p1, p2;
                 split8_half(ar[0], p1, p2);
-                ab[(pa * 2) * 64 + lane] = p1;
-                ab[(pa * 2 + 1) * 64 + lane] = p2;
+                ab[(wave * 2) * 64 + lane] = p1;
+                ab[(wave * 2 + 1) * 64 + lane] = p2;
             }
         } else {
-            *reinterpret_cast<u32x4*>(ab + pa * 64 + lane) = ar[0];
-            if (!xrole) *reinterpret_cast<u32x4*>(ab + (pa + 1) * 64 + lane) = ar[1];
+            *reinterpret_cast<u32x4*>(ab + wave * 64 + lane) = ar[0];
+            if (a2) *reinterpret_cast<u32x4*>(ab + (wave + 8) * 64 + lane) = ar[1];
         }
-        if (xrole) {
-            uint4 p1, p2, p3;
-            split8(xr, p1, p2, p3);
-            uint4* xb = Xs + buf * KNN_X_U4;
-            xb[xdst] = p1;
-            xb[256 + xdst] = p2;
-            xb[512 + xdst] = p3;
-        }
+        uint4 p1, p2, p3;
+        split8(xr, p1, p2, p3);
+        uint4* xb = Xs + buf * KNN_X_U4;
+        xb[xdst] = p1;
+        xb[2 * KNN_QT + xdst] = p2;
+        xb[4 * KNN_QT + xdst] = p3;
     };
 
-    Top4 top;
-    top.init();
-    f32x16 acc[2];
+    Top4 top[2];
+    top[0].init();
+    top[1].init();
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (G > 0) {
         gload(0);
@@ -296,55 +299,69 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ blob, lo
             if (g + 2 < G) gload(g + 2);            // flies across this step's MFMAs and the next barrier
         }
         const uint4* as = As + cur * KNN_A_U4 + wm * (2 * NP * 64) + lane;
-        const uint4* xs = Xs + cur * KNN_X_U4 + lh * 128 + wn * 32 + l31;
-        bf16x8 af[2][NP], bf[3];
+        const uint4* xs = Xs + cur * KNN_X_U4 + lh * KNN_QT + wn * 64 + l31;
+        bf16x8 af[2][NP], bf[2][3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(bf16x8, xs[p * 256]);
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[j][p] = __builtin_bit_cast(bf16x8, xs[p * 2 * KNN_QT + j * 32]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int p = 0; p < NP; ++p) af[i][p] = __builtin_bit_cast(bf16x8, as[(i * NP + p) * 64]);
         // part-products, least significant first: (index part, query part)
+#ifdef KNN_NQ_TEST
+        constexpr int NQ = KNN_NQ_TEST;      // timing experiment only (wrong results): fewer part-products
+#else
         constexpr int NQ = F16 ? 5 : 6;
+#endif
         constexpr int PA3[6] = {2, 1, 0, 1, 0, 0}, PB3[6] = {0, 1, 2, 0, 1, 0};
         constexpr int PA2[5] = {1, 0, 1, 0, 0}, PB2[5] = {1, 2, 0, 1, 0};
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][F16 ? PA2[q < 5 ? q : 0] : PA3[q]], bf[F16 ? PB2[q < 5 ? q : 0] : PB3[q]], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][F16 ? PA2[q < 5 ? q : 0] : PA3[q]], bf[j][F16 ? PB2[q < 5 ? q : 0] : PB3[q]],
+                                                                        acc[i][j], 0, 0, 0);
         const int st = g - (g / STEPS) * STEPS;
         if (st == STEPS - 1) {
-            // running top-4: this lane's 16 registers are 16 index vectors against its own query
+            // running top-4: a lane's 16 registers of one MFMA tile are 16 index vectors against ONE of its two queries
             const int m0 = (mt_lo + g / STEPS) * 128;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (row < N) {
-                        float v = acc[i][r];
-                        if (F16) v *= inv[row];
-                        top.insert(nan_max(v), row);
+                        const float sc = F16 ? inv[row] : 1.f;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) top[j].insert(nan_max(F16 ? acc[i][j][r] * sc : acc[i][j][r]), row);
                     }
-                    acc[i][r] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j][r] = 0.f;
                 }
         }
         slab_barrier();
     }
 
-    // merge the 4 partial lists (wm in {0,1} x lh in {0,1}) of every query through LDS
-    {
-        int q = wn * 32 + l31;
-        int slot = (wm * 2 + lh) * 4;
+    // merge the 4 partial lists (wm in {0,1} x lh in {0,1}) of every query through LDS (the staging buffers are free now:
+    // the loop's last barrier is behind every wave's last fragment read)
+    float (*mv)[16] = reinterpret_cast<float (*)[16]>(smem);
+    int (*mi)[16] = reinterpret_cast<int (*)[16]>(reinterpret_cast<float*>(smem) + KNN_QT * 16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = wn * 64 + j * 32 + l31;
+        const int slot = (wm * 2 + lh) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            mv[q][slot + e] = top.v[e];
-            mi[q][slot + e] = top.i[e];
+            mv[q][slot + e] = top[j].v[e];
+            mi[q][slot + e] = top[j].i[e];
         }
     }
     __syncthreads();
-    if (tid < 128) {
+    if (tid < KNN_QT) {
         Top4 t4;
         t4.init();
         for (int e = 0; e < 16; ++e) t4.insert(mv[tid][e], mi[tid][e]);
@@ -364,12 +381,10 @@ static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const float*
                                                                     const float* __restrict__ qn, int ncols, int T,
                                                                     int nsplit, int tiles_per_split,
                                                                     float* __restrict__ cand_v, int* __restrict__ cand_i) {
-    __shared__ __attribute__((aligned(16))) uint4 smem[2 * (KNN_A_U4 + KNN_X_U4)];
-    __shared__ float mv[128][16];
-    __shared__ int mi[128][16];
+    __shared__ __attribute__((aligned(16))) uint4 smem[2 * (KNN_A_U4 + KNN_X_U4)];      // 72 KiB; the final merge reuses 32 KiB of it
     const int kind = reinterpret_cast<const int*>(blob)[1];      // uniform: which storage this prepared index uses
-    if (kind == KIND_F16) knn_topk_body<true>(blob, Npad, N, qn, ncols, T, nsplit, tiles_per_split, cand_v, cand_i, smem, mv, mi);
-    else knn_topk_body<false>(blob, Npad, N, qn, ncols, T, nsplit, tiles_per_split, cand_v, cand_i, smem, mv, mi);
+    if (kind == KIND_F16) knn_topk_body<true>(blob, Npad, N, qn, ncols, T, nsplit, tiles_per_split, cand_v, cand_i, smem);
+    else knn_topk_body<false>(blob, Npad, N, qn, ncols, T, nsplit, tiles_per_split, cand_v, cand_i, smem);
 }
 
 // One workgroup = 32 consecutive query columns: merge split candidates -> top-4, write indices,
@@ -497,7 +512,7 @@ static KnnPlan knn_plan(int B, int T, int64_t N) {
     KnnPlan p;
     p.ncols = B * T;
     p.Npad = npad128(N);
-    p.qtiles = (p.ncols + 127) / 128;
+    p.qtiles = (p.ncols + KNN_QT - 1) / KNN_QT;
     const int mtiles = (int)(p.Npad / 128);
     int nsplit = (KNN_BLOCKS + p.qtiles - 1) / p.qtiles;
     if (nsplit > mtiles) nsplit = mtiles;
