@@ -104,7 +104,8 @@ int tvc_pitch_decode_f32(tvc_ctx* ctx, void* stream, const float* logits, float*
  * reference extract_index.py:58 / infer.py:49, or Generator.encode's output) -> `prepared`, a blob of
  * tvc_knn_prepared_elems(N) floats: a 256-byte header, the raw vectors row-major (the final gather) and the vectors
  * scaled by 1/(||r||+1e-6) (feature_retrieval.py:25 recomputes that on every call) split into three bf16 parts per
- * value in MFMA lane order (the similarity GEMM's operand): 10 bytes per index element.  The layout is private to the
+ * value in MFMA lane order (the similarity GEMM's operand), plus the same vectors in fp16 and their inverse norms (the
+ * coarse pass of the two-stage search): 12 bytes per index element.  The layout is private to the
  * library; the blob is self-describing, so every entry point below takes either kind of blob. */
 int64_t tvc_knn_prepared_elems(int64_t N);
 int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, float* prepared,

@@ -172,9 +172,9 @@ def test_cfg5_five_minutes_against_a_million_vector_fp16_index(gen):
     sims16, idx16 = eng.knn_topk(ssl, blob16, n)
     torch.cuda.synchronize()
     t_knn = time.perf_counter() - t0
-    mfma = 5 * 2 * 768 * T * N / t_knn / 2.5e15
-    print(f"[cfg5] kNN T={T} x N={N}: {t_knn * 1e3:.1f} ms = {2 * 768 * T * N / t_knn / 1e12:.0f} TFLOP/s fp32-equivalent, "
-          f"{mfma:.2f} of the bf16 MFMA peak (5 part-products per product)")
+    print(f"[cfg5] kNN T={T} x N={N}: {t_knn * 1e3:.1f} ms = {T * N / t_knn / 1e9:.0f} G (query, vector) pairs/s "
+          f"(two-stage search: one fp16 product per pair in the coarse passes = {1.125 * 2 * 768 * T * N / t_knn / 2.5e15:.2f} of the f16 MFMA peak, "
+          f"then an exact fp32 rescoring of a few dozen candidates per query; the exact kernel alone needs ~137 ms)")
     # (1) oracle on a 200-query slice, on the same fp16-rounded vectors
     q = ssl[:, :, 7000:7200].cpu()
     ref = index16.float()

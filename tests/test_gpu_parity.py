@@ -119,7 +119,7 @@ def test_knn_ties_lowest_index_and_self_match(models):
     assert torch.equal(o_idx[decidable], idx[decidable])
 
 
-@pytest.mark.parametrize("n_index", [4, 5, 127, 128, 129, 1001])
+@pytest.mark.parametrize("n_index", [4, 5, 127, 128, 129, 1001, 4096, 4097, 5003])      # >= 4096: the two-stage (coarse + rescore) search
 def test_knn_ragged_index_sizes(models, n_index):
     from tinyvc_amd.module.tinyvc import match_features
     g = torch.Generator().manual_seed(n_index)
@@ -133,6 +133,40 @@ def test_knn_ragged_index_sizes(models, n_index):
     assert (idx.cpu() < n_index).all() and (idx.cpu() >= 0).all()
     if bool(decidable.all()):
         check(f"matched N={n_index}", out, o_out, 1e-6)
+
+
+def test_knn_two_stage_ties_and_dense_neighbourhoods(models):
+    """The two-stage search (index >= 4096 vectors) must give what the exact kernel gives: exact duplicates tie towards the
+    lower index, and a neighbourhood denser than its candidate capacity (more than 64 vectors within the coarse window of
+    the 4th best) falls back to the exact kernel inside the same call."""
+    from tinyvc_amd.module.tinyvc import match_features
+    g = torch.Generator().manual_seed(7)
+    index = torch.randn(1, 768, 6000, generator=g)
+    index[0, :, 4500] = index[0, :, 17]          # exact duplicates of vector 17
+    index[0, :, 5900] = index[0, :, 17]
+    q = index[:, :, [17, 3, 5999]].clone()
+    out, idx = match_features(q.to(DEV), index.to(DEV), return_indices=True)
+    idx = idx.cpu()
+    assert idx[0, 0, :3].tolist() == [17, 4500, 5900]
+    assert idx[0, 1, 0].item() == 3 and idx[0, 2, 0].item() == 5999
+    o_out, o_idx, sims = R.match_features(q, index, return_indices=True)
+    top = torch.topk(sims.double(), 5, dim=2).values
+    decidable = (top[..., :-1] - top[..., 1:]).min(dim=2).values > 1e-5
+    assert torch.equal(o_idx[decidable], idx[decidable])
+    # dense: 200 vectors all within 1e-4 (cosine) of one query -> more than 64 candidates -> exact fallback, same answer as the oracle
+    base = torch.randn(768, generator=g)
+    dense = torch.randn(1, 768, 5000, generator=g)
+    for j in range(200):
+        dense[0, :, 1000 + 7 * j] = base + 1e-3 * (j + 1) * torch.randn(768, generator=g) / 27.7
+    qd = torch.stack([base, dense[0, :, 3]], dim=1)[None]            # query 0 sits in the dense cluster, query 1 is ordinary
+    out, idx = match_features(qd.to(DEV), dense.to(DEV), return_indices=True)
+    o_out, o_idx, sims = R.match_features(qd, dense, return_indices=True)
+    top = torch.topk(sims.double(), 5, dim=2).values
+    gaps = (top[..., :-1] - top[..., 1:]).min(dim=2).values
+    print(f"[knn] dense cluster: top-5 gaps of the cluster query {gaps[0, 0]:.2e}")
+    decidable = gaps > 2e-7
+    assert bool(decidable[0, 1]) and torch.equal(idx.cpu()[decidable], o_idx[decidable])
+    assert torch.equal(idx.cpu()[0, 1], o_idx[0, 1])
 
 
 @pytest.mark.parametrize("shift", [0.0, 3.0, -12.0])

@@ -708,7 +708,8 @@ int64_t tvc_knn_prepared_elems(int64_t N) {
     if (N <= 0) return 0;
     int64_t npad = (N + 127) / 128 * 128;
     // header + raw rows [N][768] + split image of the normalised vectors (3 bf16 per value = 1.5 floats)
-    return 64 + N * (int64_t)kSslDim + (int64_t)kSslDim * npad * 3 / 2;
+    // + inverse norms [Npad] + fp16 image of the normalised vectors (the coarse pass's operand, half a float per value)
+    return 64 + N * (int64_t)kSslDim + (int64_t)kSslDim * npad * 3 / 2 + npad + (int64_t)kSslDim * npad / 2;
 }
 
 int64_t tvc_knn_prepared_elems_f16(int64_t N) {

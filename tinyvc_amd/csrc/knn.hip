@@ -30,6 +30,15 @@ constexpr int STEPS = KD / 16;     // 48 K16 steps per index tile
 constexpr int HDR = 64;            // blob header, floats: [0] magic, [1] kind, [2] N (low 32 bits), [3] N (high)
 constexpr int KIND_F32 = 0, KIND_F16 = 1;
 constexpr int BLOB_MAGIC = 0x54564B4E;
+// fp32 kind:  header | rows fp32 [N][768] | bf16x3 image of v / den [Npad*768*3 bf16] | inv = 1 / den [Npad] | fp16 image of v / den [Npad*768]
+// fp16 kind:  header | inv [Npad] | fp16 image of the raw vectors [Npad*768]
+// (both fp16 images in the 128-vector-tiled MFMA lane order, one part)
+__host__ __device__ inline const float* blob_inv(const float* blob, int kind, long N, long Npad) {
+    return kind == KIND_F16 ? blob + HDR : blob + HDR + (size_t)N * KD + (size_t)Npad * KD * 3 / 2;
+}
+__host__ __device__ inline const uint4* blob_img16(const float* blob, int kind, long N, long Npad) {
+    return reinterpret_cast<const uint4*>(blob_inv(blob, kind, N, Npad) + Npad);
+}
 #ifndef KNN_BLOCKS
 #define KNN_BLOCKS 1024   // target workgroup count (query tiles x index splits)
 #endif
@@ -66,7 +75,8 @@ static __global__ void blob_header_kernel(float* blob, int kind, long N) {
 // fp32 storage.  index [768][N] (the [1,768,N] tensor of index.pt) -> raw rows + the bf16x3 image of v / (||v|| + 1e-6)
 // (feature_retrieval.py:25 recomputes that normalisation on every call).  One thread per vector; reads run along n.
 static __global__ void index_prepare_kernel(const float* __restrict__ index, float* __restrict__ rows,
-                                            unsigned short* __restrict__ img, long N, long Npad) {
+                                            unsigned short* __restrict__ img, float* __restrict__ inv, __half* __restrict__ img16,
+                                            long N, long Npad) {
     long n = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (n >= Npad) return;
     float den = 1.f;
@@ -78,10 +88,12 @@ static __global__ void index_prepare_kernel(const float* __restrict__ index, flo
         }
         den = sqrtf(s) + 1e-6f;
     }
+    inv[n] = n < N ? 1.f / den : 0.f;
     for (int k = 0; k < KD; ++k) {
         float raw = n < N ? index[(long)k * N + n] : 0.f;
         if (n < N) rows[n * KD + k] = raw;
         float v = raw / den;
+        img16[img_elem(n, k, 1)] = __float2half(v);      // the coarse pass's operand (knn_coarse_kernel)
         __bf16 h1 = (__bf16)v;
         float r = v - (float)h1;
         __bf16 h2 = (__bf16)r;
@@ -118,7 +130,9 @@ int run_prepare_index(tvc_ctx* ctx, hipStream_t s, const float* index, float* pr
     hipLaunchKernelGGL(blob_header_kernel, dim3(1), dim3(64), 0, s, prepared, KIND_F32, (long)N);
     float* rows = prepared + HDR;
     unsigned short* img = reinterpret_cast<unsigned short*>(rows + (size_t)N * KD);
-    hipLaunchKernelGGL(index_prepare_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, s, index, rows, img, (long)N, Npad);
+    float* inv = const_cast<float*>(blob_inv(prepared, KIND_F32, N, Npad));
+    __half* img16 = reinterpret_cast<__half*>(const_cast<uint4*>(blob_img16(prepared, KIND_F32, N, Npad)));
+    hipLaunchKernelGGL(index_prepare_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, s, index, rows, img, inv, img16, (long)N, Npad);
     return launch_check(ctx, "knn_prepare_index");
 }
 
@@ -135,7 +149,11 @@ int run_prepare_index_f16(tvc_ctx* ctx, hipStream_t s, const void* rows16, float
 // qn[b][k][t] = src[b][k][t] / (||src[b][:][t]|| + 1e-6).  One workgroup = 64 consecutive columns;
 // its 4 waves each sum a quarter of the 768 channels (lanes along time, coalesced), partial sums of
 // squares meet in LDS in a fixed order, then every wave rescales its quarter.
-static __global__ __launch_bounds__(256) void query_normalize_kernel(const float* __restrict__ src, float* __restrict__ qn, int B, int T) {
+// qh (optional) = the same values in fp16, in the coarse pass's B-fragment order [256-query tile][K16 step][8-channel half][query][8]
+// (columns beyond ncols of the last tile are zero); cnt / flag (optional) = the two-stage search's per-query candidate
+// counters and its overflow flag, zeroed here.
+static __global__ __launch_bounds__(256) void query_normalize_kernel(const float* __restrict__ src, float* __restrict__ qn, int B, int T,
+                                                                     uint4* __restrict__ qh, int* __restrict__ cnt, int* __restrict__ flag) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long ncols = (long)B * T;
@@ -151,8 +169,27 @@ static __global__ __launch_bounds__(256) void query_normalize_kernel(const float
     part[wave][lane] = s;
     __syncthreads();
     const float den = sqrtf(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) + 1e-6f;
-    if (!ok) return;
-    for (int k = k0; k < k1; ++k) q[(long)k * T] = p[(long)k * T] / den;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && flag) *flag = 0;
+    if (wave == 0 && ok && cnt) cnt[n] = 0;
+    uint4* qhp = qh ? qh + (n >> 8) * (long)(STEPS * 2 * 256) + (n & 255) : nullptr;
+    for (int k = k0; k < k1; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ok ? p[(long)(k + j) * T] / den : 0.f;
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[(long)(k + j) * T] = v[j];
+        }
+        if (qh) {
+            unsigned o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const __half2 h = __floats2half2_rn(v[2 * j], v[2 * j + 1]);
+                o[j] = (unsigned)__half_as_ushort(__low2half(h)) | ((unsigned)__half_as_ushort(__high2half(h)) << 16);
+            }
+            qhp[(long)(k >> 3) * 256] = make_uint4(o[0], o[1], o[2], o[3]);     // (K16 step, half) = k / 8
+        }
+    }
 }
 
 // torch.topk orders NaN above every number; a query column with NaN / Inf samples upstream makes every similarity NaN.
@@ -380,8 +417,10 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ blob, lo
 static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const float* __restrict__ blob, long Npad, int N,
                                                                     const float* __restrict__ qn, int ncols, int T,
                                                                     int nsplit, int tiles_per_split,
-                                                                    float* __restrict__ cand_v, int* __restrict__ cand_i) {
+                                                                    float* __restrict__ cand_v, int* __restrict__ cand_i,
+                                                                    const int* __restrict__ run_flag) {
     __shared__ __attribute__((aligned(16))) uint4 smem[2 * (KNN_A_U4 + KNN_X_U4)];      // 72 KiB; the final merge reuses 32 KiB of it
+    if (run_flag && *run_flag == 0) return;                      // two-stage search succeeded: nothing to do (uniform)
     const int kind = reinterpret_cast<const int*>(blob)[1];      // uniform: which storage this prepared index uses
     if (kind == KIND_F16) knn_topk_body<true>(blob, Npad, N, qn, ncols, T, nsplit, tiles_per_split, cand_v, cand_i, smem);
     else knn_topk_body<false>(blob, Npad, N, qn, ncols, T, nsplit, tiles_per_split, cand_v, cand_i, smem);
@@ -393,9 +432,16 @@ static __global__ __launch_bounds__(512) void knn_topk_split_kernel(const float*
 static __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
                                                                       int nsplit, int ncols, int T, int N, long Npad,
                                                                       const float* __restrict__ blob,
-                                                                      float* __restrict__ out, int64_t* __restrict__ idx_out) {
+                                                                      float* __restrict__ out, int64_t* __restrict__ idx_out,
+                                                                      const float* __restrict__ rv, const int* __restrict__ ri,
+                                                                      const int* __restrict__ flag) {
     __shared__ int sel[32][4];
     __shared__ float tile[32][193];
+    if (flag && *flag == 0) {      // the two-stage search's rescored lists (one "split") are the result
+        cand_v = rv;
+        cand_i = ri;
+        nsplit = 1;
+    }
     const int tid = threadIdx.x;
     const int n0 = blockIdx.x * 32;
     const int kind = reinterpret_cast<const int*>(blob)[1];
@@ -445,9 +491,15 @@ static __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const floa
 // ---- index-sharded search (one index shard per GPU): local top-4 with similarities, slot gather, finish ----
 // merge the split candidates of every query -> this shard's top-4 (similarity, local index)
 static __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i, int nsplit, int ncols,
-                                                               float* __restrict__ sims_out, int64_t* __restrict__ idx_out) {
+                                                               float* __restrict__ sims_out, int64_t* __restrict__ idx_out,
+                                                               const float* __restrict__ rv, const int* __restrict__ ri, const int* __restrict__ flag) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= ncols) return;
+    if (flag && *flag == 0) {
+        cand_v = rv;
+        cand_i = ri;
+        nsplit = 1;
+    }
     Top4 t4;
     t4.init();
     for (int sp = 0; sp < nsplit; ++sp) {
@@ -504,6 +556,256 @@ static __global__ __launch_bounds__(256) void knn_finish_kernel(const float* __r
     }
 }
 
+// =================================================================================================
+// Two-stage search (N >= KNN_COARSE_MIN).  The exact kernel above spends six bf16 part-products per similarity on every
+// (query, index vector) pair although only a handful of index vectors per query can be in the top 4.  Stage 1 computes a
+// COARSE similarity c with ONE fp16 product per element (fp16 has 11 significant bits: |c - s| <= eps for unit vectors, see
+// C_EPS) and keeps, per query, every index vector that could still be in the exact top 4:
+//   pass A  coarse top-4 values over a sample of the index (any subset's 4th best is a lower bound of the global 4th
+//           best) -> theta = c4 - 2 eps;
+//   pass B  coarse similarities of the whole index; rows with c >= theta are appended to the query's candidate list
+//           (C_CAP entries; a handful for random data);
+//   rescore exact fp32 similarity of every candidate (fp32 FMA chain over the raw vectors, x 1 / norm), top-4 with the
+//           library's order (similarity descending, lower index first).
+// Why this is exact: let R be the final top-4 (by the rescored similarity s') and T4 the coarse top-4 of the sample.
+// For r in R: s'_r >= 4th largest s' overall >= min_{t in T4} s'_t >= c4 - eps, hence c_r >= s'_r - eps >= c4 - 2 eps = theta,
+// so r is a candidate.  If any query collects more than C_CAP candidates (dense neighbourhoods), a flag makes the exact
+// kernel run instead (it is always launched and exits at once when the flag is clear), so results never depend on the
+// data distribution - only the speed does.
+// =================================================================================================
+constexpr int C_QT = 256, C_MT = 256, C_K = 64, C_STEPS = KD / C_K;            // 256 queries x 256 index vectors x K = 64 per step
+constexpr int C_A_U4 = 4 * 8 * 64, C_X_U4 = 4 * 2 * C_QT;                      // one LDS buffer each: 32 KiB + 32 KiB
+constexpr int C_LDS = 2 * (C_A_U4 + C_X_U4) * 16;                              // 128 KiB, double-buffered
+constexpr int C_CAP = 256;                                                     // candidates per query before the exact fallback (theta comes from a sample, so lists run to a few dozen)
+// |coarse - exact| for unit vectors: both operands rounded to fp16 (2^-11 relative each, 2^-25 absolute below the normal
+// range), fp32 accumulation of 768 exact products (<= 768 * 2^-24), the rescoring's own rounding (< 1e-6):
+// 2^-10 * 1.01 + 768 * 2^-25 + 768 * 2^-24 + 1e-6 < 1.06e-3; C_EPS leaves a margin.
+constexpr float C_EPS = 1.25e-3f;
+#ifndef KNN_COARSE_MIN
+#define KNN_COARSE_MIN 4096
+#endif
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct Top4V {   // four largest values
+    float v[4];
+    __device__ __forceinline__ void init() { v[0] = v[1] = v[2] = v[3] = -INFINITY; }
+    __device__ __forceinline__ void insert(float x) {
+        if (!(x > v[3])) return;
+        if (x > v[0]) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = x; }
+        else if (x > v[1]) { v[3] = v[2]; v[2] = v[1]; v[1] = x; }
+        else if (x > v[2]) { v[3] = v[2]; v[2] = x; }
+        else v[3] = x;
+    }
+};
+
+// grid = qtiles * nsplit; a workgroup owns 256 queries and walks `tiles_per_split` 256-vector index tiles (of the first
+// `t2_cover` tiles).  8 waves as 2 (index halves) x 4 (query quarters), a wave owns 128 index vectors x 64 queries = 4 x 2
+// MFMA tiles (v_mfma_f32_32x32x16_f16); both operands arrive as ready 16-byte fragments rows (the index's fp16 image,
+// the queries' fp16 image), so staging is copies only: 8 loads + 8 ds_write_b128 per thread and K = 64 step, 32 MFMAs per
+// wave and step.  MODE 0: coarse top-4 values per (split, query) -> c4v.  MODE 1: rows with c >= theta -> candidate lists.
+template <bool F16, int MODE>
+static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __restrict__ blob, long Npad, int N, const uint4* __restrict__ qh,
+                                                                int ncols, int nsplit, int tiles_per_split, int t2_cover,
+                                                                float* __restrict__ c4v, const float* __restrict__ theta,
+                                                                int* __restrict__ cnt, int* __restrict__ cand, int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) uint4 csmem[];
+    uint4* As = csmem;
+    uint4* Xs = csmem + 2 * C_A_U4;
+    const int kind = F16 ? KIND_F16 : KIND_F32;
+    if (reinterpret_cast<const int*>(blob)[1] != kind) return;      // launched for both storages: the other instantiation does the work
+    const uint4* img = blob_img16(blob, kind, N, Npad);
+    const float* inv = blob_inv(blob, kind, N, Npad);          // fp16 storage: the image holds the raw vectors
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int split = blockIdx.x % nsplit;
+    const int qtile = blockIdx.x / nsplit;
+    const int n0 = qtile * C_QT;
+    const int mtiles = (int)(Npad >> 7);                         // 128-vector tiles of the image
+    const int t_lo = split * tiles_per_split;
+    const int t_hi = min(t2_cover, t_lo + tiles_per_split);
+    const int G = (t_hi - t_lo) * C_STEPS;
+
+    // staging: thread tid copies uint4 number tid + 512 i (i < 4) of the step's A block [k16][m-tile (8)][lane] and of its
+    // X block [k16][8-channel half][query] - the LDS images are linear in exactly that order
+    const uint4* xsrc = qh + (long)qtile * (STEPS * 2 * 256) + (tid & 511);
+    u32x4 ar[4], xr[4];
+    auto gload = [&](int g) __attribute__((always_inline)) {
+        const int t2 = t_lo + g / C_STEPS, st = g - (g / C_STEPS) * C_STEPS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave + 8 * i, k16 = piece >> 3, mt8 = piece & 7;
+            int t128 = 2 * t2 + (mt8 >> 2);
+            t128 = t128 < mtiles ? t128 : mtiles - 1;                 // odd tile count: the missing half re-reads the last tile (its rows are >= N: ignored)
+            ar[i] = *reinterpret_cast<const u32x4*>(img + (((long)t128 * STEPS + 4 * st + k16) * 4 + (mt8 & 3)) * 64 + lane);
+            xr[i] = *reinterpret_cast<const u32x4*>(xsrc + (long)(4 * st + i) * 512);
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(As + buf * C_A_U4 + tid + 512 * i) = ar[i];
+            *reinterpret_cast<u32x4*>(Xs + buf * C_X_U4 + tid + 512 * i) = xr[i];
+        }
+    };
+
+    Top4V top[2];
+    top[0].init();
+    top[1].init();
+    float th[2] = {INFINITY, INFINITY};
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            th[j] = n < ncols ? theta[n] : INFINITY;
+        }
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (G > 0) {
+        gload(0);
+        lstore(0);
+        if (G > 1) gload(1);
+        slab_barrier();
+    }
+    for (int g = 0; g < G; ++g) {
+        const int cur = g & 1;
+        if (g + 1 < G) {
+            lstore(cur ^ 1);
+            if (g + 2 < G) gload(g + 2);
+        }
+        const uint4* as = As + cur * C_A_U4 + wm * (4 * 64) + lane;
+        const uint4* xs = Xs + cur * C_X_U4 + lh * C_QT + wn * 64 + l31;
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16) {
+            f16x8 af[4], bf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(f16x8, as[(k16 * 8 + i) * 64]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = __builtin_bit_cast(f16x8, xs[k16 * 2 * C_QT + j * 32]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        const int st = g - (g / C_STEPS) * C_STEPS;
+        if (st == C_STEPS - 1) {
+            const int m0 = (t_lo + g / C_STEPS) * C_MT;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < N) {
+                        const float sc = F16 ? inv[row] : 1.f;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float c = F16 ? acc[i][j][r] * sc : acc[i][j][r];
+                            if (MODE == 0) {
+                                top[j].insert(nan_max(c));
+                            } else if (c >= th[j]) {
+                                const int n = n0 + wn * 64 + j * 32 + l31;
+                                const int pos = atomicAdd(&cnt[n], 1);
+                                if (pos < C_CAP) cand[(long)n * C_CAP + pos] = row;
+                                else *overflow = 1;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j][r] = 0.f;
+                }
+        }
+        slab_barrier();
+    }
+    if (MODE == 1) return;
+
+    // merge the 4 partial lists (wm x lh) of every query through LDS, write this split's four largest coarse values
+    float (*mv)[16] = reinterpret_cast<float (*)[16]>(csmem);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = wn * 64 + j * 32 + l31;
+        const int slot = (wm * 2 + lh) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mv[q][slot + e] = top[j].v[e];
+    }
+    __syncthreads();
+    if (tid < C_QT) {
+        Top4V t4;
+        t4.init();
+        for (int e = 0; e < 16; ++e) t4.insert(mv[tid][e]);
+        const int n = n0 + tid;
+        if (n < ncols) {
+            const long o = ((long)split * ncols + n) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c4v[o + e] = t4.v[e];
+        }
+    }
+}
+
+// theta[n] = (4th largest coarse similarity of the sample) - 2 eps
+static __global__ __launch_bounds__(256) void knn_theta_kernel(const float* __restrict__ c4v, int nsplit, int ncols, float* __restrict__ theta) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= ncols) return;
+    Top4V t4;
+    t4.init();
+    for (int sp = 0; sp < nsplit; ++sp)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t4.insert(c4v[((long)sp * ncols + n) * 4 + e]);
+    theta[n] = t4.v[3] - 2.f * C_EPS;
+}
+
+// One wavefront per query: exact similarity of every candidate = (fp32 FMA chain of q_hat against the raw vector, lanes
+// along k, fixed-order shuffle reduction) * (1 / norm); top-4 in the library's order -> rv / ri [ncols][4].
+// A query with fewer than four candidates had non-finite coarse similarities (NaN / Inf samples upstream): rows 0..3 with
+// similarity +inf, what the exact kernel's NaN-as-maximum rule selects.
+static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restrict__ blob, long Npad, int N, const float* __restrict__ qn,
+                                                                 int ncols, int T, const int* __restrict__ cnt, const int* __restrict__ cand,
+                                                                 float* __restrict__ rv, int* __restrict__ ri) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= ncols) return;
+    const int kind = reinterpret_cast<const int*>(blob)[1];
+    const float* inv = blob_inv(blob, kind, N, Npad);
+    const int b = n / T, t = n - b * T;
+    const float* qp = qn + (long)b * KD * T + t;
+    float qv[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) qv[u] = qp[(long)(lane + 64 * u) * T];
+    const int nc = min(cnt[n], C_CAP);
+    Top4 t4;
+    t4.init();
+    for (int c = 0; c < nc; ++c) {
+        const int row = cand[(long)n * C_CAP + c];
+        float d = 0.f;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) d = fmaf(qv[u], blob_row_value(blob, kind, N, Npad, row, lane + 64 * u), d);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        t4.insert(nan_max(d * inv[row]), row);
+    }
+    if (nc < 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t4.v[e] = INFINITY;
+            t4.i[e] = e;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            rv[(long)n * 4 + e] = t4.v[e];
+            ri[(long)n * 4 + e] = t4.i[e];
+        }
+    }
+}
+
 struct KnnPlan {
     int ncols, qtiles, nsplit, tps;
     long Npad;
@@ -522,29 +824,94 @@ static KnnPlan knn_plan(int B, int T, int64_t N) {
     return p;
 }
 
-// query normalisation + the per-split top-4 candidates of every query; shared by the whole-index match and the
-// index-sharded variant
+struct KnnLists {        // where the merge kernels find the per-query top-4 lists
+    float* cv = nullptr;    // exact kernel: [nsplit][ncols][4]
+    int* ci = nullptr;
+    float* rv = nullptr;    // two-stage search: [ncols][4]
+    int* ri = nullptr;
+    int* flag = nullptr;    // 0 = the two-stage lists are valid; nullptr = exact kernel only
+};
+
+template <bool F16, int MODE>
+static int coarse_launch(tvc_ctx* ctx, hipStream_t s, const float* prepared, long Npad, int N, const uint4* qh, int ncols, int qtiles, int t2_cover,
+                         float* c4v, const float* theta, int* cnt, int* cand, int* flag, int* nsplit_out) {
+    static bool ready_dev[64] = {};
+    bool& ready = ready_dev[ctx->device & 63];
+    if (!ready) {
+        hipError_t e = hipFuncSetAttribute((const void*)knn_coarse_kernel<F16, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, C_LDS);
+        if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "knn coarse setup: %s", hipGetErrorString(e));
+        ready = true;
+    }
+    int nsplit = (768 + qtiles - 1) / qtiles;           // ~3 workgroups per CU's worth of work units (one resident workgroup per CU: 128 KiB of LDS)
+    if (nsplit > t2_cover) nsplit = t2_cover;
+    if (nsplit < 1) nsplit = 1;
+    const int tps = (t2_cover + nsplit - 1) / nsplit;
+    nsplit = (t2_cover + tps - 1) / tps;
+    if (nsplit_out) *nsplit_out = nsplit;
+    hipLaunchKernelGGL((knn_coarse_kernel<F16, MODE>), dim3((unsigned)(qtiles * nsplit)), dim3(512), C_LDS, s, prepared, Npad, N, qh, ncols, nsplit, tps, t2_cover,
+                       c4v, theta, cnt, cand, flag);
+    return 0;
+}
+
+// workspace of the two-stage search for `qtiles` 256-query tiles (also the worst case over index sizes)
+static int coarse_max_nsplit(int qtiles) { return (768 + qtiles - 1) / qtiles; }
+
+// query normalisation + the per-query top-4 lists; shared by the whole-index match and the index-sharded variant.
+// The blob's kind lives in device memory (its header), so the host cannot pick the coarse kernel's instantiation: both
+// are launched and the one that does not match the blob returns at once (the exact kernel dispatches inside one launch;
+// the coarse kernel's two instantiations differ in register use enough to keep them apart).
 static int knn_candidates(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, const float* prepared, int64_t N, int B, int T,
-                          const KnnPlan& p, float** cv, int** ci) {
+                          const KnnPlan& p, KnnLists* L) {
     float* qn = ws.get<float>((size_t)B * KD * T);
-    *cv = ws.get<float>((size_t)p.nsplit * p.ncols * 4);
-    *ci = ws.get<int>((size_t)p.nsplit * p.ncols * 4);
+    L->cv = ws.get<float>((size_t)p.nsplit * p.ncols * 4);
+    L->ci = ws.get<int>((size_t)p.nsplit * p.ncols * 4);
+    const bool two_stage = N >= KNN_COARSE_MIN;
+    uint4* qh = nullptr;
+    float *c4v = nullptr, *theta = nullptr;
+    int *cnt = nullptr, *cand = nullptr;
+    const int cq = (p.ncols + C_QT - 1) / C_QT;
+    if (two_stage) {
+        qh = ws.get<uint4>((size_t)cq * STEPS * 2 * 256);
+        c4v = ws.get<float>((size_t)coarse_max_nsplit(cq) * p.ncols * 4);
+        theta = ws.get<float>((size_t)p.ncols);
+        cnt = ws.get<int>((size_t)p.ncols);
+        cand = ws.get<int>((size_t)p.ncols * C_CAP);
+        L->rv = ws.get<float>((size_t)p.ncols * 4);
+        L->ri = ws.get<int>((size_t)p.ncols * 4);
+        L->flag = ws.get<int>(64);
+    }
     if (dry) return 0;
     if (N > 0x7fffff00L) return fail(ctx, TVC_ERR_ARG, "index too large");
-    hipLaunchKernelGGL(query_normalize_kernel, dim3((p.ncols + 63) / 64), dim3(256), 0, s, src, qn, B, T);
+    const int nblk = two_stage ? cq * 4 : (p.ncols + 63) / 64;      // the fp16 query image is written for whole 256-query tiles
+    hipLaunchKernelGGL(query_normalize_kernel, dim3(nblk), dim3(256), 0, s, src, qn, B, T, qh, cnt, L->flag);
+    if (two_stage) {
+        ProfScope ps(ctx, s, dry, "knn.coarse+rescore");
+        const int t2 = (int)((p.Npad + C_MT - 1) / C_MT);          // 256-vector tiles
+        int sample = t2 / 8;                                         // pass A: an eighth of the index, at least 2048 vectors
+        if (sample < 8) sample = 8;
+        if (sample > t2) sample = t2;
+        int nsA = 1;
+        // both storages' instantiations are launched; each returns at once unless the blob is of its kind
+        TVC_CHECK((coarse_launch<false, 0>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, sample, c4v, nullptr, cnt, cand, L->flag, &nsA)));
+        TVC_CHECK((coarse_launch<true, 0>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, sample, c4v, nullptr, cnt, cand, L->flag, &nsA)));
+        hipLaunchKernelGGL(knn_theta_kernel, dim3((p.ncols + 255) / 256), dim3(256), 0, s, c4v, nsA, p.ncols, theta);
+        TVC_CHECK((coarse_launch<false, 1>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, t2, c4v, theta, cnt, cand, L->flag, nullptr)));
+        TVC_CHECK((coarse_launch<true, 1>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, t2, c4v, theta, cnt, cand, L->flag, nullptr)));
+        hipLaunchKernelGGL(knn_rescore_kernel, dim3((p.ncols + 3) / 4), dim3(256), 0, s, prepared, p.Npad, (int)N, qn, p.ncols, T, cnt, cand, L->rv, L->ri);
+    }
+    ProfScope ps(ctx, s, dry, "knn.exact");       // ~0 when the two-stage search succeeded (the kernel exits on the flag)
     hipLaunchKernelGGL(knn_topk_split_kernel, dim3((unsigned)(p.qtiles * p.nsplit)), dim3(512), 0, s, prepared, p.Npad, (int)N, qn, p.ncols, T,
-                       p.nsplit, p.tps, *cv, *ci);
+                       p.nsplit, p.tps, L->cv, L->ci, (const int*)L->flag);
     return 0;
 }
 
 int run_knn_topk(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, const float* prepared, int64_t N,
                  float* sims_out, int64_t* idx_out, int B, int T) {
     const KnnPlan p = knn_plan(B, T, N);
-    float* cv;
-    int* ci;
-    TVC_CHECK(knn_candidates(ctx, s, ws, dry, src, prepared, N, B, T, p, &cv, &ci));
+    KnnLists L;
+    TVC_CHECK(knn_candidates(ctx, s, ws, dry, src, prepared, N, B, T, p, &L));
     if (dry) return 0;
-    hipLaunchKernelGGL(knn_merge_kernel, dim3((p.ncols + 255) / 256), dim3(256), 0, s, cv, ci, p.nsplit, p.ncols, sims_out, idx_out);
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((p.ncols + 255) / 256), dim3(256), 0, s, L.cv, L.ci, p.nsplit, p.ncols, sims_out, idx_out, L.rv, L.ri, L.flag);
     return launch_check(ctx, "knn_topk");
 }
 
@@ -562,12 +929,11 @@ int run_knn_finish(tvc_ctx* ctx, hipStream_t s, const float* slots, float* out, 
 int run_knn(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, const float* prepared, int64_t N,
             float* out, int64_t* idx_out, int B, int T) {
     const KnnPlan p = knn_plan(B, T, N);
-    float* cv;
-    int* ci;
-    TVC_CHECK(knn_candidates(ctx, s, ws, dry, src, prepared, N, B, T, p, &cv, &ci));
+    KnnLists L;
+    TVC_CHECK(knn_candidates(ctx, s, ws, dry, src, prepared, N, B, T, p, &L));
     if (dry) return 0;
-    hipLaunchKernelGGL(knn_merge_gather_kernel, dim3((p.ncols + 31) / 32), dim3(256), 0, s, cv, ci, p.nsplit, p.ncols, T, (int)N, p.Npad,
-                       prepared, out, idx_out);
+    hipLaunchKernelGGL(knn_merge_gather_kernel, dim3((p.ncols + 31) / 32), dim3(256), 0, s, L.cv, L.ci, p.nsplit, p.ncols, T, (int)N, p.Npad,
+                       prepared, out, idx_out, L.rv, L.ri, L.flag);
     return launch_check(ctx, "knn_match");
 }
 
