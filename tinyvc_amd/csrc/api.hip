@@ -54,7 +54,8 @@ struct Packer {
         }
         fix.push_back({slot, ab.put(t->data)});
     }
-    // Stack one or more conv weights [cout_i][cin][taps] along cout into At[k][m].
+    // Stack one or more conv weights [cout_i][cin][taps] along cout (host staging layout At[k][m], k = ci*taps + tap) and
+    // pack the bf16x3 split image + the bias row.
     void conv(const std::vector<std::string>& names, PackedW* pw, int cin, int taps) {
         int M = 0;
         std::vector<const HostTensor*> ws, bs;
@@ -87,21 +88,11 @@ struct Packer {
             }
             m0 += cout;
         }
-        fix.push_back({&pw->At, ab.put(At)});
+        // only the split image goes to the device: `At` is the host-side staging layout it is built from
         fix.push_back({&pw->bias, ab.put(bias)});
         bool equal_groups = ws.size() > 1;
         for (auto* w : ws) equal_groups = equal_groups && w->shape[0] == ws[0]->shape[0];
         a6(pw, At, equal_groups ? (int)ws[0]->shape[0] : 0);
-        if (taps > 1) {   // tap-major copy: row (tap*cin + ci)
-            std::vector<float> Att((size_t)pw->Kpad * pw->Mpad, 0.f);
-            for (int ci = 0; ci < cin; ++ci)
-                for (int t = 0; t < taps; ++t)
-                    for (int m = 0; m < pw->Mpad; ++m)
-                        Att[(size_t)(t * cin + ci) * pw->Mpad + m] = At[(size_t)(ci * taps + t) * pw->Mpad + m];
-            fix.push_back({&pw->At_tap, ab.put(Att)});
-        } else {
-            fix.push_back({&pw->At_tap, fix[fix.size() - 2].off});
-        }
     }
     // bf16x3 split image of At for conv3s.h: [step = slab*taps + tap][m-tile][part][lane][8 bf16],
     // lane -> row m = 32*mt + (lane & 31), channel ci = 16*slab + 8*(lane >> 5) + j.  x = p1 + p2 + p3 with

@@ -70,23 +70,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef S_FB_F
 #define S_FB_F 1   // FiLM-fused kernels: two accumulator sets live, single fragment set keeps the slab loops spill-free
 #endif
-#ifndef S_DB
-#define S_DB 0     // 1: 12-wave conv workgroups use two staging buffers, slab s+1 is split and written to LDS while slab s multiplies (one barrier per slab); measured slower (7.08 -> 7.3-7.6 ms for every S_EARLY order)
-#endif
-#ifndef S_DB_G
-#define S_DB_G 0   // the same for the 8-wave GEMM workgroups (two of them share a CU: LDS allows it only without the SCALED factor rows)
-#endif
-#ifndef S_EARLY
-#define S_EARLY 2   // which waves stage the next slab BEFORE their MFMAs (the others after): 0 none, 1 all, 2 (wave >> 2) & 1, 3 wave & 1
-#endif
-#ifndef S_TRANS
-#define S_TRANS 0   // 1: conv epilogues with the MFMA operands swapped - the accumulator tile is [sample][channel], a lane holds 4 consecutive samples of ONE channel and stores 16 bytes straight from registers (no LDS park, no barriers); measured slower than the parked full-line stores (6.99 -> 7.39 ms)
-#endif
 #ifndef S_PF
 #define S_PF 2   // residual rows requested at a time by the lerp epilogue
-#endif
-#ifndef S_ABL
-#define S_ABL 0   // timing ablations (wrong results): 1 no MFMA, 2 no weight loads, 4 no input loads, 8 no input split/stores, 16 no output stores, 32 no residual, 64 park only (no vector pass), 128 park + barriers only
 #endif
 
 
@@ -110,16 +95,15 @@ struct SplitTile {
     static constexpr int X_U4 = KG * XG_U4;
     static constexpr int X_PER = (KG * 2 * XROW + NTHR - 1) / NTHR;             // staging items per thread
     static constexpr int a_u4(int taps) { return taps * KG * MTB * 3 * 64; }
-    static constexpr bool DB = NW > 8 ? (S_DB != 0) : (S_DB_G != 0);           // double-buffered staging
     static constexpr int stage_u4(int taps) { return a_u4(taps) + X_U4; }
     static constexpr int KS_MAX = 2 * 768;                                      // SCALED launch: factors of <= 768 input channels for the <= 2 utterances a tile touches
     static constexpr int OS = BN + 4;                                           // row stride (floats) of the output tile parked in LDS
     static constexpr int lds_bytes(int taps) {
-        const int stage = stage_u4(taps) * 16 * (DB ? 2 : 1), out = BM * OS * 4;
+        const int stage = stage_u4(taps) * 16, out = BM * OS * 4;
         return (stage > out ? stage : out) + 2 * 3 * BM * 4 + KS_MAX * 4;  // + bias / FiLM-bias rows of this workgroup (two tiles' worth) + input-channel factors
     }
     static constexpr int bias_off(int taps) {                  // float offset of that area
-        const int stage = stage_u4(taps) * 16 * (DB ? 2 : 1), out = BM * OS * 4;
+        const int stage = stage_u4(taps) * 16, out = BM * OS * 4;
         return (stage > out ? stage : out) / 4;
     }
 };
@@ -249,7 +233,7 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
     static_assert(A_PER <= SlabRegs<TL>::A_MAX, "weight pieces must fit the staging registers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ci0 = s * 16 * TL::KG;
-    if (!(S_ABL & 2)) {
+    {
         const uint4* a_src = A6 + (long)mt0 * 192;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
@@ -259,7 +243,6 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
             r.ar[i] = ldg_so4(a_src + (long)s * STEPS * MT * 192, 16u * (unsigned)(tap * MT * 192 + rem * 64 + lane));   // uniform slab base + this wave's piece
         }
     }
-    if (S_ABL & 4) return;
     const float* xc = xb + (long)ci0 * cs;               // uniform base, 32-bit lane offsets
     // Cin % 16 == 0 is a launch precondition (every level routed here has 48/96/192/384 channels): no ragged slab
     if (LERP) {
@@ -300,7 +283,7 @@ __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restr
 
 // acc += W (.) x over all slabs of one input tensor.  Slab 0 is already in flight in `r` (first_load); `next()`
 // is called in its place behind the last slab, so the following phase or tile starts without a cold load.
-template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, bool LERP = false, bool CLAMP = false, bool TRANS = false, class Next>
+template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, bool LERP = false, bool CLAMP = false, class Next>
 __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
                                             const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next,
                                             const float* Ks = nullptr, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0, float lscale = 0.f) {
@@ -312,20 +295,17 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     make_map<TL, LERP>(m, len, dil, t0, fT, fstride, Cin, lin, lscale);
     constexpr int STEPS = TAPS * TL::KG;               // K16 steps per slab: (channel group, tap)
     constexpr int PIECES = STEPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
-    constexpr int STG = TL::DB ? A_U4 + TL::X_U4 : 0;     // u4 stride between the two staging buffers
-    auto lstore = [&](int sl, int buf) __attribute__((always_inline)) {
-        uint4* Asb = As + buf * STG;
-        uint4* Xsb = Xs + buf * STG;
-        if (!(S_ABL & 2)) {
+    auto lstore = [&](int sl) __attribute__((always_inline)) {
+        uint4* Asb = As;
+        uint4* Xsb = Xs;
 #pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-                const int q = wave + i * NW;
-                if (q < PIECES) *reinterpret_cast<u32x4*>(Asb + q * 64 + lane) = r.ar[i];
-            }
+        for (int i = 0; i < A_PER; ++i) {
+            const int q = wave + i * NW;
+            if (q < PIECES) *reinterpret_cast<u32x4*>(Asb + q * 64 + lane) = r.ar[i];
         }
 #pragma unroll
         for (int i = 0; i < X_PER; ++i)
-            if (m.xdst[i] >= 0 && !(S_ABL & 8)) {
+            if (m.xdst[i] >= 0) {
                 if (LERP) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) r.xr[i][j] = fmaf(m.w0[i], r.xr[i][j], __fmul_rn(m.w1[i], r.xr2[i][j]));   // = lerp_eval
@@ -351,37 +331,14 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     const int nslab = Cin / (16 * TL::KG);
     const uint4* as0 = As + wm * WM * 192 + lane;
     const uint4* xs0 = Xs + lh * XROW + wn * WN * 32 + l31;
-    // Double-buffered staging: slab s + 1 is split and written into the other buffer while slab s multiplies, one barrier per
-    // slab.  Half of the waves stage first and multiply second, the others the reverse, so the SIMD's vector and matrix
-    // pipes both have work all the time (with a single buffer every wave staged, then every wave multiplied).
-    const bool early = S_EARLY == 1 || (S_EARLY == 2 && ((wave >> 2) & 1)) || (S_EARLY == 3 && (wave & 1));
-    if (TL::DB) {
-        slab_barrier();                            // the previous phase / tile is done with both buffers
-        lstore(0, 0);
-        if (1 < nslab) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, 1, fT, cmax, lin);
-        else next();
-    }
     for (int s = 0; s < nslab; ++s) {
-        auto stage_next = [&]() __attribute__((always_inline)) {
-            if (s + 1 < nslab) {
-                lstore(s + 1, (s + 1) & 1);
-                if (s + 2 < nslab) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 2, fT, cmax, lin);
-                else next();
-            }
-        };
-        if (TL::DB) {
-            slab_barrier();                        // slab s is complete in its buffer; every wave has finished reading the other one
-            if (early) stage_next();
-            __builtin_amdgcn_sched_barrier(0);     // the staging code stays on its side of the MFMAs (hoisted above them it drags its vmcnt wait along)
-        } else {
-            slab_barrier();                            // every wave is done reading the previous slab
-            lstore(s, 0);                              // slab s: registers -> LDS
-            if (s + 1 < nslab) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin);   // flies across this slab's MFMAs
-            else next();
-            slab_barrier();
-        }
-        const uint4* as = as0 + (s & 1) * STG;
-        const uint4* xs = xs0 + (s & 1) * STG;
+        slab_barrier();                            // every wave is done reading the previous slab
+        lstore(s);                                 // slab s: registers -> LDS
+        if (s + 1 < nslab) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin);   // flies across this slab's MFMAs
+        else next();
+        slab_barrier();
+        const uint4* as = as0;
+        const uint4* xs = xs0;
         // fragments of tap t+1 are read while the MFMAs of tap t run
         bf16x8 af[2][WM][3], bf[2][WN][3];
         auto frags = [&](int tap, int fb) __attribute__((always_inline)) {
@@ -413,13 +370,9 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        if (!(S_ABL & 1) || q == 0)
-                            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[fb][j][PB[q]], af[fb][i][PA[q]], acc[i][j], 0, 0, 0)
-                                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][i][PA[q]], bf[fb][j][PB[q]], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][i][PA[q]], bf[fb][j][PB[q]], acc[i][j], 0, 0, 0);
             if (FB == 2) __builtin_amdgcn_sched_barrier(0);
         }
-        if (TL::DB) __builtin_amdgcn_sched_barrier(0);
-        if (TL::DB && !early) stage_next();
     }
 }
 
@@ -433,17 +386,14 @@ __device__ __forceinline__ void film_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
     constexpr int KG = TL::KG, GP = 2 * MTB * 3, PIECES = KG * GP, A_PER = (PIECES + NW - 1) / NW;   // per 16-channel group: scale and shift pieces of MTB m-tiles
     static_assert(A_PER <= SlabRegs<TL>::A_MAX, "FiLM weight pieces must fit the staging registers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (!(S_ABL & 2)) {
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            int q = wave + i * NW;
-            q = q < PIECES ? q : PIECES - 1;
-            const int kg = q / GP, q2 = q - kg * GP;
-            const int grp = q2 / (MTB * 3), rem = q2 - grp * (MTB * 3);
-            r.ar[i] = ldg_so4(F6 + ((long)s * KG * MT + mt0) * 192, 16u * (unsigned)((kg * MT + grp * mtoff) * 192 + rem * 64 + lane));
-        }
+    for (int i = 0; i < A_PER; ++i) {
+        int q = wave + i * NW;
+        q = q < PIECES ? q : PIECES - 1;
+        const int kg = q / GP, q2 = q - kg * GP;
+        const int grp = q2 / (MTB * 3), rem = q2 - grp * (MTB * 3);
+        r.ar[i] = ldg_so4(F6 + ((long)s * KG * MT + mt0) * 192, 16u * (unsigned)((kg * MT + grp * mtoff) * 192 + rem * 64 + lane));
     }
-    if (S_ABL & 4) return;
     const float* xc = xb + (long)s * 16 * KG * len;
 #pragma unroll
     for (int i = 0; i < X_PER; ++i)
@@ -457,7 +407,7 @@ __device__ __forceinline__ void film_first_load(SlabRegs<TL>& r, const uint4* __
     make_map<TL>(m, len, 0, t0);
     film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, 0);
 }
-template <class TL, bool TRANS = false, class Next>
+template <class TL, class Next>
 __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16 (&ash)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ F6,
                                            int MT, int mt0, int mtoff, const float* __restrict__ xb, int Cin, int len, int t0, uint4* As, uint4* Xs,
                                            Next next) {
@@ -471,55 +421,30 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
     const int nslab = Cin / (16 * KG);
     const uint4* as0 = As + wm * WM * 192 + lane;
     const uint4* xs0 = Xs + lh * XROW + wn * WN * 32 + l31;
-    const int stg = TL::DB ? (int)(Xs - As) + TL::X_U4 : 0;      // u4 stride between the two staging buffers (same as the conv phase's)
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
-        uint4* Asb = As + buf * stg;
-        uint4* Xsb = Xs + buf * stg;
-        if (!(S_ABL & 2)) {
+    auto lstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < A_PER; ++i) {
-                const int q = wave + i * NW;
-                if (q < PIECES) *reinterpret_cast<u32x4*>(Asb + q * 64 + lane) = r.ar[i];
-            }
+        for (int i = 0; i < A_PER; ++i) {
+            const int q = wave + i * NW;
+            if (q < PIECES) *reinterpret_cast<u32x4*>(As + q * 64 + lane) = r.ar[i];
         }
 #pragma unroll
         for (int i = 0; i < X_PER; ++i)
-            if (m.xdst[i] >= 0 && !(S_ABL & 8)) {
+            if (m.xdst[i] >= 0) {
                 uint4 p1, p2, p3;
                 split8(r.xr[i], p1, p2, p3);
-                Xsb[m.xdst[i]] = p1;
-                Xsb[2 * XROW + m.xdst[i]] = p2;
-                Xsb[4 * XROW + m.xdst[i]] = p3;
+                Xs[m.xdst[i]] = p1;
+                Xs[2 * XROW + m.xdst[i]] = p2;
+                Xs[4 * XROW + m.xdst[i]] = p3;
             }
     };
-    const bool early = S_EARLY == 1 || (S_EARLY == 2 && ((wave >> 2) & 1)) || (S_EARLY == 3 && (wave & 1));
-    if (TL::DB) {
-        slab_barrier();
-        lstore(0);
-        if (1 < nslab) film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, 1);
-        else next();
-    }
     for (int s = 0; s < nslab; ++s) {
-        auto stage_next = [&]() __attribute__((always_inline)) {
-            if (s + 1 < nslab) {
-                lstore((s + 1) & 1);
-                if (s + 2 < nslab) film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, s + 2);
-                else next();
-            }
-        };
-        if (TL::DB) {
-            slab_barrier();
-            if (early) stage_next();
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            slab_barrier();
-            lstore(0);
-            if (s + 1 < nslab) film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, s + 1);
-            else next();
-            slab_barrier();
-        }
-        const uint4* as = as0 + (s & 1) * stg;
-        const uint4* xs = xs0 + (s & 1) * stg;
+        slab_barrier();
+        lstore();
+        if (s + 1 < nslab) film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, s + 1);
+        else next();
+        slab_barrier();
+        const uint4* as = as0;
+        const uint4* xs = xs0;
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
             bf16x8 fc[WM][3], fh[WM][3], bf[WN][3];
@@ -541,18 +466,11 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        if (!(S_ABL & 1) || q == 0) {
-                            if (TRANS) {
-                                asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB[q]], fc[i][PA[q]], asc[i][j], 0, 0, 0);
-                                ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB[q]], fh[i][PA[q]], ash[i][j], 0, 0, 0);
-                            } else {
-                                asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[i][PA[q]], bf[j][PB[q]], asc[i][j], 0, 0, 0);
-                                ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i][PA[q]], bf[j][PB[q]], ash[i][j], 0, 0, 0);
-                            }
-                        }
+                    {
+                        asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[i][PA[q]], bf[j][PB[q]], asc[i][j], 0, 0, 0);
+                        ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i][PA[q]], bf[j][PB[q]], ash[i][j], 0, 0, 0);
+                    }
         }
-        if (TL::DB) __builtin_amdgcn_sched_barrier(0);
-        if (TL::DB && !early) stage_next();
     }
 }
 
@@ -585,7 +503,6 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     __builtin_amdgcn_sched_barrier(0);                         // nothing of the store pass moves up into the FiLM combine (three accumulator sets live there)
     float* yb = y + ((long)b * M + mt0 * 32) * len + t0;      // offsets inside the tile's rows fit 32 bits
     // rlin > 0: the residual is F.interpolate(res_low) of a [B][M][rlin] tensor, evaluated here instead of read back
-    if (S_ABL & 128) return;
     const float* rb = RES ? (rlin > 0 ? res + ((long)b * M + mt0 * 32) * rlin : res + ((long)b * M + mt0 * 32) * len + t0) : nullptr;
     const int rows = M - mt0 * 32 < BM ? M - mt0 * 32 : BM;
     const bool vec = (len & 3) == 0;                        // rows start 16-byte aligned (t0 is a multiple of 32)
@@ -699,7 +616,6 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     for (int idx = tid; idx < BM * (BN / 4); idx += NTHR) {
         const int row = idx / (BN / 4), c = (idx - row * (BN / 4)) * 4;
         if (row >= rows || t0 + c >= len) continue;
-        if (S_ABL & 64) continue;
         const float4 o = *reinterpret_cast<const float4*>(Ot + row * OS + c);
         const int off = row * len + c;
         if (RES && rlin > 0) {
@@ -753,95 +669,9 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     }
 }
 
-// Output tile -> HBM straight from the accumulators of a TRANS phase: register 4 g + q of a lane is sample
-// 8 g + 4 (lane >> 5) + q of channel (lane & 31), i.e. four consecutive samples per g: one 16-byte store (and one 16-byte
-// residual load) each.  Every residual tap is requested before the first store.  v holds everything but the residual.
-template <class TL, bool RES>
-__device__ __forceinline__ void tile_store_t(const f32x16 (&v)[TL::WM][TL::WN], float* __restrict__ y, const float* __restrict__ res, int b, int M, int len,
-                                             int mt0, int t0, float* __restrict__ y2 = nullptr, int f2 = 0, int rlin = 0, float rscale = 0.f) {
-    constexpr int WM = TL::WM, WN = TL::WN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave / TL::NWV, wn = wave - wm * TL::NWV;
-    const bool vec = (len & 3) == 0;
-    const int len2 = f2 > 0 ? len / f2 : 0;
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int m = mt0 * 32 + (wm * WM + i) * 32 + l31;
-            const int tb = t0 + (wn * WN + j) * 32 + 4 * lh;          // sample of register 0; g adds 8
-            if (m >= M || tb >= len) continue;
-            float* yr = y + ((long)b * M + m) * len;
-            float rv[4][4];
-            if constexpr (RES) {
-                if (rlin > 0) {                                   // residual = F.interpolate(res_low)[t], evaluated here
-                    const float* rr = res + ((long)b * M + m) * rlin;
-                    float x0[4][4], x1[4][4], lam[4][4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            int t = tb + 8 * g + q;
-                            t = t < len ? t : len - 1;
-                            const Lerp lc = lerp_coord(t, rscale, rlin);
-                            x0[g][q] = rr[lc.i0];
-                            x1[g][q] = rr[lc.i1];
-                            lam[g][q] = lc.w1;
-                        }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) rv[g][q] = fmaf(1.f - lam[g][q], x0[g][q], __fmul_rn(lam[g][q], x1[g][q]));   // = lerp_eval
-                } else {
-                    const float* rr = res + ((long)b * M + m) * len;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int t = tb + 8 * g;
-                        if (vec && t + 3 < len) {
-                            const float4 q4 = *reinterpret_cast<const float4*>(rr + t);
-                            rv[g][0] = q4.x; rv[g][1] = q4.y; rv[g][2] = q4.z; rv[g][3] = q4.w;
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) rv[g][q] = t + q < len ? rr[t + q] : 0.f;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int t = tb + 8 * g;
-                if (t >= len) continue;
-                float e[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e[q] = RES ? v[i][j][4 * g + q] + rv[g][q] : v[i][j][4 * g + q];
-                if (vec && t + 3 < len) {
-                    *reinterpret_cast<float4*>(yr + t) = make_float4(e[0], e[1], e[2], e[3]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (t + q < len) yr[t + q] = e[q];
-                }
-                if (y2) {     // 1/f2-rate copy for the next Downsample block (see C3EpiBias): pick for f2 = 3 / 5, two-sample mean for f2 = 4
-                    float* y2r = y2 + ((long)b * M + m) * len2;
-                    if (f2 == 4) {
-                        if (t + 2 < len) y2r[t >> 2] = fmaf(0.5f, e[1], __fmul_rn(0.5f, e[2]));
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int tt = t + q, qq = tt / f2;
-                            if (tt < len && tt - qq * f2 == (f2 >> 1)) y2r[qq] = e[q];
-                        }
-                    }
-                }
-            }
-        }
-}
-
 template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false, bool CLAMP = false>
 __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ? S_WPE_F : (Epi::kIgemm ? (TL::NW <= 8 ? S_WPE_G : 5) : S_WPE)))) void conv3s_kernel(ConvSArgs a, Epi ep) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, A_U4 = TL::a_u4(TAPS);
-    constexpr bool TRANS = S_TRANS && !Epi::kIgemm;     // accumulators as [sample][channel]: direct 16-byte stores (tile_store_t)
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s[];
     uint4* As = smem_s;
     uint4* Xs = smem_s + A_U4;
@@ -937,7 +767,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             // the cond tile on the same output tiles; (conv, scale, shift) combine in registers.
             const float* cb = a.cond + (long)b * a.Ccond * len;
             const int mtoff = a.MT;                                   // the stacked FiLM image has 2 * a.MT m-tiles: scale rows, then shift rows
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB, false, LERP, false, TRANS>(
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB, false, LERP, false>(
                 acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                 [&]() __attribute__((always_inline)) { film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, len, t0); }, nullptr, 0, 0u, 0, a.lin, a.lscale);
             f32x16 asc[WM][WN], ash[WM][WN];
@@ -947,22 +777,9 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) asc[i][j][r] = ash[i][j][r] = 0.f;
-            film_phase<TL, TRANS>(asc, ash, regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, a.Ccond, len, t0, As, Xs, load_next_tile);
+            film_phase<TL>(asc, ash, regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, a.Ccond, len, t0, As, Xs, load_next_tile);
             // out = ((h + b)(sc + b_sc)) + (sh + b_sh), + residual in the store pass
-            if constexpr (TRANS) {
-                const int l31 = lane & 31;
-#pragma unroll
-                for (int i = 0; i < WM; ++i) {
-                    const int row = (wm * WM + i) * 32 + l31;                 // a lane holds ONE channel
-                    const float bm = Bs[row], bs = Bs[TL::BM + row], bh = Bs[2 * TL::BM + row];
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            acc[i][j][r] = __fadd_rn(__fmul_rn(acc[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
-                }
-                tile_store_t<TL, !(S_ABL & 32)>(acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
-            } else {
+            {
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -973,7 +790,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                         for (int j = 0; j < WN; ++j)
                             acc[i][j][r] = __fadd_rn(__fmul_rn(acc[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
                     }
-                tile_store<TL, !(S_ABL & 32)>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
+                tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
             }
         } else {
             if constexpr (wants_res_conv<Epi>::value) {
@@ -981,15 +798,15 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 // the 1x1 runs as a second K phase over xi (a.cond, a.Ccond channels, image a.sc6) on the same accumulators, so
                 // the residual tensor is never written or read back and its launch disappears (ep.bias = the two biases summed).
                 const float* cb = a.cond + (long)b * a.Ccond * len;
-                split_phase<TL, TAPS, A_U4, LRELU, S_FB, false, false, false, TRANS>(
+                split_phase<TL, TAPS, A_U4, LRELU, S_FB, false, false, false>(
                     acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                     [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0); });
-                split_phase<TL, 1, A_U4, false, S_FB, false, false, false, TRANS>(acc, regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile);
+                split_phase<TL, 1, A_U4, false, S_FB, false, false, false>(acc, regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile);
             } else
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (Epi::kIgemm ? S_FB_G : S_FB), SCALED, LERP, CLAMP, TRANS>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (Epi::kIgemm ? S_FB_G : S_FB), SCALED, LERP, CLAMP>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                                                                                                    load_next_tile, Ks, fT, fstride, a.cmax, a.lin, a.lscale);
             if constexpr (Epi::kIgemm) {
-                // plain GEMM use (B = 1, len = all columns): the igemm epilogue functors finish the element
+                // plain GEMM use (B = 1, len = all columns): the gemm_epi.h epilogue functors finish the element
                 const int l31 = lane & 31, wn = wave - wm * TL::NWV;
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
@@ -1008,18 +825,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 if (tile < vtiles) coords(tile, mt0, b, t0);
                 continue;
             }
-            if constexpr (TRANS) {
-                const int l31 = lane & 31;
-#pragma unroll
-                for (int i = 0; i < WM; ++i) {
-                    const float bm = Bs[(wm * WM + i) * 32 + l31];
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] += bm;
-                }
-                if (!(S_ABL & 16)) tile_store_t<TL, Epi::kRes && !(S_ABL & 32)>(acc, ep.y, ep.res, b, ep.M, len, mt0, t0, ep.y2, ep.f2);
-            } else if constexpr (!Epi::kIgemm) {
+            if constexpr (!Epi::kIgemm) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1028,7 +834,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
 #pragma unroll
                         for (int j = 0; j < WN; ++j) acc[i][j][r] += bm;
                     }
-                if (!(S_ABL & 16)) tile_store<TL, Epi::kRes && !(S_ABL & 32)>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, ep.y2, ep.f2);
+                tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, ep.y2, ep.f2);
             }
         }
         tile = nxt;
@@ -1152,9 +958,6 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
     }
     if constexpr (FILM)
     {
-        if (TVC_SF_KG == 2 && Cin % 32 == 0 && Ccond % 32 == 0)   // 32-channel slabs: half the staging round trips, twice the MFMAs per barrier pair
-            return conv3s_launch_t<SplitTile<3, TVC_SF_WM, TVC_SF_NWV, TVC_SF_WN, 2>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond,
-                                                                                                                       Ccond, 0, S_BPC, nullptr, false, 0, lin, lscale);
         return conv3s_launch_t<SplitTile<3, TVC_SF_WM, TVC_SF_NWV, TVC_SF_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0,
                                                                                                                 S_BPC, nullptr, false, 0, lin, lscale);
     }
@@ -1163,7 +966,7 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
                                                                                                              nullptr, false, 0, lin, lscale);
 }
 
-// Plain GEMM on the split path: out(m, n) = sum_k W[m][k] x[b][k][t], n = b * len + t, finished by an igemm epilogue
+// Plain GEMM on the split path: out(m, n) = sum_k W[m][k] x[b][k][t], n = b * len + t, finished by a gemm_epi.h epilogue
 // functor (store(n, m, v[4])).  Cin must be a multiple of 16 and rows [K, Cin) must be readable (weights there are 0).
 template <int MTB, int NWV, int BPC, int KG, class Epi, bool SCALED, bool CLAMP>
 inline int gemm_s_launch_k(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,

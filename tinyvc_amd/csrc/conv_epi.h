@@ -1,7 +1,7 @@
 // Epilogue functors of the k3 / 1x1 conv launches of conv3s.h, conv48s.hip and filter_up24s.hip: what happens to an
 // accumulator tile on its way to HBM (bias, residual, the next Downsample's 1/f-rate copy, FiLM combine).
 #pragma once
-#include "igemm.h"
+#include "gemm_epi.h"
 
 namespace tvc {
 

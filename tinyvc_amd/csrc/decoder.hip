@@ -1,7 +1,6 @@
 // Source-filter decoder (decoder.py:24-266): SourceNet, additive harmonic oscillator, filtered-noise
 // iSTFT, and the FilterNet U-Net.
 #include "conv3s.h"
-#include "igemm.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
 
@@ -166,10 +165,9 @@ static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
     }
     for (int i = 0; i < 3; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->src_mid[i], x, B, T));
     if (dry) return 0;
-    // to_amps (128 -> 15 rows, 19 us): the one contraction left on exact-fp32 MFMA tiles (igemm.h)
-    LoadPlain ld{x, kSrcCh, T, (long)kSrcCh * T};
+    // to_amps (128 -> 15 rows: one 32-row m-tile)
     EpiBias<ACT_ELU1, false> ea{amps, ctx->src_to_amps.bias, nullptr, kHarm, T, ncols, (long)kHarm * T, 0};
-    igemm_launch(s, ctx->src_to_amps.At, ctx->src_to_amps.Mpad, ctx->src_to_amps.Kpad, ncols, T, ld, ea);
+    TVC_CHECK((gemm_s_launch<1, 4, 2>(ctx, s, ctx->src_to_amps, x, B, kSrcCh, T, 0, ea)));
     // to_kernel (128 -> 961 rows): the one sizeable contraction of the net, on the split-precision path
     EpiBias<ACT_ELU1, false> ek{kern, ctx->src_to_kernel.bias, nullptr, kBins, T, ncols, (long)kBins * T, 0};
     TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_to_kernel, x, B, kSrcCh, T, 0, ek)));

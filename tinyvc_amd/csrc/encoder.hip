@@ -1,6 +1,5 @@
 // Encoder (encoder.py:75-116) and the ConvNeXt-v2 layer shared with SourceNet (convnext.py:7-58).
 #include "conv3s.h"
-#include "igemm.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
 

@@ -1,0 +1,73 @@
+// Epilogue functors of the plain-GEMM launches of conv3s.h (gemm_s_launch): store(n, m, v[4]) finishes four consecutive
+// output rows m..m+3 of column n = b * T + t (bias, activation, residual, the conditioning sums of the two input layers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tvc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_ELU1 = 2 };
+
+__device__ __forceinline__ float act_apply(float o, int act) {
+    if (act == ACT_GELU) return 0.5f * o * (1.f + erff(o * 0.70710678118654752f));
+    if (act == ACT_ELU1) return (o > 0.f ? o : (expf(o) - 1.f)) + 1.f;
+    return o;
+}
+
+// y[b][m][t] = act(acc + bias[m]) (+ res[b][m][t])
+template <int ACT, bool RES>
+struct EpiBias {
+    static constexpr bool kIgemm = true;   // store(n, m, v[4]) interface (also usable from the split-precision kernel)
+    float* y;
+    const float* bias;
+    const float* res;
+    int M, T, ncols;
+    long y_bs, res_bs;  // batch strides
+    __device__ __forceinline__ void store(int n, int m, const float v[4]) const {
+        if (n >= ncols) return;
+        int b = n / T, t = n - b * T;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (m + r < M) {
+                float o = act_apply(v[r] + bias[m + r], ACT);
+                if (RES) o += res[b * res_bs + (long)(m + r) * T + t];
+                y[b * y_bs + (long)(m + r) * T + t] = o;
+            }
+        }
+    }
+};
+
+// content_in(content) + energy_in(e) + f0_in(log(relu(f0)+1e-6))   (decoder.py:128, :223)
+// e / lf0 are per-(b,t) scalars feeding 1->M 1x1 convs; `e` may be null (FilterNet has no energy).
+struct EpiSumCond {
+    static constexpr bool kIgemm = true;   // store(n, m, v[4]) interface (also usable from the split-precision kernel)
+    float* y;
+    const float* bias;
+    const float* e;     // [B][T] or null
+    const float* f0;    // [B][T]
+    const float* we;
+    const float* be;
+    const float* wf;
+    const float* bf;
+    int M, T, ncols;
+    __device__ __forceinline__ void store(int n, int m, const float v[4]) const {
+        if (n >= ncols) return;
+        int b = n / T, t = n - b * T;
+        float lf = logf(fmaxf(f0[n], 0.f) + 1e-6f);
+        float ev = e ? e[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (m + r < M) {
+                float o = v[r] + bias[m + r];
+                if (e) o = __fadd_rn(o, __fadd_rn(__fmul_rn(we[m + r], ev), be[m + r]));
+                o = __fadd_rn(o, __fadd_rn(__fmul_rn(wf[m + r], lf), bf[m + r]));
+                y[((long)b * M + m + r) * T + t] = o;
+            }
+        }
+    }
+};
+
+// |STFT| in two passes: pass 1 parks Re X in `spec`; pass 2 holds Im X in its accumulators and
+// overwrites spec with sqrt(re^2 + im^2).  Rows are bins.
+}  // namespace tvc

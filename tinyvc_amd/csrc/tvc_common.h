@@ -26,13 +26,11 @@ constexpr int kSrcCh = 128;
 constexpr int kHarm = 15;  // num_harmonics + 1 sinusoids
 constexpr int kSolaCross = 1920, kSolaSearch = 1920, kSolaDelay = 3840;
 
-// A conv / 1x1 weight packed for the implicit-GEMM kernel: At[k][m] (k = ci*taps + tap, m = cout),
-// zero padded to Kpad x Mpad (Kpad % 16 == 0, Mpad % 32 == 0), plus the bias [Mpad].
+// A conv / 1x1 weight packed for the split-precision MFMA kernels (conv3s.h): the bf16x3 image A6 (K16 steps x MT6 = Mpad / 32
+// m-tiles x 3 parts, 1 KiB pieces in MFMA lane order) plus the bias row [Mpad].  M / K = real rows / k = cin * taps.
 struct PackedW {
-    const float* At = nullptr;
-    const float* At_tap = nullptr;  // same weight with k = tap*cin + ci (tap-major), for the LDS-tiled conv kernels
     const float* bias = nullptr;
-    const float* A6 = nullptr;      // bf16x3 split image for the split-precision MFMA kernels (conv3s.h), MT6 = Mpad / 32 m-tiles
+    const float* A6 = nullptr;
     int M = 0, K = 0, Mpad = 0, Kpad = 0, cin = 0, taps = 1, MT6 = 0, S6 = 0;   // S6 = 16-channel slabs in A6 (zero-padded to a multiple of 6)
 };
 
