@@ -43,7 +43,7 @@ def test_version_and_null_safety(lib):
     # header + raw rows [N][768] + the bf16x3 image of the normalised vectors (1.5 floats per value) + inverse norms + their fp16 image
     assert lib.tvc_knn_prepared_elems(1000) == 64 + 1000 * 768 + 768 * 1024 * 3 // 2 + 1024 + 768 * 1024 // 2
     # fp16 storage: header + inverse norms [Npad] + the fp16 image (half a float per value): 2 B per element
-    assert lib.tvc_knn_prepared_elems_f16(1000) == 64 + 1024 + 768 * 1024 // 2
+    assert lib.tvc_knn_prepared_elems_f16(1000) == 64 + 1024 + 768 * 1024 // 2 + 8
     assert lib.tvc_knn_prepared_elems_f16(1000000) * 4 < 1.55e9
     assert lib.tvc_knn_prepared_elems(0) == 0
     # argument validation happens before any device work

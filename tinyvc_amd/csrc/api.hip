@@ -706,8 +706,8 @@ int64_t tvc_knn_prepared_elems(int64_t N) {
 int64_t tvc_knn_prepared_elems_f16(int64_t N) {
     if (N <= 0) return 0;
     int64_t npad = (N + 127) / 128 * 128;
-    // header + inverse norms [Npad] + fp16 image (half a float per value)
-    return 64 + npad + (int64_t)kSslDim * npad / 2;
+    // header + inverse norms [Npad] + fp16 image (half a float per value) + the largest inverse norm of every 128-vector tile
+    return 64 + npad + (int64_t)kSslDim * npad / 2 + npad / 128;
 }
 
 int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, float* prepared, int64_t N) {

@@ -31,13 +31,16 @@ constexpr int HDR = 64;            // blob header, floats: [0] magic, [1] kind, 
 constexpr int KIND_F32 = 0, KIND_F16 = 1;
 constexpr int BLOB_MAGIC = 0x54564B4E;
 // fp32 kind:  header | rows fp32 [N][768] | bf16x3 image of v / den [Npad*768*3 bf16] | inv = 1 / den [Npad] | fp16 image of v / den [Npad*768]
-// fp16 kind:  header | inv [Npad] | fp16 image of the raw vectors [Npad*768]
+// fp16 kind:  header | inv [Npad] | fp16 image of the raw vectors [Npad*768] | largest inv of every 128-vector tile [Npad/128]
 // (both fp16 images in the 128-vector-tiled MFMA lane order, one part)
 __host__ __device__ inline const float* blob_inv(const float* blob, int kind, long N, long Npad) {
     return kind == KIND_F16 ? blob + HDR : blob + HDR + (size_t)N * KD + (size_t)Npad * KD * 3 / 2;
 }
 __host__ __device__ inline const uint4* blob_img16(const float* blob, int kind, long N, long Npad) {
     return reinterpret_cast<const uint4*>(blob_inv(blob, kind, N, Npad) + Npad);
+}
+__host__ __device__ inline const float* blob_invmax(const float* blob, long Npad) {      // fp16 kind only
+    return blob + HDR + Npad + (size_t)Npad * KD / 2;
 }
 #ifndef KNN_BLOCKS
 #define KNN_BLOCKS 1024   // target workgroup count (query tiles x index splits)
@@ -136,6 +139,14 @@ int run_prepare_index(tvc_ctx* ctx, hipStream_t s, const float* index, float* pr
     return launch_check(ctx, "knn_prepare_index");
 }
 
+static __global__ void index_invmax_kernel(const float* __restrict__ inv, float* __restrict__ invmax, long ntiles) {
+    const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    float m = 0.f;
+    for (int i = 0; i < 128; ++i) m = fmaxf(m, inv[t * 128 + i]);
+    invmax[t] = m;
+}
+
 int run_prepare_index_f16(tvc_ctx* ctx, hipStream_t s, const void* rows16, float* prepared, int64_t N) {
     const long Npad = npad128(N);
     hipLaunchKernelGGL(blob_header_kernel, dim3(1), dim3(64), 0, s, prepared, KIND_F16, (long)N);
@@ -143,6 +154,7 @@ int run_prepare_index_f16(tvc_ctx* ctx, hipStream_t s, const void* rows16, float
     __half* img = reinterpret_cast<__half*>(inv + Npad);
     hipLaunchKernelGGL(index_prepare_f16_kernel, dim3((unsigned)((Npad * 64 + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const __half*>(rows16), inv, img, (long)N, Npad);
+    hipLaunchKernelGGL(index_invmax_kernel, dim3((unsigned)((Npad / 128 + 255) / 256)), dim3(256), 0, s, inv, const_cast<float*>(blob_invmax(prepared, Npad)), Npad / 128);
     return launch_check(ctx, "knn_prepare_index_f16");
 }
 
@@ -697,24 +709,41 @@ static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __r
         }
         const int st = g - (g / C_STEPS) * C_STEPS;
         if (st == C_STEPS - 1) {
-            const int m0 = (t_lo + g / C_STEPS) * C_MT;
+            const int t2 = t_lo + g / C_STEPS;
+            const int m0 = t2 * C_MT;
+            // fp16 storage: c = acc * inv[row].  max(acc, 0) * (largest inv of the tile) bounds c from above, so the
+            // per-row inverse norm is only fetched for the few values that survive that bound.
+            float imx = 1.f;
+            if (F16) {
+                const float* im = blob_invmax(blob, Npad);
+                const int ta = 2 * t2 < mtiles ? 2 * t2 : mtiles - 1, tb = 2 * t2 + 1 < mtiles ? 2 * t2 + 1 : mtiles - 1;
+                imx = fmaxf(im[ta], im[tb]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + (wm * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (row < N) {
-                        const float sc = F16 ? inv[row] : 1.f;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const float c = F16 ? acc[i][j][r] * sc : acc[i][j][r];
+                            const float a = acc[i][j][r];
                             if (MODE == 0) {
-                                top[j].insert(nan_max(c));
-                            } else if (c >= th[j]) {
-                                const int n = n0 + wn * 64 + j * 32 + l31;
-                                const int pos = atomicAdd(&cnt[n], 1);
-                                if (pos < C_CAP) cand[(long)n * C_CAP + pos] = row;
-                                else *overflow = 1;
+                                if (!F16) {
+                                    top[j].insert(nan_max(a));
+                                } else if (!(fmaxf(a, 0.f) * imx <= top[j].v[3])) {      // could enter the list (NaN passes)
+                                    top[j].insert(nan_max(a * inv[row]));
+                                }
+                            } else {
+                                bool hit;
+                                if (!F16) hit = a >= th[j];
+                                else hit = (fmaxf(a, 0.f) * imx >= th[j]) && (a * inv[row] >= th[j]);
+                                if (hit) {
+                                    const int n = n0 + wn * 64 + j * 32 + l31;
+                                    const int pos = atomicAdd(&cnt[n], 1);
+                                    if (pos < C_CAP) cand[(long)n * C_CAP + pos] = row;
+                                    else *overflow = 1;
+                                }
                             }
                         }
                     }
@@ -775,20 +804,54 @@ static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __
     const float* inv = blob_inv(blob, kind, N, Npad);
     const int b = n / T, t = n - b * T;
     const float* qp = qn + (long)b * KD * T + t;
-    float qv[12];
-#pragma unroll
-    for (int u = 0; u < 12; ++u) qv[u] = qp[(long)(lane + 64 * u) * T];
     const int nc = min(cnt[n], C_CAP);
     Top4 t4;
     t4.init();
-    for (int c = 0; c < nc; ++c) {
-        const int row = cand[(long)n * C_CAP + c];
-        float d = 0.f;
+    if (kind == KIND_F16) {
+        // the fp16 image keeps a vector as 96 16-byte segments (8 consecutive channels each, 4 KiB apart): lane l reads
+        // segments l and 64 + l (l < 32) with one 16-byte load each instead of twelve 2-byte loads
+        const uint4* img = blob_img16(blob, kind, N, Npad);
+        float qs[2][8];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) d = fmaf(qv[u], blob_row_value(blob, kind, N, Npad, row, lane + 64 * u), d);
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-        t4.insert(nan_max(d * inv[row]), row);
+            for (int j = 0; j < 8; ++j) {
+                const int seg = lane + 64 * h;
+                qs[h][j] = seg < 96 ? qp[(long)(8 * seg + j) * T] : 0.f;
+            }
+        for (int c = 0; c < nc; ++c) {
+            const int row = cand[(long)n * C_CAP + c];
+            const long rbase = ((long)(row >> 7) * STEPS * 4 + ((row & 127) >> 5)) * 64 + (row & 31);     // + (step * 4) * 64 + half * 32
+            float d = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int seg = lane + 64 * h;
+                if (seg < 96) {
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(img + rbase + (long)(seg >> 1) * 256 + (seg & 1) * 32);
+                    const f16x8 hv = __builtin_bit_cast(f16x8, w);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d = fmaf(qs[h][j], (float)hv[j], d);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            t4.insert(nan_max(d * inv[row]), row);
+        }
+    } else {
+        float qv[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) qv[u] = qp[(long)(lane + 64 * u) * T];
+        const float* rows = blob + HDR;
+        for (int c = 0; c < nc; ++c) {
+            const int row = cand[(long)n * C_CAP + c];
+            const float* rp = rows + (long)row * KD + lane;
+            float d = 0.f;
+#pragma unroll
+            for (int u = 0; u < 12; ++u) d = fmaf(qv[u], rp[64 * u], d);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            t4.insert(nan_max(d * inv[row]), row);
+        }
     }
     if (nc < 4) {
 #pragma unroll
