@@ -170,6 +170,30 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& p1, uint4& p2
 // workgroup barrier that drains this wave's LDS traffic but not its global loads
 __device__ __forceinline__ void slab_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifdef S_TRACE
+// diagnostic build only: cycle stamps of one wave's walk through the slab loop (tools/micro/slab_trace.py)
+static __device__ unsigned long long g_trace[64 * 256];
+static __device__ unsigned g_trace_slot;
+#ifndef S_TRACE_WG
+#define S_TRACE_WG 0
+#endif
+#ifndef S_TRACE_TID
+#define S_TRACE_TID 0
+#endif
+#define TR_STAMP(r, id)                                                                              \
+    do {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        if ((r).tr && (r).trn < 250) {                                                               \
+            unsigned long long t_;                                                                   \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+            (r).tr[(r).trn++] = (t_ << 8) | (unsigned)(id);                                          \
+        }                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    } while (0)
+#else
+#define TR_STAMP(r, id) do {} while (0)
+#endif
+
 // Staging registers of one thread (one slab in flight) and its share of the halo tile.
 template <class TL>
 struct SlabRegs {
@@ -177,6 +201,10 @@ struct SlabRegs {
     u32x4 ar[A_MAX];
     float xr[TL::X_PER][8];
     float xr2[TL::X_PER][8];   // LERP staging: the second interpolation tap
+#ifdef S_TRACE
+    unsigned long long* tr = nullptr;
+    int trn = 0;
+#endif
 };
 template <class TL>
 struct SlabMap {
@@ -332,11 +360,16 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
     const uint4* as0 = As + wm * WM * 192 + lane;
     const uint4* xs0 = Xs + lh * XROW + wn * WN * 32 + l31;
     for (int s = 0; s < nslab; ++s) {
+        TR_STAMP(r, 0);
         slab_barrier();                            // every wave is done reading the previous slab
+        TR_STAMP(r, 1);
         lstore(s);                                 // slab s: registers -> LDS
+        TR_STAMP(r, 2);
         if (s + 1 < nslab) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin);   // flies across this slab's MFMAs
         else next();
+        TR_STAMP(r, 3);
         slab_barrier();
+        TR_STAMP(r, 4);
         const uint4* as = as0;
         const uint4* xs = xs0;
         // fragments of tap t+1 are read while the MFMAs of tap t run
@@ -373,6 +406,7 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][i][PA[q]], bf[fb][j][PB[q]], acc[i][j], 0, 0, 0);
             if (FB == 2) __builtin_amdgcn_sched_barrier(0);
         }
+        TR_STAMP(r, 5);
     }
 }
 
@@ -714,6 +748,10 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         return v;
     };
     SlabRegs<TL> regs;
+#ifdef S_TRACE
+    __shared__ unsigned long long tr_lds[256];
+    if (blockIdx.x == S_TRACE_WG && threadIdx.x == S_TRACE_TID) regs.tr = tr_lds;
+#endif
     int tile = next_valid(blockIdx.x), mt0 = 0, b = 0, t0 = 0;
     if (tile >= vtiles) return;
     coords(tile, mt0, b, t0);
@@ -837,9 +875,23 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, ep.y2, ep.f2);
             }
         }
+        TR_STAMP(regs, 7);
         tile = nxt;
         if (tile < vtiles) coords(tile, mt0, b, t0);
     }
+#ifdef S_TRACE
+    if (regs.tr) {
+        const unsigned slot = atomicAdd(&g_trace_slot, 1u) & 63u;
+        unsigned long long* g = g_trace + slot * 256;
+        g[0] = 0x5452414345000000ull | ((unsigned long long)TL::MTB << 20) | ((unsigned long long)TL::KG << 16) | ((unsigned long long)TAPS << 12) | ((unsigned long long)SCALED << 8) | (unsigned long long)FILM;
+        g[1] = ((unsigned long long)a.Cin << 32) | (unsigned)regs.trn;
+        g[2] = ((unsigned long long)gridDim.x << 32) | (unsigned)ntiles;
+        unsigned long long rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+        g[3] = rt;
+        for (int i = 0; i < regs.trn; ++i) g[4 + i] = regs.tr[i];
+    }
+#endif
 }
 
 template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false, bool CLAMP = false>

@@ -368,3 +368,9 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
 }
 
 }  // namespace tvc
+
+#ifdef S_TRACE
+extern "C" int tvc_debug_trace_dec(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(tvc::g_trace), sizeof(tvc::g_trace)) == hipSuccess ? 0 : -1;
+}
+#endif

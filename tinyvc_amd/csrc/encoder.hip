@@ -1,10 +1,14 @@
 // Encoder (encoder.py:75-116) and the ConvNeXt-v2 layer shared with SourceNet (convnext.py:7-58).
 #include "conv3s.h"
+#include "gemm_s2.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
 
 namespace tvc {
 
+#ifndef ENC_G2
+#define ENC_G2 7     // the ConvNeXt / output 1x1s on the pipelined GEMM kernel (gemm_s2.h); 0 = the conv3s TAPS = 1 launches
+#endif
 #ifndef ENC_NWV
 #define ENC_MTB 4
 #define ENC_NWV 4
@@ -144,7 +148,9 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     }
     {
         EpiBias<ACT_GELU, false> ep{h, w.c2.bias, nullptr, C2, T, ncols, (long)C2 * T, 0};
-        TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, w.c2, y, B, C, T, 0, ep)));
+        int rc = 0;
+        if (!((ENC_G2 & 1) && gemm_s2_try(&rc, ctx, s, w.c2, y, B, C, T, 0, ep))) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, w.c2, y, B, C, T, 0, ep);
+        TVC_CHECK(rc);
     }
     {
         hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)B * C2 * 64)), dim3(256), 0, s, h, gx, (long)B * C2, T);
@@ -152,7 +158,10 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     }
     {
         EpiBias<ACT_NONE, true> ep{x, w.c3_bias_grn, x, C, T, ncols, (long)C * T, (long)C * T};
-        TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC, EpiBias<ACT_NONE, true>, true>(ctx, s, w.c3, h, B, C2, T, 0, ep, nx)));
+        int rc = 0;
+        if (!((ENC_G2 & 2) && gemm_s2_try<EpiBias<ACT_NONE, true>, true>(&rc, ctx, s, w.c3, h, B, C2, T, 0, ep, nx)))
+            rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC, EpiBias<ACT_NONE, true>, true>(ctx, s, w.c3, h, B, C2, T, 0, ep, nx);
+        TVC_CHECK(rc);
     }
     return launch_check(ctx, "convnext");
 }
@@ -274,7 +283,9 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     for (int i = 0; i < 4; ++i) TVC_CHECK(run_convnext(ctx, sp, ws, dry, ctx->pit_mid[i], xp, B, T));
     if (!dry) {
         EpiBias<ACT_NONE, false> ep{lg, ctx->pit_out.bias, nullptr, kPitchClasses, T, ncols, (long)kPitchClasses * T, 0};
-        TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep)));
+        int rc = 0;
+        if (!((ENC_G2 & 4) && gemm_s2_try(&rc, ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep))) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep);
+        TVC_CHECK(rc);
         hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(256), 0, sp, lg, ctx->pitch_freq, f0, B, T);
     }
     if (fork) TVC_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
@@ -283,10 +294,18 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     if (dry) return 0;
     {
         EpiBias<ACT_NONE, false> ep{ssl, ctx->ssl_out.bias, nullptr, kSslDim, T, ncols, (long)kSslDim * T, 0};
-        TVC_CHECK((gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep)));
+        int rc = 0;
+        if (!((ENC_G2 & 4) && gemm_s2_try(&rc, ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep))) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep);
+        TVC_CHECK(rc);
     }
     if (fork) TVC_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     return launch_check(ctx, "encoder");
 }
 
 }  // namespace tvc
+
+#ifdef S_TRACE
+extern "C" int tvc_debug_trace_enc(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(tvc::g_trace), sizeof(tvc::g_trace)) == hipSuccess ? 0 : -1;
+}
+#endif
