@@ -374,6 +374,7 @@ void build_fft_tables(Packer& pk, tvc_ctx* ctx) {
     pk.fix.push_back({&ctx->fft_tw960, pk.ab.put(t960)});
     pk.fix.push_back({&ctx->fft_tw1920, pk.ab.put(t1920)});
     pk.fix.push_back({&ctx->fft_hann, pk.ab.put(hann)});
+    pk.fix.push_back({&ctx->sola_part, pk.ab.put(std::vector<float>(tvc::kSolaPartFloats, 0.f))});   // device scratch, not a table (sola.hip)
 }
 
 }  // namespace

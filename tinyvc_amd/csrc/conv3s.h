@@ -750,7 +750,11 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     SlabRegs<TL> regs;
 #ifdef S_TRACE
     __shared__ unsigned long long tr_lds[256];
-    if (blockIdx.x == S_TRACE_WG && threadIdx.x == S_TRACE_TID) regs.tr = tr_lds;
+    unsigned long long t0_mem = 0, t0_real = 0;
+    if (blockIdx.x == S_TRACE_WG && threadIdx.x == S_TRACE_TID) {
+        regs.tr = tr_lds;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_mem), "=s"(t0_real)::"memory");
+    }
 #endif
     int tile = next_valid(blockIdx.x), mt0 = 0, b = 0, t0 = 0;
     if (tile >= vtiles) return;
@@ -886,9 +890,9 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         g[0] = 0x5452414345000000ull | ((unsigned long long)TL::MTB << 20) | ((unsigned long long)TL::KG << 16) | ((unsigned long long)TAPS << 12) | ((unsigned long long)SCALED << 8) | (unsigned long long)FILM;
         g[1] = ((unsigned long long)a.Cin << 32) | (unsigned)regs.trn;
         g[2] = ((unsigned long long)gridDim.x << 32) | (unsigned)ntiles;
-        unsigned long long rt;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
-        g[3] = rt;
+        unsigned long long rt, mt;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt), "=s"(rt)::"memory");
+        g[3] = ((mt - t0_mem) << 32) | ((rt - t0_real) & 0xffffffffull);     // kernel-long deltas: s_memtime ticks | 100 MHz ticks
         for (int i = 0; i < regs.trn; ++i) g[4 + i] = regs.tr[i];
     }
 #endif

@@ -190,8 +190,9 @@ struct EpiSplit {
 
 // PitchEstimator.decode (encoder.py:61-67): top-4 logits (ties -> lower class id), softmax over
 // them, expectation of the class frequencies, <= 20 Hz -> 0.
-// One workgroup = 64 consecutive columns: each of the 4 waves scans a quarter of the 512 classes with
-// lanes along time (coalesced), keeps a per-lane top-4, and the four partial lists merge through LDS.
+// One workgroup = 64 consecutive columns: each of the 16 waves scans 32 of the 512 classes with
+// lanes along time (coalesced), keeps a per-lane top-4, and the partial lists merge through LDS (the order
+// of the merge does not matter: `better` is a total order, ties go to the lower class id).
 struct PTop4 {
     float v[4];
     int i[4];
@@ -209,10 +210,11 @@ struct PTop4 {
     }
 };
 
-static __global__ __launch_bounds__(256) void pitch_decode_kernel(const float* __restrict__ logits, const float* __restrict__ freq,
+constexpr int kPdWaves = 16;
+static __global__ __launch_bounds__(kPdWaves * 64) void pitch_decode_kernel(const float* __restrict__ logits, const float* __restrict__ freq,
                                                                   float* __restrict__ f0, int B, int T) {
-    __shared__ float sv[4][64][4];
-    __shared__ int si[4][64][4];
+    __shared__ float sv[kPdWaves][64][4];
+    __shared__ int si[kPdWaves][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long ncols = (long)B * T;
     const long n = blockIdx.x * 64L + lane;
@@ -222,7 +224,7 @@ static __global__ __launch_bounds__(256) void pitch_decode_kernel(const float* _
     const float* p = logits + (long)b * kPitchClasses * T + t;
     PTop4 top;
     top.init();
-    for (int c = wave * (kPitchClasses / 4); c < (wave + 1) * (kPitchClasses / 4); ++c) {
+    for (int c = wave * (kPitchClasses / kPdWaves); c < (wave + 1) * (kPitchClasses / kPdWaves); ++c) {
         const float x = p[(long)c * T];
         top.insert(x != x ? INFINITY : x, c);   // torch.topk orders NaN first; also keeps the list sentinel out of freq[]
     }
@@ -230,7 +232,7 @@ static __global__ __launch_bounds__(256) void pitch_decode_kernel(const float* _
     for (int e = 0; e < 4; ++e) { sv[wave][lane][e] = top.v[e]; si[wave][lane][e] = top.i[e]; }
     __syncthreads();
     if (wave != 0 || !ok) return;
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < kPdWaves; ++w)
 #pragma unroll
         for (int e = 0; e < 4; ++e) top.insert(sv[w][lane][e], si[w][lane][e]);
 #pragma unroll
@@ -249,7 +251,7 @@ static __global__ __launch_bounds__(256) void pitch_decode_kernel(const float* _
 int run_pitch_decode(tvc_ctx* ctx, hipStream_t s, const float* logits, float* f0, int B, int T) {
     if (!ctx->pitch_freq) return fail(ctx, TVC_ERR_STATE, "pitch table not uploaded (tvc_set_pitch_table + tvc_finalize_weights)");
     const long ncols = (long)B * T;
-    hipLaunchKernelGGL(pitch_decode_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(256), 0, s, logits, ctx->pitch_freq, f0, B, T);
+    hipLaunchKernelGGL(pitch_decode_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(kPdWaves * 64), 0, s, logits, ctx->pitch_freq, f0, B, T);
     return launch_check(ctx, "pitch_decode");
 }
 
@@ -286,7 +288,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
         int rc = 0;
         if (!((ENC_G2 & 4) && gemm_s2_try(&rc, ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep))) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep);
         TVC_CHECK(rc);
-        hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(256), 0, sp, lg, ctx->pitch_freq, f0, B, T);
+        hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(kPdWaves * 64), 0, sp, lg, ctx->pitch_freq, f0, B, T);
     }
     if (fork) TVC_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
     for (int i = 0; i < 6; ++i) TVC_CHECK(run_convnext(ctx, s, wssl, dry, ctx->ssl_mid[i], xs, B, T));

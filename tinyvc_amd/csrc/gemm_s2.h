@@ -22,6 +22,10 @@
 
 namespace tvc {
 
+#ifndef G2_NWV_MIN
+#define G2_NWV_MIN 2     // narrowest workgroup tile: 32 * G2_NWV_MIN columns
+#endif
+
 struct Gemm2Args {
     const uint4* A6;       // split weight image [K16 step][m-tile][part][lane][8 bf16]
     int MT;                // m-tiles (32 rows) in the image
@@ -296,13 +300,15 @@ inline bool gemm_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const PackedW& w, 
     const int mblocks = w.MT6 / 4, slots = ncu / 8 * 8;
     int best = 4;
     long best_cost = -1;
-    for (int nwv = 4; nwv <= 6; ++nwv) {
+    for (int nwv = G2_NWV_MIN; nwv <= 6; ++nwv) {     // 64-column tiles only pay when the launch cannot fill the chip (a streaming block: 896 columns)
         const long tiles = (ncols + nwv * 32 - 1) / (nwv * 32) * mblocks;
         const long rounds = (tiles + slots - 1) / slots;
         const long cost = rounds * (nwv * 32 + 64);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nwv; }
     }
-    if (best == 4) *rc = gemm_s2_launch_t<4, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu);
+    if (best == 2) *rc = gemm_s2_launch_t<2, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu);
+    else if (best == 3) *rc = gemm_s2_launch_t<3, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu);
+    else if (best == 4) *rc = gemm_s2_launch_t<4, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu);
     else if (best == 5) *rc = gemm_s2_launch_t<5, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu);
     else *rc = gemm_s2_launch_t<6, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu);
     return true;

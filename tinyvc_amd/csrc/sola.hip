@@ -54,10 +54,67 @@ static __device__ void phase_vocoder_block(const float* a, const float* b, const
     __syncthreads();
 }
 
-// one workgroup per stream
+// Normalised cross-correlation over the SEARCH + 1 lags (the two F.conv1d of stream.py:77-78), split over kSolaGroups workgroups
+// per stream: one lag per thread, the same sums in the same order as the one-workgroup kernel below (bit-identical values), so
+// the search of 32 streams fills the chip instead of 32 CUs (173 us -> see DESIGN.md).  part[(st * G + g) * 2] = best value of
+// the group, [.. + 1] = its lag (as bits); ties keep the lowest lag.
+static __global__ __launch_bounds__(256) void sola_corr_kernel(const float* __restrict__ y, const float* __restrict__ sola_buf,
+                                                               float* __restrict__ part, long Ly, int block) {
+    constexpr int LPG = (SEARCH + 1 + kSolaGroups - 1) / kSolaGroups;     // 241 lags per group
+    __shared__ float ci[LPG + CROSS], sq[LPG + CROSS], sb[CROSS];
+    __shared__ float bestv[4];
+    __shared__ int besti[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int st = blockIdx.x / kSolaGroups, g = blockIdx.x - st * kSolaGroups;
+    const int lag0 = g * LPG;
+    const int tw_len = block + CROSS + SEARCH;
+    const float* tw = y + (long)st * Ly + (Ly - tw_len - DELAY) + lag0;
+    const int nload = (lag0 + LPG + CROSS <= CROSS + SEARCH ? LPG + CROSS : CROSS + SEARCH - lag0);
+    for (int i = tid; i < LPG + CROSS; i += 256) {
+        const float v = i < nload ? tw[i] : 0.f;
+        ci[i] = v;
+        sq[i] = v * v;
+    }
+    for (int i = tid; i < CROSS; i += 256) sb[i] = sola_buf[(long)st * CROSS + i];
+    __syncthreads();
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    const int lag = lag0 + tid;
+    if (tid < LPG && lag <= SEARCH) {
+        float nom = 0.f, den = 0.f;
+        const float* c = ci + tid;
+        const float* q = sq + tid;
+#pragma unroll 8
+        for (int j = 0; j < CROSS; ++j) {
+            nom = fmaf(c[j], sb[j], nom);
+            den += q[j];
+        }
+        bv = nom / sqrtf(den + 1e-8f);
+        bi = lag;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(bv, o);
+        int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { bestv[wave] = bv; besti[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        float v = bestv[0];
+        int i = besti[0];
+        for (int w = 1; w < 4; ++w)
+            if (bestv[w] > v || (bestv[w] == v && besti[w] < i)) { v = bestv[w]; i = besti[w]; }
+        part[(long)blockIdx.x * 2] = v;
+        part[(long)blockIdx.x * 2 + 1] = __int_as_float(i);
+    }
+}
+
+// one workgroup per stream; `part` != nullptr: the lag search was done by sola_corr_kernel, only its kSolaGroups candidates are compared here
 static __global__ __launch_bounds__(256) void sola_kernel(const float* __restrict__ y, float* __restrict__ sola_buf,
                                                           const float* __restrict__ fade_in, float* __restrict__ out,
-                                                          int32_t* __restrict__ shift_out, long Ly, int block, int use_pv) {
+                                                          int32_t* __restrict__ shift_out, long Ly, int block, int use_pv,
+                                                          const float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* ci = sm;                       // [CROSS + SEARCH] head of temp_wav
     float* sb = sm + CROSS + SEARCH;      // [CROSS] sola buffer
@@ -71,10 +128,12 @@ static __global__ __launch_bounds__(256) void sola_kernel(const float* __restric
     const float* tw = y + (long)st * Ly + (Ly - tw_len - DELAY);
     float* sbuf = sola_buf + (long)st * CROSS;
 
-    for (int i = tid; i < CROSS + SEARCH; i += 256) {
-        float v = tw[i];
-        ci[i] = v;
-        sq[i] = v * v;
+    if (!part) {
+        for (int i = tid; i < CROSS + SEARCH; i += 256) {
+            float v = tw[i];
+            ci[i] = v;
+            sq[i] = v * v;
+        }
     }
     for (int i = tid; i < CROSS; i += 256) sb[i] = sbuf[i];
     __syncthreads();
@@ -82,14 +141,21 @@ static __global__ __launch_bounds__(256) void sola_kernel(const float* __restric
     // normalised cross-correlation over SEARCH+1 lags (two F.conv1d in stream.py:77-78)
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int lag = tid; lag <= SEARCH; lag += 256) {
-        float nom = 0.f, den = 0.f;
-        for (int j = 0; j < CROSS; ++j) {
-            nom = fmaf(ci[lag + j], sb[j], nom);
-            den += sq[lag + j];
+    if (part) {
+        if (tid < kSolaGroups) {
+            bv = part[((long)st * kSolaGroups + tid) * 2];
+            bi = __float_as_int(part[((long)st * kSolaGroups + tid) * 2 + 1]);
         }
-        float v = nom / sqrtf(den + 1e-8f);
-        if (v > bv) { bv = v; bi = lag; }   // ascending lags per thread: first maximum kept
+    } else {
+        for (int lag = tid; lag <= SEARCH; lag += 256) {
+            float nom = 0.f, den = 0.f;
+            for (int j = 0; j < CROSS; ++j) {
+                nom = fmaf(ci[lag + j], sb[j], nom);
+                den += sq[lag + j];
+            }
+            float v = nom / sqrtf(den + 1e-8f);
+            if (v > bv) { bv = v; bi = lag; }   // ascending lags per thread: first maximum kept
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -137,7 +203,14 @@ static __global__ __launch_bounds__(256) void sola_kernel(const float* __restric
 int run_sola(tvc_ctx* ctx, hipStream_t s, const float* y, float* sola_buf, const float* fade_in, float* out,
              int32_t* shift_out, int S, int64_t Ly, int block, int use_pv) {
     size_t lds = (size_t)(2 * (CROSS + SEARCH) + CROSS + 8 + 4 * 968) * sizeof(float) + 64;
-    hipLaunchKernelGGL(sola_kernel, dim3(S), dim3(256), lds, s, y, sola_buf, fade_in, out, shift_out, (long)Ly, block, use_pv);
+    // the lag search on S * kSolaGroups workgroups when its scratch (context-owned, one call at a time like every other scratch of the
+    // context) holds their candidates; the arg-max, cross-fade and buffer update stay one workgroup per stream
+    float* part = nullptr;
+    if (ctx->sola_part && (long)S * kSolaGroups * 2 <= kSolaPartFloats) {
+        part = const_cast<float*>(ctx->sola_part);
+        hipLaunchKernelGGL(sola_corr_kernel, dim3(S * kSolaGroups), dim3(256), 0, s, y, sola_buf, part, (long)Ly, block);
+    }
+    hipLaunchKernelGGL(sola_kernel, dim3(S), dim3(256), lds, s, y, sola_buf, fade_in, out, shift_out, (long)Ly, block, use_pv, part);
     return launch_check(ctx, "sola");
 }
 

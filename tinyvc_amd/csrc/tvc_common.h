@@ -25,6 +25,7 @@ constexpr int kPitchClasses = 512;
 constexpr int kSrcCh = 128;
 constexpr int kHarm = 15;  // num_harmonics + 1 sinusoids
 constexpr int kSolaCross = 1920, kSolaSearch = 1920, kSolaDelay = 3840;
+constexpr int kSolaGroups = 8, kSolaPartFloats = 16384;   // lag groups (workgroups) per stream of the correlation search; its scratch in the context's constant arena
 
 // A conv / 1x1 weight packed for the split-precision MFMA kernels (conv3s.h): the bf16x3 image A6 (K16 steps x MT6 = Mpad / 32
 // m-tiles x 3 parts, 1 KiB pieces in MFMA lane order) plus the bias row [Mpad].  M / K = real rows / k = cin * taps.
@@ -96,6 +97,7 @@ struct tvc_ctx {
     const float* fft_tw1920 = nullptr;
     const float* fft_hann = nullptr;
     const float* pitch_freq = nullptr;  // [512]
+    const float* sola_part = nullptr;   // scratch of the split SOLA search: (best value, best lag) per (stream, lag group); kSolaPartFloats floats
 
     // encoder
     tvc::PackedW enc_in;  // ssl(384) and pitch(128) input 1x1 stacked: M = 512

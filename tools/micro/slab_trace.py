@@ -44,6 +44,9 @@ for slot in range(64):
     grid, ntiles = int(g[2]) >> 32, int(g[2]) & 0xffffffff
     st = [(int(v) >> 8, int(v) & 255) for v in g[4:4 + n]]
     nm = names2 if mtb == 2 else names
+    if int(g[3]):
+        mt, rt = int(g[3]) >> 32, int(g[3]) & 0xffffffff
+        print(f"   calibration: {mt} s_memtime ticks in {rt} x 10 ns -> {mt / max(rt, 1) * 100:.0f} MHz")
     print(f"slot {slot}: MTB={mtb} KG={kg} TAPS={taps} SCALED={scaled} FILM={film} Cin={cin} grid={grid} tiles={ntiles} stamps={n}")
     # per phase: time from previous stamp
     acc = {}
