@@ -164,9 +164,10 @@ int run_prepare_index_f16(tvc_ctx* ctx, hipStream_t s, const void* rows16, float
 // qh (optional) = the same values in fp16, in the coarse pass's B-fragment order [256-query tile][K16 step][8-channel half][query][8]
 // (columns beyond ncols of the last tile are zero); cnt / flag (optional) = the two-stage search's per-query candidate
 // counters and its overflow flag, zeroed here.
-static __global__ __launch_bounds__(256) void query_normalize_kernel(const float* __restrict__ src, float* __restrict__ qn, int B, int T,
+constexpr int QN_WAVES = 16;     // waves per 64-column group: each squares / scales KD / 16 = 48 channels (strided rows: the loop is a latency chain)
+static __global__ __launch_bounds__(QN_WAVES * 64) void query_normalize_kernel(const float* __restrict__ src, float* __restrict__ qn, int B, int T,
                                                                      uint4* __restrict__ qh, int* __restrict__ cnt, int* __restrict__ flag) {
-    __shared__ float part[4][64];
+    __shared__ float part[QN_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long ncols = (long)B * T;
     const long n = blockIdx.x * 64L + lane;
@@ -175,12 +176,15 @@ static __global__ __launch_bounds__(256) void query_normalize_kernel(const float
     const int b = (int)(nn / T), t = (int)(nn - (long)b * T);
     const float* p = src + (long)b * KD * T + t;
     float* q = qn + (long)b * KD * T + t;
-    const int k0 = wave * (KD / 4), k1 = k0 + KD / 4;
+    const int k0 = wave * (KD / QN_WAVES), k1 = k0 + KD / QN_WAVES;
     float s = 0.f;
     for (int k = k0; k < k1; ++k) s = fmaf(p[(long)k * T], p[(long)k * T], s);
     part[wave][lane] = s;
     __syncthreads();
-    const float den = sqrtf(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) + 1e-6f;
+    float ss = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < QN_WAVES; ++w) ss += part[w][lane];      // fixed order
+    const float den = sqrtf(ss) + 1e-6f;
     if (blockIdx.x == 0 && threadIdx.x == 0 && flag) *flag = 0;
     if (wave == 0 && ok && cnt) cnt[n] = 0;
     uint4* qhp = qh ? qh + (n >> 8) * (long)(STEPS * 2 * 256) + (n & 255) : nullptr;
@@ -946,7 +950,7 @@ static int knn_candidates(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
     if (dry) return 0;
     if (N > 0x7fffff00L) return fail(ctx, TVC_ERR_ARG, "index too large");
     const int nblk = two_stage ? cq * 4 : (p.ncols + 63) / 64;      // the fp16 query image is written for whole 256-query tiles
-    hipLaunchKernelGGL(query_normalize_kernel, dim3(nblk), dim3(256), 0, s, src, qn, B, T, qh, cnt, L->flag);
+    hipLaunchKernelGGL(query_normalize_kernel, dim3(nblk), dim3(QN_WAVES * 64), 0, s, src, qn, B, T, qh, cnt, L->flag);
     if (two_stage) {
         ProfScope ps(ctx, s, dry, "knn.coarse+rescore");
         const int t2 = (int)((p.Npad + C_MT - 1) / C_MT);          // 256-vector tiles
