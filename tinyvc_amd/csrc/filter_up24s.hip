@@ -48,7 +48,7 @@ struct U24S {
     static constexpr int HP = NT1 * 32;                        // Hs rows per (part, group)
     static constexpr int XW = W2 + 2 * H;                      // input columns (position t0 - E - H + c)
     static constexpr int XP = XW;
-    static constexpr int PS = W2r + 4;                         // fp32 residual tile row stride
+    static constexpr int PS = W2r + 16;                        // fp32 residual tile row stride: 272 = the one stride <= 300 for which the output pass's 16-byte reads (8 lanes x 3 rows apart, 4 columns per lane) are conflict-free in all four ds_read_b128 lane groups (W2r + 4 was 3-way)
     static constexpr int ITEMS = 3 * XW, XPER = (ITEMS + NT - 1) / NT;
     static constexpr int PIECES = 42, FL = 304;
     static constexpr int LDS_BYTES = (9 * XP + 9 * HP + PIECES * 64) * 16 + (FL + C * PS) * 4;
