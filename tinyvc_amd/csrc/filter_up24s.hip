@@ -33,6 +33,9 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 #ifndef U24S_S4VEC
 #define U24S_S4VEC 1   // output conv reads its 10 activations per channel as three 16-byte LDS reads on interior tiles
 #endif
+#ifndef U24S_SWAP
+#define U24S_SWAP 1
+#endif
 #ifndef U24S_WPE
 #define U24S_WPE 2     // 8 waves per CU: 256 registers each
 #endif
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const int h = nt * 32 + l31;
             if (!(U24S_ABL & 1)) conv24_phase<XP, D1>(acc, Xs, Wt, h, 0, XW - 1, lane);      // Xs already holds the replicate-padded input
+            u32x2 p3s[3];
 #pragma unroll
             for (int g = 0; g < ((U24S_ABL & 16) ? 0 : 3); ++g) {
                 const f32x4s bv = *reinterpret_cast<const f32x4s*>(Fl + 8 * g + 4 * lh);
@@ -255,10 +259,31 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 u32x2 p1, p2, p3;
                 split4(v, p1, p2, p3);
                 u32x2* hrow = reinterpret_cast<u32x2*>(Hs);
+#if U24S_SWAP
+                // A position's 16-byte row = [lanes 0-31's four channels | lanes 32-63's four].  Two 8-byte stores per row from the two
+                // lane halves are 2-way bank conflicts (16-byte stride inside a 16-lane store group); v_permlane32_swap hands the lower
+                // half of the wave both halves of the part-1 row and the upper half both halves of the part-2 row: one 16-byte store
+                // each, conflict-free.  Part 3 keeps its 8-byte stores.
+                const auto sx = __builtin_amdgcn_permlane32_swap(p1[0], p2[0], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(p1[1], p2[1], false, false);
+                const u32x4 row = {sx[0], sy[0], sx[1], sy[1]};
+                *reinterpret_cast<u32x4*>(Hs + (3 * lh + g) * HP + h) = row;
+                p3s[g] = p3;
+#else
                 hrow[((0 + g) * HP + h) * 2 + lh] = p1;
                 hrow[((3 + g) * HP + h) * 2 + lh] = p2;
                 hrow[((6 + g) * HP + h) * 2 + lh] = p3;
+#endif
             }
+#if U24S_SWAP
+            if (!(U24S_ABL & 16)) {   // part 3: the rows of channel groups 0 and 1 the same way (lower half -> group 0, upper half -> group 1), group 2 as two 8-byte stores
+                const auto sx = __builtin_amdgcn_permlane32_swap(p3s[0][0], p3s[1][0], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(p3s[0][1], p3s[1][1], false, false);
+                const u32x4 row = {sx[0], sy[0], sx[1], sy[1]};
+                *reinterpret_cast<u32x4*>(Hs + (6 + lh) * HP + h) = row;
+                reinterpret_cast<u32x2*>(Hs)[((6 + 2) * HP + h) * 2 + lh] = p3s[2];
+            }
+#endif
         }
         slab_barrier();
 
