@@ -272,15 +272,27 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
             // the finished 48 x 128 tile goes back into the (now idle) input tile as c5's B operand: split, rows
             // [part][group 4 mt + g][column], this lane's four channels are one 8-byte half of a row
             slab_barrier();                               // every wave is done reading Xs
-            u32x2_t* xrow = reinterpret_cast<u32x2_t*>(Xs);
+            // (a row = [lanes 0-31's four channels | lanes 32-63's four]: 8-byte stores from the two lane halves are 2-way bank
+            // conflicts; v_permlane32_swap gives the lower half of the wave both halves of one row and the upper half both halves of
+            // another - part 1 / part 2 of a group, part 3 of two neighbouring groups - so every store is 16 bytes)
+            u32x2_t p3s[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (32 * mt + 8 * g >= C) continue;
-                u32x2_t p1, p2, p3;
-                split4_48(xv[g], p1, p2, p3);
-                xrow[((0 + 4 * mt + g) * XP + n) * 2 + lh] = p1;
-                xrow[((6 + 4 * mt + g) * XP + n) * 2 + lh] = p2;
-                xrow[((12 + 4 * mt + g) * XP + n) * 2 + lh] = p3;
+                u32x2_t p1, p2;
+                split4_48(xv[g], p1, p2, p3s[g]);
+                const auto sx = __builtin_amdgcn_permlane32_swap(p1[0], p2[0], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(p1[1], p2[1], false, false);
+                const u32x4 row = {sx[0], sy[0], sx[1], sy[1]};
+                *reinterpret_cast<u32x4*>(Xs + (6 * lh + 4 * mt + g) * XP + n) = row;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                if (32 * mt + 8 * g >= C) continue;
+                const auto sx = __builtin_amdgcn_permlane32_swap(p3s[g][0], p3s[g + 1][0], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(p3s[g][1], p3s[g + 1][1], false, false);
+                const u32x4 row = {sx[0], sy[0], sx[1], sy[1]};
+                *reinterpret_cast<u32x4*>(Xs + (12 + 4 * mt + g + lh) * XP + n) = row;
             }
             slab_barrier();
             if (mt == 0) {                                // 24 output rows = one m-tile: the first four waves, one n-tile each

@@ -213,8 +213,8 @@ struct PTop4 {
 constexpr int kPdWaves = 16;
 static __global__ __launch_bounds__(kPdWaves * 64) void pitch_decode_kernel(const float* __restrict__ logits, const float* __restrict__ freq,
                                                                   float* __restrict__ f0, int B, int T) {
-    __shared__ float sv[kPdWaves][64][4];
-    __shared__ int si[kPdWaves][64][4];
+    __shared__ float sv[kPdWaves][4][64];     // [wave][entry][lane]: lanes along the fastest axis (the [lane][entry] order was a 4-way bank conflict)
+    __shared__ int si[kPdWaves][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long ncols = (long)B * T;
     const long n = blockIdx.x * 64L + lane;
@@ -229,12 +229,12 @@ static __global__ __launch_bounds__(kPdWaves * 64) void pitch_decode_kernel(cons
         top.insert(x != x ? INFINITY : x, c);   // torch.topk orders NaN first; also keeps the list sentinel out of freq[]
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { sv[wave][lane][e] = top.v[e]; si[wave][lane][e] = top.i[e]; }
+    for (int e = 0; e < 4; ++e) { sv[wave][e][lane] = top.v[e]; si[wave][e][lane] = top.i[e]; }
     __syncthreads();
     if (wave != 0 || !ok) return;
     for (int w = 1; w < kPdWaves; ++w)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) top.insert(sv[w][lane][e], si[w][lane][e]);
+        for (int e = 0; e < 4; ++e) top.insert(sv[w][e][lane], si[w][e][lane]);
 #pragma unroll
     for (int e = 0; e < 4; ++e) top.i[e] = (unsigned)top.i[e] < (unsigned)kPitchClasses ? top.i[e] : 0;
     const float v0 = top.v[0];
