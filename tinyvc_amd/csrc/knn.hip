@@ -685,18 +685,25 @@ static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef S_TRACE
+    struct { unsigned long long* tr = nullptr; int trn = 0; } trs;
+    __shared__ unsigned long long tr_lds[256];
+    if (MODE == 1 && blockIdx.x == S_TRACE_WG && threadIdx.x == S_TRACE_TID) trs.tr = tr_lds;
+#endif
     if (G > 0) {
         gload(0);
         lstore(0);
-        if (G > 1) gload(1);
+        gload(G > 1 ? 1 : 0);
         slab_barrier();
     }
     for (int g = 0; g < G; ++g) {
         const int cur = g & 1;
-        if (g + 1 < G) {
-            lstore(cur ^ 1);
-            if (g + 2 < G) gload(g + 2);
-        }
+        TR_STAMP(trs, 0);
+        // no branch around the staging: past the end it re-stages the last step into the idle buffer (harmless), and the
+        // compiler is free to thread the stores and loads between this step's MFMAs
+        lstore(cur ^ 1);
+        gload(g + 2 < G ? g + 2 : G - 1);
+        TR_STAMP(trs, 1);
         const uint4* as = As + cur * C_A_U4 + wm * (4 * 64) + lane;
         const uint4* xs = Xs + cur * C_X_U4 + lh * C_QT + wn * 64 + l31;
 #pragma unroll
@@ -711,6 +718,7 @@ static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __r
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        TR_STAMP(trs, 2);
         const int st = g - (g / C_STEPS) * C_STEPS;
         if (st == C_STEPS - 1) {
             const int t2 = t_lo + g / C_STEPS;
@@ -723,40 +731,70 @@ static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __r
                 const int ta = 2 * t2 < mtiles ? 2 * t2 : mtiles - 1, tb = 2 * t2 + 1 < mtiles ? 2 * t2 + 1 : mtiles - 1;
                 imx = fmaxf(im[ta], im[tb]);
             }
+            // Per 32 x 32 accumulator tile: the largest of a lane's 16 values decides, for the whole wave at once (ballot), whether
+            // any of them can matter; only then are the 16 walked one by one.  (The element-wise walk with its per-element
+            // branches cost 11 000 cycles per 256 x 256 tile - 18 % of the pass - although a lane sees a hit every few dozen tiles.)
+            const bool whole = m0 + C_MT <= N;                      // uniform: no row of this tile lies beyond the index
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + (wm * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < N) {
+                for (int j = 0; j < 2; ++j) {
+                    float mx = acc[i][j][0];
+                    bool anynan = false;
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const float a = acc[i][j][r];
-                            if (MODE == 0) {
-                                if (!F16) {
-                                    top[j].insert(nan_max(a));
-                                } else if (!(fmaxf(a, 0.f) * imx <= top[j].v[3])) {      // could enter the list (NaN passes)
-                                    top[j].insert(nan_max(a * inv[row]));
-                                }
-                            } else {
-                                bool hit;
-                                if (!F16) hit = a >= th[j];
-                                else hit = (fmaxf(a, 0.f) * imx >= th[j]) && (a * inv[row] >= th[j]);
-                                if (hit) {
-                                    const int n = n0 + wn * 64 + j * 32 + l31;
-                                    const int pos = atomicAdd(&cnt[n], 1);
-                                    if (pos < C_CAP) cand[(long)n * C_CAP + pos] = row;
-                                    else *overflow = 1;
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
+                    if (MODE == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) anynan |= acc[i][j][r] != acc[i][j][r];      // NaN enters the list as +inf (nan_max): never skipped
+                    }
+                    bool maybe;
+                    if (MODE == 0) maybe = anynan || !((F16 ? fmaxf(mx, 0.f) * imx : mx) <= top[j].v[3]);
+                    else maybe = (F16 ? fmaxf(mx, 0.f) * imx : mx) >= th[j];
+                    if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = m0 + (wm * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            if (whole || row < N) {
+                                const float a = acc[i][j][r];
+                                if (MODE == 0) {
+                                    if (!F16) {
+                                        top[j].insert(nan_max(a));
+                                    } else if (!(fmaxf(a, 0.f) * imx <= top[j].v[3])) {      // could enter the list (NaN passes)
+                                        top[j].insert(nan_max(a * inv[row]));
+                                    }
+                                } else {
+                                    bool hit;
+                                    if (!F16) hit = a >= th[j];
+                                    else hit = (fmaxf(a, 0.f) * imx >= th[j]) && (a * inv[row] >= th[j]);
+                                    if (hit) {
+                                        const int n = n0 + wn * 64 + j * 32 + l31;
+                                        const int pos = atomicAdd(&cnt[n], 1);
+                                        if (pos < C_CAP) cand[(long)n * C_CAP + pos] = row;
+                                        else *overflow = 1;
+                                    }
                                 }
                             }
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
                 }
         }
+        TR_STAMP(trs, 3);
         slab_barrier();
+        TR_STAMP(trs, 4);
     }
+#ifdef S_TRACE
+    if (trs.tr) {
+        const unsigned slot = atomicAdd(&g_trace_slot, 1u) & 63u;
+        unsigned long long* gt = g_trace + slot * 256;
+        gt[0] = 0x5452414345000000ull | (9ull << 20) | ((unsigned long long)F16 << 8);
+        gt[1] = ((unsigned long long)G << 32) | (unsigned)trs.trn;
+        gt[2] = ((unsigned long long)gridDim.x << 32) | (unsigned)nsplit;
+        gt[3] = 0;
+        for (int i = 0; i < trs.trn; ++i) gt[4 + i] = trs.tr[i];
+    }
+#endif
     if (MODE == 1) return;
 
     // merge the 4 partial lists (wm x lh) of every query through LDS, write this split's four largest coarse values
@@ -1005,3 +1043,9 @@ int run_knn(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, con
 }
 
 }  // namespace tvc
+
+#ifdef S_TRACE
+extern "C" int tvc_debug_trace_knn(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(tvc::g_trace), sizeof(tvc::g_trace)) == hipSuccess ? 0 : -1;
+}
+#endif

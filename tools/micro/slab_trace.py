@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--frames", type=int, default=200)
 ap.add_argument("--dec", action="store_true")
+ap.add_argument("--knn", type=int, default=0, help="trace the coarse kNN pass against an index of this many vectors instead")
 ap.add_argument("--reps", type=int, default=3)
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -23,16 +24,17 @@ eng = gen.engine(dev)
 lib = _lib.load_library()
 L = args.frames * 480
 wf = synth.synth_wave(args.batch, L, seed=100).to(dev)
-tgt = synth.synth_index(10000, seed=4).to(dev)
+tgt = synth.synth_index(args.knn or 10000, seed=4).to(dev)
 for _ in range(args.reps):
     out = gen.convert(wf, tgt, 0.0)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (64 * 256))()
-fn = getattr(lib, "tvc_debug_trace_dec" if args.dec else "tvc_debug_trace_enc")
+fn = getattr(lib, "tvc_debug_trace_knn" if args.knn else ("tvc_debug_trace_dec" if args.dec else "tvc_debug_trace_enc"))
 fn.argtypes = [ctypes.c_void_p]
 assert fn(buf) == 0
 tr = np.frombuffer(buf, dtype=np.uint64).reshape(64, 256)
 names = {0: "top", 1: "bar1", 2: "lstore", 3: "loads", 4: "bar2", 5: "mfma", 7: "tile_end"}
+names9 = {0: "top", 1: "stage_issue", 2: "mfma", 3: "epilogue", 4: "barrier"}
 names2 = {0: "top", 1: "mfma_k0", 2: "split+ds_write", 3: "load_issue", 4: "mfma_k1", 5: "barrier"}
 for slot in range(64):
     g = tr[slot]
@@ -43,7 +45,7 @@ for slot in range(64):
     cin, n = int(g[1]) >> 32, int(g[1]) & 0xffffffff
     grid, ntiles = int(g[2]) >> 32, int(g[2]) & 0xffffffff
     st = [(int(v) >> 8, int(v) & 255) for v in g[4:4 + n]]
-    nm = names2 if mtb == 2 else names
+    nm = names9 if mtb == 9 else (names2 if mtb == 2 else names)
     if int(g[3]):
         mt, rt = int(g[3]) >> 32, int(g[3]) & 0xffffffff
         print(f"   calibration: {mt} s_memtime ticks in {rt} x 10 ns -> {mt / max(rt, 1) * 100:.0f} MHz")
