@@ -128,6 +128,8 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
                 kr[i][1] = ldg_so4(kc, 4u * ko[i] + 16u);
             }
         }
+    };
+    auto advance_load = [&]() __attribute__((always_inline)) {
         if (++ls == nslab) {      // next tile of this workgroup's walk; past the last one the cursor stays on the last slab
             const int v2 = next_valid(lv + stride);   // (the loads it repeats are harmless and keep the loop body free of branches)
             if (v2 < a.vtiles) {
@@ -202,8 +204,10 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
 #endif
 
     issue_load();                 // unit 0
+    advance_load();
     lstore(0);
     issue_load();                 // unit 1
+    advance_load();
     slab_barrier();
     int buf = 0;
     while (true) {
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
         TR_STAMP(trs, 3);
         multiply(buf, 1);
         TR_STAMP(trs, 4);
+        advance_load();           // (behind the MFMAs: the slab body above is one basic block)
         if (++cs == nslab) {
             // epilogue straight from the accumulators (gemm_epi.h functors finish the element)
 #pragma unroll
