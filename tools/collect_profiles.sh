@@ -21,4 +21,5 @@ rm -rf /tmp/p4; cd /tmp; TVC_BENCH_NOTIMERS=1 timeout 600 rocprofv3 --kernel-tra
 python tools/rocpd_stats.py $(find /tmp/p4 -name "*.db" | head -1) $O/${TAG}_kernel_stats_notimers.txt
 python tools/copybuffer_origin.py $(find /tmp/p4 -name "*.db" | head -1) > $O/${TAG}_copybuffer_origin.txt 2>&1
 timeout 900 python bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench.json
+timeout 300 python bench_stream.py 2>/dev/null | tail -1 > $O/${TAG}_stream_32streams.json      # configs[2] on its own (200 blocks)
 tail -2 $O/${TAG}_pytest_gpu.txt; cut -c1-400 $O/${TAG}_bench.json; grep -c copyBuffer $O/${TAG}_kernel_stats.txt $O/${TAG}_kernel_stats_notimers.txt; grep copyBuffer $O/${TAG}_kernel_stats.txt $O/${TAG}_kernel_stats_notimers.txt
