@@ -311,10 +311,14 @@ __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restr
 
 // acc += W (.) x over all slabs of one input tensor.  Slab 0 is already in flight in `r` (first_load); `next()`
 // is called in its place behind the last slab, so the following phase or tile starts without a cold load.
-template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, bool LERP = false, bool CLAMP = false, class Next>
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+// TWO: the same input tile is multiplied with two row blocks of the image one after the other (mt0, then mt0b) in ONE slab loop -
+// FiLM's scale and shift on wide tiles, `mid()` is called between the two (it folds the first result away and clears `acc`)
+template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, bool LERP = false, bool CLAMP = false, bool TWO = false, class Next, class Mid = NoMid>
 __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
                                             const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next,
-                                            const float* Ks = nullptr, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0, float lscale = 0.f) {
+                                            const float* Ks = nullptr, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0, float lscale = 0.f,
+                                            int mt0b = 0, Mid mid = Mid()) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -356,17 +360,21 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
             }
     };
 
-    const int nslab = Cin / (16 * TL::KG);
+    const int nslab1 = Cin / (16 * TL::KG);
+    const int nslab = TWO ? 2 * nslab1 : nslab1;
     const uint4* as0 = As + wm * WM * 192 + lane;
     const uint4* xs0 = Xs + lh * XROW + wn * WN * 32 + l31;
     for (int s = 0; s < nslab; ++s) {
         TR_STAMP(r, 0);
         slab_barrier();                            // every wave is done reading the previous slab
         TR_STAMP(r, 1);
-        lstore(s);                                 // slab s: registers -> LDS
+        if (TWO && s == nslab1) mid();
+        lstore(TWO && s >= nslab1 ? s - nslab1 : s);   // slab s: registers -> LDS
         TR_STAMP(r, 2);
-        if (s + 1 < nslab) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin);   // flies across this slab's MFMAs
-        else next();
+        if (s + 1 < nslab) {                       // flies across this slab's MFMAs
+            if (TWO) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, s + 1 >= nslab1 ? mt0b : mt0, xb, Cin, len, s + 1 >= nslab1 ? s + 1 - nslab1 : s + 1, fT, cmax, lin);
+            else slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin);
+        } else next();
         TR_STAMP(r, 3);
         slab_barrier();
         TR_STAMP(r, 4);
@@ -804,7 +812,49 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        if constexpr (FILM) {
+        if constexpr (FILM && TL::WN > 1) {
+            // Wide tiles (two n-tiles per wave): three accumulator sets do not fit the register budget, so scale and shift are the two
+            // halves of ONE slab loop over the cond tile (split_phase<TWO>) sharing one extra set: out = ((h + b)(sc + b_sc)) + (sh + b_sh)
+            // in the same order as below, (h + b)(sc + b_sc) replaces h between the halves.  The cond tile is staged twice; in exchange
+            // the conv phase (3/5 of the MFMAs) runs on the 96 x 256 tile of the plain convs.
+            const float* cb = a.cond + (long)b * a.Ccond * len;
+            const int mtoff = a.MT;
+            split_phase<TL, TAPS, A_U4, LRELU, S_FB_F, false, LERP, false>(
+                acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+                [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, 2 * a.MT, mt0, cb, a.Ccond, len, 0, t0); }, nullptr, 0, 0u, 0, a.lin, a.lscale);
+            f32x16 af[WM][WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) af[i][j][r] = 0.f;
+            split_phase<TL, 1, A_U4, false, S_FB_F, false, false, false, true>(
+                af, regs, a.sc6, 2 * a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile, nullptr, 0, 0u, 0, 0, 0.f, mtoff + mt0,
+                [&]() __attribute__((always_inline)) {
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = rl + i * 32 + (r & 3) + 8 * (r >> 2);
+                            const float bm = Bs[row], bs = Bs[TL::BM + row];
+#pragma unroll
+                            for (int j = 0; j < WN; ++j) {
+                                acc[i][j][r] = __fmul_rn(acc[i][j][r] + bm, af[i][j][r] + bs);
+                                af[i][j][r] = 0.f;
+                            }
+                        }
+                });
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float bh = Bs[2 * TL::BM + rl + i * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j][r] = __fadd_rn(acc[i][j][r], af[i][j][r] + bh);
+                }
+            tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
+        } else if constexpr (FILM) {
             // conv -> FiLM -> + residual (decoder.py:94-97,181-182): scale and shift come from one more 1x1 phase over
             // the cond tile on the same output tiles; (conv, scale, shift) combine in registers.
             const float* cb = a.cond + (long)b * a.Ccond * len;
@@ -992,6 +1042,9 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
 #ifndef TVC_SF_WN
 #define TVC_SF_WN 1
 #endif
+#ifndef TVC_SF_WIDE
+#define TVC_SF_WIDE 1   // FiLM-fused launches: 0 = always the 96 x 128 tile, 1 = the 96 x 256 tile where rounds x tile cost favours it, 2 = always wide
+#endif
 #ifndef TVC_S_WM
 #define TVC_S_WM 1
 #endif
@@ -1014,6 +1067,19 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
     }
     if constexpr (FILM)
     {
+        // Two tiles for the FiLM-fused launches.  96 x 128: scale and shift in one phase, three accumulator sets.  96 x 256 (the plain
+        // convs' tile): the conv phase stages a slab for twice the columns, scale and shift run one after the other on one extra set
+        // (split_phase<TWO>) and the cond tile is staged twice - per column ~7 % cheaper (measured: C = 384 level 0.950 -> 0.915 ms,
+        // C = 96 level 0.725 -> 0.698), unless the wide tiles leave the last round of the 256 persistent workgroups underfilled (C = 192
+        // level, 640 tiles: 0.675 -> 0.712).  Rounds x per-tile cost decides; a launch that cannot fill the chip keeps the narrow tile.
+        const long mb = w.MT6 / 3;
+        const long tiles_n = mb * ((len + 127) / 128) * B, tiles_w = mb * ((len + 255) / 256) * B;
+        const long slots = 256 * S_BPC;
+        const long rounds_n = (tiles_n + slots - 1) / slots, rounds_w = (tiles_w + slots - 1) / slots;
+        const bool wide = TVC_SF_WIDE == 2 || (TVC_SF_WIDE == 1 && tiles_w >= slots && rounds_w * 186 < rounds_n * 100);
+        if (wide)
+            return conv3s_launch_t<SplitTile<3, 1, 4, 2>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC, nullptr, false,
+                                                                                           0, lin, lscale);
         return conv3s_launch_t<SplitTile<3, TVC_SF_WM, TVC_SF_NWV, TVC_SF_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0,
                                                                                                                 S_BPC, nullptr, false, 0, lin, lscale);
     }
