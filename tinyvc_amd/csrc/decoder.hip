@@ -1,8 +1,13 @@
 // Source-filter decoder (decoder.py:24-266): SourceNet, additive harmonic oscillator, filtered-noise
 // iSTFT, and the FilterNet U-Net.
 #include "conv3s.h"
+#include "gemm_s2.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
+
+#ifndef DEC_G2
+#define DEC_G2 1     // the two 768-channel input contractions on the pipelined GEMM kernel (gemm_s2.h)
+#endif
 
 namespace tvc {
 
@@ -161,7 +166,9 @@ static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
     if (!dry) {
         hipLaunchKernelGGL(window_max_kernel, dim3(grid_for((long)ncols * 64)), dim3(256), 0, s, energy, ef, (long)B, T, kHop);
         EpiSumCond ep{x, ctx->src_content_in.bias, ef, f0, ctx->src_e_w, ctx->src_e_b, ctx->src_f_w, ctx->src_f_b, kSrcCh, T, ncols};
-        TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep)));
+        int rc = 0;
+        if (!(DEC_G2 && gemm_s2_try(&rc, ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep))) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep);
+        TVC_CHECK(rc);
     }
     for (int i = 0; i < 3; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->src_mid[i], x, B, T));
     if (dry) return 0;
@@ -228,7 +235,9 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
     if (!dry) {
         ProfScope ps(ctx, s, dry, "filter.in+down0");
         EpiSumCond ep{x, ctx->flt_content_in.bias, nullptr, f0, nullptr, nullptr, ctx->flt_f_w, ctx->flt_f_b, ch[0], T, B * T};
-        TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep)));
+        int rc = 0;
+        if (!(DEC_G2 && gemm_s2_try(&rc, ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep))) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep);
+        TVC_CHECK(rc);
         TVC_CHECK(run_down0_split(ctx, s, ctx->flt_down0s, source, energy, skip[0], xi_pre[1], B, (int)L));
     }
     // down path
