@@ -70,6 +70,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friend
 #ifndef S_FB_F
 #define S_FB_F 1   // FiLM-fused kernels: two accumulator sets live, single fragment set keeps the slab loops spill-free
 #endif
+#ifndef S_FB_FW
+#define S_FB_FW 2   // conv phase of the wide FiLM tile
+#endif
 #ifndef S_PF
 #define S_PF 2   // residual rows requested at a time by the lerp epilogue
 #endif
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             // the conv phase (3/5 of the MFMAs) runs on the 96 x 256 tile of the plain convs.
             const float* cb = a.cond + (long)b * a.Ccond * len;
             const int mtoff = a.MT;
-            split_phase<TL, TAPS, A_U4, LRELU, S_FB_F, false, LERP, false>(
+            split_phase<TL, TAPS, A_U4, LRELU, S_FB_FW, false, LERP, false>(      // only one accumulator set is live here: two fragment sets fit
                 acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                 [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, 2 * a.MT, mt0, cb, a.Ccond, len, 0, t0); }, nullptr, 0, 0u, 0, a.lin, a.lscale);
             f32x16 af[WM][WN];
