@@ -7,13 +7,16 @@
 // alternating between two barriers, so the matrix pipe idles half of the time.  Here
 //   * the LDS staging area is double-buffered and a slab costs ONE barrier: while slab u multiplies out of buffer
 //     u & 1, the same waves split slab u + 1 into the other buffer and request slab u + 2 - the staging
-//     instructions sit between the two K16 steps' MFMAs of every wave instead of in a phase of their own;
+//     instructions sit between the two K16 steps' MFMAs of every wave instead of in a phase of their own.  The slab body
+//     has no branch (the load cursor parks on the last slab of the walk and is advanced behind the MFMAs), so it is one
+//     basic block and the compiler threads the ds_writes, splits and loads between the first step's MFMAs;
 //   * the (tile, slab) pairs a persistent workgroup walks form ONE flat pipeline: the next tile's first slabs are
 //     staged under the last slabs of this one, and a wave's epilogue (bias / GELU / residual, stores straight from the
 //     accumulators) overlaps the other waves' next slab;
-//   * one workgroup per CU (96-144 KB of LDS), so the register budget is 168-256 per lane: no spills at any tile;
-//   * the column-tile width is chosen per launch (128 / 160 / 192 columns) so that the tile count fills whole
-//     rounds of the 256 CUs (600 tiles on 512 slots was 2 rounds at 59 % fill);
+//   * one workgroup per CU (72-123 KB of LDS), 4-12 waves: no spills at any tile;
+//   * the column-tile width is chosen per launch (64 ... 192 columns) so that the tile count fills whole rounds of
+//     the 256 CUs (conv3s's 600 tiles on 512 slots were 2 rounds at 59 % fill) and, when a launch cannot fill the chip
+//     (a streaming block is 896 columns), so that it spreads over the most CUs;
 //   * GRN's per-(utterance, channel) factors travel with the slab (two 16-byte loads per staged item), so a flat
 //     column tile may straddle any number of utterances.
 #pragma once
