@@ -40,6 +40,9 @@ FP32_MFMA_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_* p
 SPLIT_PRODUCTS = 6                         # bf16x3 split precision: six bf16 part-products per fp32 product
 
 
+STAGE_STEPS = 5      # untimed steps with every stage bracketed, after the timed region
+
+
 def measured_filter_traffic(B, L):
     """HBM bytes moved by one step's FilterNet launches, from the newest committed rocprofv3 PMC passes
     (FETCH_SIZE / WRITE_SIZE, collected and corrected as MI355X_MICROARCH.md prescribes: tools/filter_traffic.py);
@@ -150,7 +153,7 @@ def main():
     wf = synth.synth_wave(B, L, seed=(100 if world == 1 else 1000) + rank * B).to(dev)      # SURVEY §8d seeds
     tgt = synth.synth_index(n_index, seed=4 if world == 1 else 5).to(dev)
     dest = torch.empty(world, B, L, device=dev) if gather and rank == 0 else None        # rank 0's landing buffer, allocated once
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup + 1))] if gather else None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup + 1 + STAGE_STEPS))] if gather else None
     state = {"i": 0, "out": None}
     from tinyvc_amd import parallel
 
@@ -168,9 +171,12 @@ def main():
     # the warm-up too, so that the context's event pool is populated before the timed region
     # (creating events mid-stream stalls it).
     timers = not os.environ.get("TVC_BENCH_NOTIMERS")     # diagnostic: run without the library's hipEvent stage timers (no roofline then)
-    eng.profile(timers)
+    # During the timed steps only the roofline's region (FilterNet) is bracketed: one hipEvent pair per step.  All 19 regions cost
+    # ~0.12 ms of a step (38 event records); the stage split is taken from STAGE_STEPS extra, untimed steps afterwards.
+    eng.profile(1 if timers else 0)                       # every region once, so that the context's event pool is populated before the timed steps
     step()
     eng.profile_read()
+    eng.profile(2 if timers else 0)
     for _ in range(args.warmup):
         step()
         eng.profile_read()
@@ -188,11 +194,19 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    prof = eng.profile_read()
+    last = state["i"]
+    prof = eng.profile_read()                             # {"filter_net": ms summed over the timed steps}
+    stage_prof = {}
+    if timers:
+        eng.profile(1)
+        for _ in range(STAGE_STEPS):
+            step()
+        stage_prof = {k: v / STAGE_STEPS for k, v in eng.profile_read().items()}
+        fence()
     eng.profile(False)
     gather_ms = None
     if gather:
-        gather_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(first, state["i"])) / max(args.steps, 1)
+        gather_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(first, last)) / max(args.steps, 1)
     if world > 1:
         t = torch.tensor([dt, gather_ms or 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -243,7 +257,8 @@ def main():
                        "global_batch": world * B, "utterance_samples_24k": L, "index_vectors": n_index,
                        "parallelism": f"utterance-dp{world}", "x_realtime": audio_s / dt},
             "roofline": roof,
-            "stage_ms_per_step": {k: v / args.steps for k, v in sorted(prof.items())},
+            "stage_ms_per_step": dict(sorted(stage_prof.items())),
+            "stage_ms_note": f"hipEvent pairs around every stage over {STAGE_STEPS} extra steps after the timed region (the timed steps carry the filter_net pair only)",
         }
         if world > 1:
             res["rccl_ranks"] = world

@@ -823,7 +823,7 @@ int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* p
 
 int tvc_profile_enable(tvc_ctx* ctx, int on) {
     if (!ctx) return TVC_ERR_ARG;
-    ctx->profiling = on != 0;
+    ctx->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
     return TVC_OK;
 }
 

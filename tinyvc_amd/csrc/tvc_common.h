@@ -78,7 +78,7 @@ struct tvc_prof_region {
 
 struct tvc_ctx {
     int device = 0;
-    bool profiling = false;                   // tvc_profile_enable: hipEvent pairs around named regions
+    int profiling = 0;                        // tvc_profile_enable: 0 = off, 1 = hipEvent pairs around every named region, 2 = around `filter_net` only
     std::vector<tvc_prof_region> regions;
     std::vector<hipEvent_t> event_pool;       // recycled hipEvents: no hipEventCreate on the hot path
     hipStream_t side = nullptr;               // fork/join stream: the pitch estimator runs beside the SSL chain
@@ -157,6 +157,7 @@ struct ProfScope {
     int idx = -1;
     ProfScope(tvc_ctx* c, hipStream_t st, bool dry, const char* name) : ctx(c), s(st) {
         if (!c || !c->profiling || dry) return;
+        if (c->profiling == 2 && std::strcmp(name, "filter_net") != 0) return;     // the roofline's region alone: 2 event records per step instead of 38
         tvc_prof_region r;
         r.name = name;
         auto take = [&](hipEvent_t* e) {

@@ -98,7 +98,8 @@ class Engine:
         return self._seed
 
     def profile(self, on=True):
-        """Bracket every stage with hipEvents on the launch stream (see tvc_profile_read)."""
+        """Bracket stages with hipEvents on the launch stream (see tvc_profile_read): True / 1 = every stage and FilterNet block,
+        2 = the `filter_net` region only, False / 0 = off."""
         self._ok(self.lib.tvc_profile_enable(self.ctx, int(on)), "tvc_profile_enable")
 
     def profile_read(self):
