@@ -62,33 +62,104 @@ def build_generator(device):
     return Generator(enc, dec).to(device).eval()
 
 
-def cpu_baseline(seconds, n_index, batch=8, reps=5):
-    """The oracle (CPU restatement of the reference path, torch CPU ops) on the host cores, on a bounded sample of the
-    same workload (a B = 8 slice of configs[1]; all host threads, and one utterance on ONE thread)."""
+def _median(ts):
+    return sorted(ts)[len(ts) // 2]
+
+
+def cpu_baseline(seconds, n_index, batch=8):
+    """The oracle (CPU restatement of the reference path, torch CPU ops) on the host cores, on bounded samples of the
+    same workloads.  The thread count is swept ({1, 8, 16, 32, 64, all}; one warm-up + one run each on the
+    B = 8 slice of configs[1]): oneDNN / MKL oversubscribe at 128 threads on this size, so "all cores" is not the host's
+    best.  `value` = 3 warm-ups + median of 10 at the best setting (BASELINE.md §3's protocol).  Also: configs[0] (one
+    4 s utterance, 1 000-vector index, B = 1) and configs[2] with ONE stream (200 blocks, p50 / p95), same thread count."""
     from oracle import ref_cpu as R
     enc_sd, dec_sd = synth.synth_state_dict("encoder"), synth.synth_state_dict("decoder")
     L = int(seconds * SR)
     wf = synth.synth_wave(batch, L, seed=100)
     tgt = synth.synth_index(n_index, seed=4)
     angle = synth.synth_angle(batch, L // 480, 3)
-    threads = torch.get_num_threads()
-    R.convert(enc_sd, dec_sd, wf[:1], tgt, 0.0, angle[:1])          # warm-up
-    ts = []
-    for _ in range(reps):
+    all_threads = torch.get_num_threads()
+    ncpu = os.cpu_count() or all_threads
+
+    def run(b):
         t0 = time.perf_counter()
-        R.convert(enc_sd, dec_sd, wf, tgt, 0.0, angle)
-        ts.append(time.perf_counter() - t0)
-    t = sorted(ts)[len(ts) // 2]
-    torch.set_num_threads(1)
-    t0 = time.perf_counter()
-    R.convert(enc_sd, dec_sd, wf[:1], tgt, 0.0, angle[:1])
-    t1 = time.perf_counter() - t0
-    torch.set_num_threads(threads)
-    return {"value": batch * seconds * 16000 / t, "unit": "16kHz-samples/s", "cores": threads, "kind": "port",
-            "value_1thread": seconds * 16000 / t1,
-            "sample": f"{batch} of the 64 utterances ({seconds:g} s each, {n_index}-vector index): 1 warm-up + median of {reps} runs on "
-                      f"{threads} threads; 1-thread figure = one utterance, one run; oracle/ref_cpu.py on torch CPU ops "
-                      f"(BASELINE.md §3 plans 3 warm-ups / median of 10: shortened to keep the default run within minutes)"}
+        R.convert(enc_sd, dec_sd, wf[:b], tgt, 0.0, angle[:b])
+        return time.perf_counter() - t0
+
+    sweep = {}
+    for th in sorted({t for t in (1, 8, 16, 32, 64, all_threads) if t <= max(all_threads, 1)}):
+        torch.set_num_threads(th)
+        run(batch)
+        sweep[th] = batch * seconds * 16000 / run(batch)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    for _ in range(2):                         # (the sweep's two runs at this setting were the first warm-ups)
+        run(batch)
+    t = _median([run(batch) for _ in range(10)])
+    # the same utterances one at a time (B = 1 calls, what the reference's own loop does, infer.py:60-66): on this host the
+    # batched call is often the slower way to spend the cores, so `value` is the better of the two
+    for _ in range(3):
+        run(1)
+    t_seq = _median([run(1) for _ in range(10)])
+    v_batched, v_seq = batch * seconds * 16000 / t, seconds * 16000 / t_seq
+    # configs[0]: one utterance, 1 000-vector index (the reference's own CPU-runnable case)
+    tgt1 = synth.synth_index(1000, seed=2)
+
+    def run1():
+        t0 = time.perf_counter()
+        R.convert(enc_sd, dec_sd, wf[:1], tgt1, 0.0, angle[:1])
+        return time.perf_counter() - t0
+
+    for _ in range(3):
+        run1()
+    t_cfg1 = _median([run1() for _ in range(10)])
+    # configs[2] with one stream: the reference's StreamInfer loop (stream.py:68-96), 20 warm-up + 200 blocks
+    st = R.StreamState(block_size=1920, extra_size=3840)
+    blocks = synth.synth_wave(1, 220 * 1920, seed=200)[0].view(220, 1920)
+    ang = synth.synth_angle(1, st.input_size // 480, 7)
+    lat = []
+    for i in range(220):
+        t0 = time.perf_counter()
+        R.stream_callback(st, enc_sd, dec_sd, tgt1, 0.0, blocks[i], ang)
+        lat.append(time.perf_counter() - t0)
+    lat = sorted(lat[20:])
+    torch.set_num_threads(all_threads)
+    return {"value": max(v_batched, v_seq), "unit": "16kHz-samples/s", "cores": best, "kind": "port",
+            "value_batched_b8": v_batched, "value_one_at_a_time": v_seq,
+            "threads_best": best, "host_cpus": ncpu, "threads_sweep": {str(k): v for k, v in sweep.items()},
+            "value_1thread": sweep.get(1),
+            "cfg1_b1_ms": t_cfg1 * 1e3, "cfg1_b1_value": seconds * 16000 / t_cfg1,
+            "cfg3_one_stream": {"p50_ms": lat[len(lat) // 2] * 1e3, "p95_ms": lat[int(len(lat) * 0.95)] * 1e3, "blocks": len(lat), "budget_ms": 80.0},
+            "sample": f"{batch} of the 64 utterances ({seconds:g} s each, {n_index}-vector index): thread sweep (1 warm-up + 1 run per setting), then "
+                      f"3 warm-ups + median of 10 runs on the best setting = {best} threads of {ncpu} host CPUs (BASELINE.md §3), "
+                      f"batched (B = {batch}) and one utterance per call - value = the faster of the two; "
+                      f"cfg1_b1 = one 4 s utterance, 1000-vector index, 3 warm-ups + median of 10; cfg3_one_stream = one real-time stream, "
+                      f"200 blocks after 20 warm-ups; oracle/ref_cpu.py on torch CPU ops"}
+
+
+def gpu_side_configs(gen, dev, L):
+    """Two more configurations timed on the GPU after the headline region (N = 1 line only):
+    `cfg1_b1_ms` = BASELINE configs[0] as one call (one 4 s utterance, 1 000-vector index: latency of a B = 1 convert, median of 30),
+    `index100k_ms_per_step` = configs[3]'s per-rank workload (64 x 4 s against a 100 000-vector index, mean of 5 steps)."""
+    def timed(fn, n, warm):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        return ts
+    wf1 = synth.synth_wave(1, L, seed=1).to(dev)
+    tgt1 = synth.synth_index(1000, seed=2).to(dev)
+    t1 = timed(lambda: gen.convert(wf1, tgt1, 0.0), 30, 5)
+    wf = synth.synth_wave(64, L, seed=1000).to(dev)
+    tgt = synth.synth_index(100000, seed=5).to(dev)
+    t2 = timed(lambda: gen.convert(wf, tgt, 0.0), 5, 2)
+    return {"cfg1_b1_ms": _median(t1) * 1e3, "cfg1_b1_x_realtime": (L / SR) / _median(t1),
+            "index100k_ms_per_step": sum(t2) / len(t2) * 1e3, "index100k_value": 64 * (L / SR) * 16000 / (sum(t2) / len(t2))}
 
 
 def stream_latency(gen, dev, streams=32, blocks=120, warmup=20, n_index=1000):
@@ -268,6 +339,8 @@ def main():
             res["gather_bytes_per_rank"] = B * L * 4 if gather else 0
         if world == 1 and not args.no_stream:
             res["stream"] = stream_latency(gen, dev)
+            if B == 64 and n_index == 10000:
+                res.update(gpu_side_configs(gen, dev, L))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(L / SR, n_index)
         print(json.dumps(res), flush=True)

@@ -72,11 +72,14 @@ SOLA_LATENCY = 1920 + 3840 + 960     # cross-fade + last delay + half the search
 
 
 @torch.no_grad()
-def convert_chunked(gen, batch, tgt, pitch_shift, chunk_size, buffer_blocks, use_phase_vocoder=False):
+def convert_chunked(gen, batch, tgt, pitch_shift, chunk_size, buffer_blocks, use_phase_vocoder=False, noise_angles=None, return_blocks=False):
     """Block-wise conversion of `batch` [B, L] with bounded memory: every utterance is a stream of `chunk_size`-sample
     blocks through BatchedStreamInfer (rolling buffer with `buffer_blocks` blocks of extra context, full convert per
     block, SOLA alignment + cross-fade: reference module/infer/stream.py:68-96).  The streaming output lags its input by
-    ~SOLA_LATENCY samples; the lag is flushed with silence and trimmed so the result has the input's length."""
+    ~SOLA_LATENCY samples; the lag is flushed with silence and trimmed so the result has the input's length.
+    `noise_angles(i)` -> [B, 961, T] injects the decoder's noise phases of block i (parity runs against the oracle's
+    `stream_callback`; default: drawn on the device per block, as the reference's `torch.rand` is).
+    `return_blocks`: also return the untrimmed block outputs [B, nblk, chunk_size] and the SOLA lags [nblk, B]."""
     from tinyvc_amd.module.infer import BatchedStreamInfer
     B, L = batch.shape
     st = BatchedStreamInfer(gen, n_streams=B, target=tgt, pitch_shift=pitch_shift, device=batch.device, block_size=chunk_size,
@@ -85,8 +88,15 @@ def convert_chunked(gen, batch, tgt, pitch_shift, chunk_size, buffer_blocks, use
     nblk = -(-(L + SOLA_LATENCY) // chunk_size)
     padded = torch.zeros(B, nblk * chunk_size, device=batch.device)
     padded[:, :L] = batch
-    outs = [st.audio_callback(padded[:, i * chunk_size:(i + 1) * chunk_size]) for i in range(nblk)]
-    return torch.cat(outs, dim=1)[:, SOLA_LATENCY:SOLA_LATENCY + L]
+    outs, lags = [], []
+    for i in range(nblk):
+        outs.append(st.audio_callback(padded[:, i * chunk_size:(i + 1) * chunk_size], noise_angle=noise_angles(i) if noise_angles else None))
+        if return_blocks:
+            lags.append(st.last_shift.clone())
+    out = torch.cat(outs, dim=1)[:, SOLA_LATENCY:SOLA_LATENCY + L]
+    if return_blocks:
+        return out, torch.stack(outs, dim=1), torch.stack(lags, dim=0)
+    return out
 
 
 def main(argv=None):

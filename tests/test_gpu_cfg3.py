@@ -1,0 +1,153 @@
+"""BASELINE configs[3]'s per-rank workload on one GPU (64 utterances x 4 s against a 100 000-vector index), the two-stage
+kNN's exact fallback, and the chunked offline mode against the oracle's streaming loop."""
+import pytest
+import torch
+
+from helpers import rms, state_dicts
+from oracle import ref_cpu as R
+from tinyvc_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gen():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from tinyvc_amd.module.infer import Generator
+    from tinyvc_amd.module.tinyvc import Decoder, Encoder
+    enc_sd, dec_sd = state_dicts(0)
+    enc, dec = Encoder(), Decoder()
+    enc.load_state_dict(enc_sd)
+    dec.load_state_dict(dec_sd)
+    return Generator(enc, dec).to(DEV)
+
+
+def test_cfg3_rank_workload_100k_index(gen):
+    """What every rank of configs[3] computes: 64 x 4 s (seeds 1000..1063) against synth_index(100000, seed=5).
+    (a) kNN indices of a 200-query slice vs the oracle wherever fp32 can decide; (b) one utterance end to end vs the oracle
+    run live (north_star gate 1e-4); (c) the size-independent properties of the batch."""
+    from tinyvc_amd.module.tinyvc import match_features
+    enc_sd, dec_sd = state_dicts(0)
+    N = 100000
+    wf = synth.synth_wave(64, 96000, seed=1000)
+    tgt = synth.synth_index(N, seed=5)
+    angle = synth.synth_angle(64, 200, 5)
+    d_wf, d_tgt, d_angle = wf.to(DEV), tgt.to(DEV), angle.to(DEV)
+    # (b) utterance 0 through the oracle (its kNN alone is 200 x 100 000 x 768 on the host)
+    st = R.convert(enc_sd, dec_sd, wf[:1], tgt, 0.0, angle[:1], return_stages=True)
+    # (a) the GPU search on the oracle's own queries: indices equal wherever the fp64 top-5 gaps exceed 1e-5
+    _m, idx = match_features(st["ssl"].to(DEV), d_tgt, return_indices=True)
+    _o, o_idx, sims = R.match_features(st["ssl"], tgt, return_indices=True)
+    top = torch.topk(sims.double(), 5, dim=2).values
+    decidable = (top[..., :-1] - top[..., 1:]).min(dim=2).values > 1e-5
+    print(f"[cfg3] kNN 200 queries x {N}: {int(decidable.sum())} decidable at 1e-5")
+    assert decidable.float().mean() > 0.9
+    assert torch.equal(idx.cpu()[decidable], o_idx[decidable])
+    del sims, top
+    out = gen.convert(d_wf, d_tgt, 0.0, noise_angle=d_angle)
+    assert out.shape == (64, 96000) and torch.isfinite(out).all()
+    d = rms(out[0].cpu() - st["wave"][0])
+    print(f"[cfg3] utterance 0 of the batch vs the oracle (live, N = {N}): abs rms diff {d:.3e}")
+    assert d <= 1e-4
+    # (c) properties at size
+    again = gen.convert(d_wf, d_tgt, 0.0, noise_angle=d_angle)
+    assert torch.equal(out, again)
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    outp = gen.convert(d_wf[perm], d_tgt, 0.0, noise_angle=d_angle[perm])
+    assert torch.equal(outp, out[perm])
+    sub = gen.convert(d_wf[17:20], d_tgt, 0.0, noise_angle=d_angle[17:20])
+    assert torch.equal(sub, out[17:20])
+    q = d_tgt[:, :, 99000:99512].contiguous()
+    _m, idx = match_features(q, d_tgt, return_indices=True)
+    assert torch.equal(idx[0, :, 0].cpu(), torch.arange(99000, 99512))
+
+
+def _fallback_ms(eng, fn):
+    """Run fn() with the stage timers on; returns (result, ms spent in the exact kernel's region)."""
+    eng.profile(1)
+    eng.profile_read()
+    res = fn()
+    torch.cuda.synchronize()
+    prof = eng.profile_read()
+    eng.profile(0)
+    return res, prof
+
+
+def test_knn_exact_fallback_runs_when_a_candidate_list_overflows(gen):
+    """the two-stage search is exact only because a query with more than C_CAP (256) candidates makes the exact
+    kernel run inside the same call.  A 400-vector cluster around one query overflows its list; a zero query (every
+    similarity 0 = theta) overflows every list.  Both must return the oracle's rows, and the exact kernel must really have
+    run (its profile region takes time; with ordinary data it exits on the flag)."""
+    from tinyvc_amd.module.tinyvc import match_features
+    eng = gen.engine(DEV)
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(768, generator=g)
+    dense = torch.randn(1, 768, 6000, generator=g)
+    for j in range(400):
+        dense[0, :, 500 + 9 * j] = base + 1e-3 * (j + 1) * torch.randn(768, generator=g) / 27.7
+    qd = torch.stack([base, dense[0, :, 3], dense[0, :, 5999]], dim=1)[None]
+    d_dense, d_q = dense.to(DEV), qd.to(DEV)
+    match_features(d_q, d_dense, return_indices=True)          # prepares the index outside the timed call
+    (out, idx), prof = _fallback_ms(eng, lambda: match_features(d_q, d_dense, return_indices=True))
+    o_out, o_idx, sims = R.match_features(qd, dense, return_indices=True)
+    top = torch.topk(sims.double(), 5, dim=2).values
+    gaps = (top[..., :-1] - top[..., 1:]).min(dim=2).values
+    decidable = gaps > 2e-7
+    print(f"[knn] 400-vector cluster: top-5 gap of the cluster query {gaps[0, 0]:.2e}; regions {prof}")
+    assert bool(decidable[0, 1]) and bool(decidable[0, 2])
+    assert torch.equal(idx.cpu()[decidable], o_idx[decidable])
+    # the cluster query's four rows all come from the cluster
+    assert all(((int(i) - 500) % 9 == 0 and 500 <= int(i) < 500 + 9 * 400) for i in idx[0, 0].cpu())
+    ordinary = torch.randn(1, 768, 3, generator=g)
+    _r, prof0 = _fallback_ms(eng, lambda: match_features(ordinary.to(DEV), d_dense, return_indices=True))
+    print(f"[knn] exact-kernel region: overflow {prof.get('knn.exact', 0.0):.4f} ms, ordinary data {prof0.get('knn.exact', 0.0):.4f} ms")
+    assert prof["knn.exact"] > 3 * prof0["knn.exact"], "the exact fallback did not run on an overflowing candidate list"
+    # zero-norm query: all similarities are 0, every row passes theta -> overflow -> exact kernel -> rows 0..3 (ties go to the lower index)
+    qz = torch.zeros(1, 768, 2)
+    qz[0, :, 1] = dense[0, :, 77]
+    (_out, idxz), profz = _fallback_ms(eng, lambda: match_features(qz.to(DEV), d_dense, return_indices=True))
+    assert idxz[0, 0].cpu().tolist() == [0, 1, 2, 3]
+    assert int(idxz[0, 1, 0]) == 77
+    assert profz["knn.exact"] > 3 * prof0["knn.exact"]
+
+
+@pytest.mark.parametrize("use_pv", [False, True])
+def test_chunked_mode_matches_the_oracle_stream_loop(gen, use_pv):
+    """infer.py's --chunked path against oracle.ref_cpu.stream_callback (= reference stream.py:68-96) fed the
+    same blocks and the same noise phases: SOLA lags identical, every block within 1e-4; and the trimmed output is aligned
+    with the whole-file conversion."""
+    import infer
+    enc_sd, dec_sd = state_dicts(0)
+    chunk, buf = 1920, 4
+    L = 24000 * 2 + 333
+    wf = synth.synth_wave(1, L, seed=77)
+    tgt = synth.synth_index(300, seed=2)
+    ost = R.StreamState(block_size=chunk, extra_size=buf * chunk)
+    T = ost.input_size // 480
+    angles = lambda i: synth.synth_angle(1, T, 4000 + i)
+    out, blocks, lags = infer.convert_chunked(gen, wf.to(DEV), tgt.to(DEV), 1.0, chunk, buf, use_pv,
+                                              noise_angles=lambda i: angles(i).to(DEV), return_blocks=True)
+    nblk = blocks.shape[1]
+    padded = torch.zeros(nblk * chunk)
+    padded[:L] = wf[0]
+    worst = 0.0
+    for i in range(nblk):
+        o, shift = R.stream_callback(ost, enc_sd, dec_sd, tgt, 1.0, padded[i * chunk:(i + 1) * chunk], angles(i), use_phase_vocoder=use_pv)
+        assert int(lags[i, 0]) == shift, f"block {i}: SOLA lag {int(lags[i, 0])} != oracle {shift}"
+        worst = max(worst, rms(blocks[0, i].cpu() - o))
+    print(f"[f4] chunked ({'phase vocoder' if use_pv else 'sin^2'}) vs oracle stream loop: {nblk} blocks, lags identical, worst block rms diff {worst:.3e}")
+    assert worst <= 1e-4
+    # alignment with the whole-file result: the streaming output is the same signal delayed by SOLA_LATENCY +- the per-block lag
+    whole = gen.convert(wf.to(DEV), tgt.to(DEV), 1.0, noise_angle=synth.synth_angle(1, -(-L // 480), 9).to(DEV))[0, :L].cpu().double()
+    ch = out[0].cpu().double()
+    a, b = whole[4800:L - 4800], None
+    best, best_lag = -1.0, None
+    for lag in range(-1920, 1921, 8):
+        b = ch[4800 + lag:L - 4800 + lag]
+        c = float((a * b).sum() / (a.norm() * b.norm()))
+        if c > best:
+            best, best_lag = c, lag
+    print(f"[f4] trimmed chunked output vs whole-file conversion: correlation peak {best:.3f} at lag {best_lag} samples")
+    assert out.shape == (1, L)
+    assert abs(best_lag) <= 960 and best > 0.5
