@@ -22,6 +22,19 @@ def convert_inputs(g):
     return wf, tgt, float(g["pitch_shift"]), angle
 
 
+class oracle_one_thread:
+    """The oracle's waveform depends on the host's thread count (oneDNN / MKL reduction orders: 2e-4 rms between 1 and 128
+    threads at T = 200 on the GPU box's host).  Live comparisons run it on ONE thread - sequential
+    reductions, the reproducible setting (the committed fixtures came from the 8-thread build host)."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.n)
+
+
 _SD = {}
 
 

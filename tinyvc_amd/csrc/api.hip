@@ -54,19 +54,46 @@ struct Packer {
         }
         fix.push_back({slot, ab.put(t->data)});
     }
-    // Stack one or more conv weights [cout_i][cin][taps] along cout (host staging layout At[k][m], k = ci*taps + tap) and
-    // pack the bf16x3 split image + the bias row.
-    void conv(const std::vector<std::string>& names, PackedW* pw, int cin, int taps) {
+    // ---- two-part fp16 split of the packed weights (conv3s.h): w = (h1 + 2^-11 h2) * 2^e, e per 32-row m-tile -------------------
+    static uint16_t f16_bits(float f) {
+        const _Float16 h = (_Float16)f;          // round to nearest even, subnormals kept
+        uint16_t u;
+        std::memcpy(&u, &h, 2);
+        return u;
+    }
+    static float f16_value(uint16_t u) {
+        _Float16 h;
+        std::memcpy(&h, &u, 2);
+        return (float)h;
+    }
+    // the two parts of w / scale (scale = a power of two: the division is exact)
+    static void split2(float w, float scale, uint16_t* h1, uint16_t* h2) {
+        const float x = w / scale;
+        *h1 = f16_bits(x);
+        *h2 = f16_bits((x - f16_value(*h1)) * 2048.f);
+    }
+    // power of two that brings `amax` into [1, 2) (1 for an all-zero tile)
+    static float pow2_scale(float amax) {
+        if (!(amax > 0.f) || !std::isfinite(amax)) return 1.f;
+        int e;
+        std::frexp(amax, &e);                    // amax = m * 2^e, m in [0.5, 1)
+        return std::ldexp(1.f, e - 1);
+    }
+    std::map<const PackedW*, std::vector<float>> host_wscale;      // the scales chosen for every packed image (joint packing, fused-block blobs)
+
+    // Stack one or more conv weights [cout_i][cin][taps] along cout into the host staging layout At[k][m], k = ci*taps + tap
+    // (zero-padded to Kpad x Mpad) and the bias row [Mpad].
+    bool stage(const std::vector<std::string>& names, PackedW* pw, int cin, int taps, std::vector<float>* At, std::vector<float>* bias, int* group_rows) {
         int M = 0;
         std::vector<const HostTensor*> ws, bs;
         for (auto& n : names) {
             const HostTensor* w = find(n + ".weight");
             const HostTensor* b = find(n + ".bias");
-            if (!w || !b) return;
+            if (!w || !b) return false;
             if (w->shape.size() != 3 || w->shape[1] != cin || w->shape[2] != taps ||
                 (int64_t)b->data.size() != w->shape[0]) {
                 if (missing.empty()) missing = n + " (unexpected shape)";
-                return;
+                return false;
             }
             ws.push_back(w);
             bs.push_back(b);
@@ -78,73 +105,101 @@ struct Packer {
         pw->taps = taps;
         pw->Mpad = pad_m(M);
         pw->Kpad = (pw->K + 15) / 16 * 16;
-        std::vector<float> At((size_t)pw->Kpad * pw->Mpad, 0.f), bias(pw->Mpad, 0.f);
+        At->assign((size_t)pw->Kpad * pw->Mpad, 0.f);
+        bias->assign(pw->Mpad, 0.f);
         int m0 = 0;
         for (size_t i = 0; i < ws.size(); ++i) {
             int cout = (int)ws[i]->shape[0];
             for (int m = 0; m < cout; ++m) {
-                bias[m0 + m] = bs[i]->data[m];
-                for (int k = 0; k < pw->K; ++k) At[(size_t)k * pw->Mpad + m0 + m] = ws[i]->data[(size_t)m * pw->K + k];
+                (*bias)[m0 + m] = bs[i]->data[m];
+                for (int k = 0; k < pw->K; ++k) (*At)[(size_t)k * pw->Mpad + m0 + m] = ws[i]->data[(size_t)m * pw->K + k];
             }
             m0 += cout;
         }
-        // only the split image goes to the device: `At` is the host-side staging layout it is built from
-        fix.push_back({&pw->bias, ab.put(bias)});
         bool equal_groups = ws.size() > 1;
         for (auto* w : ws) equal_groups = equal_groups && w->shape[0] == ws[0]->shape[0];
-        a6(pw, At, equal_groups ? (int)ws[0]->shape[0] : 0);
+        *group_rows = equal_groups ? (int)ws[0]->shape[0] : 0;
+        return true;
     }
-    // bf16x3 split image of At for conv3s.h: [step = slab*taps + tap][m-tile][part][lane][8 bf16],
-    // lane -> row m = 32*mt + (lane & 31), channel ci = 16*slab + 8*(lane >> 5) + j.  x = p1 + p2 + p3 with
-    // round-to-nearest-even parts; both residuals are exact in fp32.
-    // group_rows > 0: the M rows are `M / group_rows` stacked groups (FiLM scale ; shift), each padded to whole 32-row tiles
-    void a6(PackedW* pw, const std::vector<float>& At, int group_rows = 0) {
-        auto to_bf16 = [](float f) -> uint16_t {
-            uint32_t u;
-            std::memcpy(&u, &f, 4);
-            u += 0x7FFFu + ((u >> 16) & 1u);
-            return (uint16_t)(u >> 16);
-        };
-        auto from_bf16 = [](uint16_t h) -> float {
-            uint32_t u = (uint32_t)h << 16;
-            float f;
-            std::memcpy(&f, &u, 4);
-            return f;
-        };
-        const int taps = pw->taps, cin = pw->cin, nslab = ((cin + 15) / 16 + 5) / 6 * 6;   // zero slabs up to a multiple of 6: any slab depth divides
+    // image geometry: group_rows > 0 = the M rows are `M / group_rows` stacked groups (FiLM scale ; shift), each padded to whole 32-row tiles
+    static int image_mt(const PackedW* pw, int group_rows) {
         const int gp = group_rows > 0 ? (group_rows + 31) / 32 * 32 : 0;
-        const int MT = group_rows > 0 ? (pw->M / group_rows) * gp / 32 : pw->Mpad / 32;
-        std::vector<float> img((size_t)nslab * taps * MT * 3 * 256, 0.f);
+        return group_rows > 0 ? (pw->M / group_rows) * gp / 32 : pw->Mpad / 32;
+    }
+    static int image_row(const PackedW* pw, int group_rows, int m) {      // staged row of image row m (pw->M = a padding row)
+        if (group_rows <= 0) return m < pw->M ? m : pw->M;
+        const int gp = (group_rows + 31) / 32 * 32, g = m / gp, mi = m - g * gp;
+        return mi < group_rows ? g * group_rows + mi : pw->M;
+    }
+    std::vector<float> mt_amax(const PackedW* pw, const std::vector<float>& At, int group_rows) {
+        const int MT = image_mt(pw, group_rows);
+        std::vector<float> amax(MT, 0.f);
+        for (int mt = 0; mt < MT; ++mt)
+            for (int r = 0; r < 32; ++r) {
+                const int m = image_row(pw, group_rows, mt * 32 + r);
+                if (m >= pw->M) continue;
+                for (int k = 0; k < pw->K; ++k) amax[mt] = std::max(amax[mt], std::fabs(At[(size_t)k * pw->Mpad + m]));
+            }
+        return amax;
+    }
+    void conv(const std::vector<std::string>& names, PackedW* pw, int cin, int taps) {
+        std::vector<float> At, bias;
+        int group_rows = 0;
+        if (!stage(names, pw, cin, taps, &At, &bias, &group_rows)) return;
+        // only the split image goes to the device: `At` is the host-side staging layout it is built from
+        fix.push_back({&pw->bias, ab.put(bias)});
+        std::vector<float> sc = mt_amax(pw, At, group_rows);
+        for (auto& v : sc) v = pow2_scale(v);
+        a6(pw, At, group_rows, sc);
+    }
+    // two convs whose results are accumulated into ONE tile (Downsample: c3(h2) + down_res(xi)): the same per-m-tile scales for both
+    void conv_joint(const std::string& na, PackedW* pa, int cin_a, int taps_a, const std::string& nb, PackedW* pb, int cin_b, int taps_b) {
+        std::vector<float> Aa, ba, Ab, bb;
+        int ga = 0, gb = 0;
+        if (!stage({na}, pa, cin_a, taps_a, &Aa, &ba, &ga) || !stage({nb}, pb, cin_b, taps_b, &Ab, &bb, &gb)) return;
+        if (pa->Mpad != pb->Mpad) {
+            if (missing.empty()) missing = na + " / " + nb + " (row counts differ)";
+            return;
+        }
+        fix.push_back({&pa->bias, ab.put(ba)});
+        fix.push_back({&pb->bias, ab.put(bb)});
+        std::vector<float> sa = mt_amax(pa, Aa, 0), sb = mt_amax(pb, Ab, 0);
+        for (size_t i = 0; i < sa.size(); ++i) sa[i] = pow2_scale(std::max(sa[i], sb[i]));
+        const size_t off_a = a6(pa, Aa, 0, sa);
+        a6(pb, Ab, 0, sa);
+        fix.push_back({&pb->wjoint, off_a});      // resolves to pa->A6: the launch checks that the pair was packed together
+    }
+    // two-part fp16 image of At for conv3s.h: [step = slab*taps + tap][m-tile][part][lane][8 fp16],
+    // lane -> row m = 32*mt + (lane & 31), channel ci = 16*slab + 8*(lane >> 5) + j.  Returns the image's arena offset.
+    size_t a6(PackedW* pw, const std::vector<float>& At, int group_rows, const std::vector<float>& scale) {
+        const int taps = pw->taps, cin = pw->cin, nslab = ((cin + 15) / 16 + 5) / 6 * 6;   // zero slabs up to a multiple of 6: any slab depth divides
+        const int MT = image_mt(pw, group_rows);
+        std::vector<float> img((size_t)nslab * taps * MT * 2 * 256, 0.f);
         uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
         for (int s = 0; s < nslab; ++s)
             for (int tap = 0; tap < taps; ++tap)
                 for (int mt = 0; mt < MT; ++mt)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 8; ++j) {
-                            int ci = s * 16 + 8 * (lane >> 5) + j, m = mt * 32 + (lane & 31);
-                            if (group_rows > 0) {
-                                const int g = m / gp, mi = m - g * gp;
-                                m = mi < group_rows ? g * group_rows + mi : pw->M;   // padding row
-                            }
-                            float w = (ci < cin && m < pw->M) ? At[(size_t)(ci * taps + tap) * pw->Mpad + m] : 0.f;
-                            uint16_t h1 = to_bf16(w);
-                            float r = w - from_bf16(h1);
-                            uint16_t h2 = to_bf16(r);
-                            float r2 = r - from_bf16(h2);
-                            uint16_t h3 = to_bf16(r2);
-                            size_t base = (((size_t)(s * taps + tap) * MT + mt) * 3 * 64 + lane) * 8 + j;
-                            o[base] = h1;
-                            o[base + 512] = h2;
-                            o[base + 1024] = h3;
+                            const int ci = s * 16 + 8 * (lane >> 5) + j, m = image_row(pw, group_rows, mt * 32 + (lane & 31));
+                            const float w = (ci < cin && m < pw->M) ? At[(size_t)(ci * taps + tap) * pw->Mpad + m] : 0.f;
+                            const size_t base = (((size_t)(s * taps + tap) * MT + mt) * 2 * 64 + lane) * 8 + j;
+                            split2(w, scale[mt], &o[base], &o[base + 512]);
                         }
         pw->MT6 = MT;
         pw->S6 = nslab;
-        fix.push_back({&pw->A6, ab.put(img)});
+        const size_t off = ab.put(img);
+        fix.push_back({&pw->A6, off});
+        fix.push_back({&pw->wscale, ab.put(scale)});
+        host_wscale[pw] = scale;
+        return off;
     }
-    // Weight blob of one half of the split-precision fused ups.4 kernel (filter_up24s.hip): 42 pieces of 1 KiB in
-    // v_mfma_f32_32x32x16_bf16 A-lane order (row m = lane & 31, k = 8 * (lane >> 5) + j), bf16 x 3 parts each:
-    //   [conv a: 5 steps][3 parts] [conv b: 5 steps][3 parts] [FiLM: 2 steps][to_scale, to_shift][3 parts]
-    // followed by 304 floats: biases a, b, scale, shift (32 each), the folded output taps [24][7] and their bias.
+    // Weight blob of one half of the fused ups.4 kernel (filter_up24s.hip): 28 pieces of 1 KiB in
+    // v_mfma_f32_32x32x16_f16 A-lane order (row m = lane & 31, k = 8 * (lane >> 5) + j), two fp16 parts each:
+    //   [conv a: 5 steps][2 parts] [conv b: 5 steps][2 parts] [FiLM: 2 steps][to_scale, to_shift][2 parts]
+    // followed by 304 floats: biases a, b, scale, shift (32 each), the folded output taps [24][7] and their bias [296], then
+    // [297..300] the power-of-two scales of conv a, conv b, to_scale, to_shift, [301] max_m sum_k |w_a[m][k]| and [302] max |b_a|
+    // (the bound of the block's on-chip intermediate, see the kernel).
     // K runs in units of (tap, 8-channel group): unit u = 2 * step + (lane >> 5), tap = u / 3, group = u % 3 (a 24-channel
     // conv has 9 units, the 10th is zero; FiLM's 1x1 has 3).
     // Second half: Upsample.c5 (1x1, decoder.py:171,189) and FilterNet.output_layer (k7, decoder.py:220,233) have nothing
@@ -167,30 +222,17 @@ struct Packer {
             if (missing.empty()) missing = ca + " (unexpected shape for the 24-channel block)";
             return;
         }
-        std::vector<float> img(42 * 256 + 304, 0.f);
+        std::vector<float> img(28 * 256 + 304, 0.f);
         uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
-        auto to_bf16 = [](float f) -> uint16_t {
-            uint32_t u;
-            std::memcpy(&u, &f, 4);
-            u += 0x7FFFu + ((u >> 16) & 1u);
-            return (uint16_t)(u >> 16);
+        auto amax_of = [](const HostTensor* t) {
+            float a = 0.f;
+            for (float v : t->data) a = std::max(a, std::fabs(v));
+            return a;
         };
-        auto from_bf16 = [](uint16_t h) -> float {
-            uint32_t u = (uint32_t)h << 16;
-            float f;
-            std::memcpy(&f, &u, 4);
-            return f;
-        };
-        auto put3 = [&](int piece0, int lane, int j, float w) {   // parts of one value into pieces piece0, +1, +2
-            uint16_t h1 = to_bf16(w);
-            float r = w - from_bf16(h1);
-            uint16_t h2 = to_bf16(r);
-            float r2 = r - from_bf16(h2);
-            uint16_t h3 = to_bf16(r2);
-            size_t base = ((size_t)piece0 * 64 + lane) * 8 + j;
-            o[base] = h1;
-            o[base + 512] = h2;
-            o[base + 1024] = h3;
+        const float sa = pow2_scale(amax_of(wa)), sb = pow2_scale(amax_of(wb)), ssc = pow2_scale(amax_of(wsc)), ssh = pow2_scale(amax_of(wsh));
+        auto put2 = [&](int piece0, int lane, int j, float w, float scale) {   // parts of one value into pieces piece0, +1
+            const size_t base = ((size_t)piece0 * 64 + lane) * 8 + j;
+            split2(w, scale, &o[base], &o[base + 512]);
         };
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
@@ -198,23 +240,35 @@ struct Packer {
                 for (int s = 0; s < 5; ++s) {
                     const int u = 2 * s + lh, tap = u / 3, ci = 8 * (u % 3) + j;
                     const bool real = u < 9 && m < C;
-                    put3(s * 3, lane, j, real ? wa->data[((size_t)m * C + ci) * 3 + tap] : 0.f);
-                    put3(15 + s * 3, lane, j, real ? wb->data[((size_t)m * C + ci) * 3 + tap] : 0.f);
+                    put2(s * 2, lane, j, real ? wa->data[((size_t)m * C + ci) * 3 + tap] : 0.f, sa);
+                    put2(10 + s * 2, lane, j, real ? wb->data[((size_t)m * C + ci) * 3 + tap] : 0.f, sb);
                 }
                 for (int s = 0; s < 2; ++s) {
                     const int u = 2 * s + lh, ci = 8 * u + j;
                     const bool real = u < 3 && m < C;
-                    put3(30 + (s * 2 + 0) * 3, lane, j, real ? wsc->data[(size_t)m * C + ci] : 0.f);
-                    put3(30 + (s * 2 + 1) * 3, lane, j, real ? wsh->data[(size_t)m * C + ci] : 0.f);
+                    put2(20 + (s * 2 + 0) * 2, lane, j, real ? wsc->data[(size_t)m * C + ci] : 0.f, ssc);
+                    put2(20 + (s * 2 + 1) * 2, lane, j, real ? wsh->data[(size_t)m * C + ci] : 0.f, ssh);
                 }
             }
-        float* fl = img.data() + 42 * 256;
+        float* fl = img.data() + 28 * 256;
+        double l1max = 0.0;
+        float bamax = 0.f;
         for (int m = 0; m < C; ++m) {
             fl[m] = ba->data[m];
             fl[32 + m] = bb->data[m];
             fl[64 + m] = bsc->data[m];
             fl[96 + m] = bsh->data[m];
+            double l1 = 0.0;
+            for (int k = 0; k < C * 3; ++k) l1 += std::fabs((double)wa->data[(size_t)m * C * 3 + k]);
+            l1max = std::max(l1max, l1);
+            bamax = std::max(bamax, std::fabs(ba->data[m]));
         }
+        fl[297] = sa;
+        fl[298] = sb;
+        fl[299] = ssc;
+        fl[300] = ssh;
+        fl[301] = (float)(l1max * 1.0000002);      // rounded up: it is a bound
+        fl[302] = bamax;
         if (!c5.empty()) {
             const HostTensor* w5 = find(c5 + ".weight");
             const HostTensor* b5 = find(c5 + ".bias");
@@ -238,8 +292,8 @@ struct Packer {
         }
         fix.push_back({slot, ab.put(img)});
     }
-    // Weight blob of the split-precision downs.0 kernel (filter_up24s.hip): the 17 -> 24 k3 conv in the same 15-piece layout
-    // as a 24-channel conv (input rows 17..23 zero), then 32 bias floats.
+    // Weight blob of the downs.0 kernel (filter_up24s.hip): the 17 -> 24 k3 conv in the same 10-piece layout
+    // as a 24-channel conv (input rows 17..23 zero), then 32 floats: bias [24], [31] = the image's power-of-two scale.
     void down0s(const float** slot, const std::string& name) {
         const HostTensor* w = find(name + ".weight");
         const HostTensor* b = find(name + ".bias");
@@ -249,41 +303,28 @@ struct Packer {
             if (missing.empty()) missing = name + " (unexpected shape for the split-precision downs.0 blob)";
             return;
         }
-        std::vector<float> img(15 * 256 + 32, 0.f);
+        std::vector<float> img(10 * 256 + 32, 0.f);
         uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
-        auto to_bf16 = [](float f) -> uint16_t {
-            uint32_t u;
-            std::memcpy(&u, &f, 4);
-            u += 0x7FFFu + ((u >> 16) & 1u);
-            return (uint16_t)(u >> 16);
-        };
-        auto from_bf16 = [](uint16_t h) -> float {
-            uint32_t u = (uint32_t)h << 16;
-            float f;
-            std::memcpy(&f, &u, 4);
-            return f;
-        };
+        float amax = 0.f;
+        for (float v : w->data) amax = std::max(amax, std::fabs(v));
+        const float sc = pow2_scale(amax);
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j)
                 for (int s = 0; s < 5; ++s) {
                     const int m = lane & 31, u = 2 * s + (lane >> 5), tap = u / 3, ci = 8 * (u % 3) + j;
                     const float v = (u < 9 && m < C && ci < CI) ? w->data[((size_t)m * CI + ci) * 3 + tap] : 0.f;
-                    uint16_t h1 = to_bf16(v);
-                    float r = v - from_bf16(h1);
-                    uint16_t h2 = to_bf16(r);
-                    float r2 = r - from_bf16(h2);
-                    uint16_t h3 = to_bf16(r2);
-                    size_t base = ((size_t)(s * 3) * 64 + lane) * 8 + j;
-                    o[base] = h1;
-                    o[base + 512] = h2;
-                    o[base + 1024] = h3;
+                    const size_t base = ((size_t)(s * 2) * 64 + lane) * 8 + j;
+                    split2(v, sc, &o[base], &o[base + 512]);
                 }
-        for (int m = 0; m < C; ++m) img[15 * 256 + m] = b->data[m];
+        for (int m = 0; m < C; ++m) img[10 * 256 + m] = b->data[m];
+        img[10 * 256 + 31] = sc;
         fix.push_back({slot, ab.put(img)});
     }
     // Weight blob of one 24-input-channel k3 conv for conv24s_kernel (filter_up24s.hip): pieces [step][m-tile][part]
-    // (same (tap, group) K order as up24s_half), then 64 bias floats.  M = 24 (one m-tile) or 48 (two).
-    void conv24s(const float** slot, const std::string& name, int M, const std::string& extra_bias = "") {
+    // (same (tap, group) K order as up24s_half), then 64 floats: bias [M <= 48], [62], [63] = the power-of-two scales of the (at
+    // most two) m-tiles.  M = 24 (one m-tile) or 48 (two).  `joint`: take the scales of this already packed image instead of the
+    // weight's own (c3 of the 24-channel Downsample block is accumulated with down_res into one tile: conv_joint).
+    void conv24s(const float** slot, const std::string& name, int M, const std::string& extra_bias = "", const PackedW* joint = nullptr) {
         const HostTensor* w = find(name + ".weight");
         const HostTensor* b = find(name + ".bias");
         const HostTensor* eb = extra_bias.empty() ? nullptr : find(extra_bias);
@@ -297,37 +338,35 @@ struct Packer {
             if (missing.empty()) missing = name + " (unexpected shape for the 24-channel split-precision blob)";
             return;
         }
-        std::vector<float> img((size_t)15 * MT * 256 + 64, 0.f);
+        std::vector<float> img((size_t)10 * MT * 256 + 64, 0.f);
         uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
-        auto to_bf16 = [](float f) -> uint16_t {
-            uint32_t u;
-            std::memcpy(&u, &f, 4);
-            u += 0x7FFFu + ((u >> 16) & 1u);
-            return (uint16_t)(u >> 16);
-        };
-        auto from_bf16 = [](uint16_t h) -> float {
-            uint32_t u = (uint32_t)h << 16;
-            float f;
-            std::memcpy(&f, &u, 4);
-            return f;
-        };
+        std::vector<float> sc(MT, 1.f);
+        if (joint) {
+            auto it = host_wscale.find(joint);
+            if (it == host_wscale.end() || (int)it->second.size() != MT) {
+                if (missing.empty()) missing = name + " (its joint image is not packed yet)";
+                return;
+            }
+            sc = it->second;
+        } else {
+            for (int mt = 0; mt < MT; ++mt) {
+                float amax = 0.f;
+                for (int m = 32 * mt; m < std::min(M, 32 * mt + 32); ++m)
+                    for (int k = 0; k < CI * 3; ++k) amax = std::max(amax, std::fabs(w->data[(size_t)m * CI * 3 + k]));
+                sc[mt] = pow2_scale(amax);
+            }
+        }
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j)
                 for (int s = 0; s < 5; ++s)
                     for (int mt = 0; mt < MT; ++mt) {
                         const int m = 32 * mt + (lane & 31), u = 2 * s + (lane >> 5), tap = u / 3, ci = 8 * (u % 3) + j;
                         const float v = (u < 9 && m < M) ? w->data[((size_t)m * CI + ci) * 3 + tap] : 0.f;
-                        uint16_t h1 = to_bf16(v);
-                        float r = v - from_bf16(h1);
-                        uint16_t h2 = to_bf16(r);
-                        float r2 = r - from_bf16(h2);
-                        uint16_t h3 = to_bf16(r2);
-                        size_t base = ((size_t)((s * MT + mt) * 3) * 64 + lane) * 8 + j;
-                        o[base] = h1;
-                        o[base + 512] = h2;
-                        o[base + 1024] = h3;
+                        const size_t base = ((size_t)((s * MT + mt) * 2) * 64 + lane) * 8 + j;
+                        split2(v, sc[mt], &o[base], &o[base + 512]);
                     }
-        for (int m = 0; m < M; ++m) img[(size_t)15 * MT * 256 + m] = b->data[m] + (eb ? eb->data[m] : 0.f);
+        for (int m = 0; m < M; ++m) img[(size_t)10 * MT * 256 + m] = b->data[m] + (eb ? eb->data[m] : 0.f);
+        for (int mt = 0; mt < MT; ++mt) img[(size_t)10 * MT * 256 + 62 + mt] = sc[mt];
         fix.push_back({slot, ab.put(img)});
     }
     void convnext(const std::string& p, ConvNeXtW* w, int C, int dil) {
@@ -337,6 +376,14 @@ struct Packer {
         raw(p + ".c1.bias", &w->dw_b, C);
         raw(p + ".norm.gamma", &w->ln_g, C);
         raw(p + ".norm.beta", &w->ln_b, C);
+        {   // |LayerNorm output| <= sqrt(C - 1) max|gamma| + max|beta| whatever the data (a normalised column has |x_hat| <= sqrt(C - 1))
+            const HostTensor* g = find(p + ".norm.gamma");
+            const HostTensor* bt = find(p + ".norm.beta");
+            float gm = 0.f, bm = 0.f;
+            if (g) for (float v : g->data) gm = std::max(gm, std::fabs(v));
+            if (bt) for (float v : bt->data) bm = std::max(bm, std::fabs(v));
+            w->ln_bound = std::sqrt((float)C) * gm + bm;
+        }
         conv({p + ".c2"}, &w->c2, C, 1);
         raw(p + ".grn.gamma", &w->grn_g, 2 * C);
         raw(p + ".grn.beta", &w->grn_b, 2 * C);
@@ -495,7 +542,6 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
     pk.conv({"filter_net.content_in"}, &ctx->flt_content_in, kSslDim, 1);
     pk.raw("filter_net.f0_in.weight", &ctx->flt_f_w, ch[0]);
     pk.raw("filter_net.f0_in.bias", &ctx->flt_f_b, ch[0]);
-    pk.conv({"filter_net.downs.0"}, &ctx->flt_down0, kHarm + 2, 3);
     pk.down0s(&ctx->flt_down0s, "filter_net.downs.0");
     for (int i = 1; i <= 4; ++i) {
         DownW& d = ctx->downs[i - 1];
@@ -503,10 +549,9 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
         d.cout = ch[4 - i];
         d.factor = fac[5 - i];
         std::string p = "filter_net.downs." + std::to_string(i);
-        pk.conv({p + ".down_res"}, &d.res, d.cin, 1);
         pk.conv({p + ".c1"}, &d.c1, d.cin, 3);
         pk.conv({p + ".c2"}, &d.c2, d.cin, 3);
-        pk.conv({p + ".c3"}, &d.c3, d.cin, 3);
+        pk.conv_joint(p + ".c3", &d.c3, d.cin, 3, p + ".down_res", &d.res, d.cin, 1);      // c3(h2) + down_res(xi) land in one tile: joint scales
         {   // c3.bias + down_res.bias for the launches that accumulate both convs into one tile
             const HostTensor* b3 = pk.find(p + ".c3.bias");
             const HostTensor* br = pk.find(p + ".down_res.bias");
@@ -519,8 +564,7 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
         if (d.cin == 24 && d.cout == 48) {
             pk.conv24s(&d.s24c1, p + ".c1", 24);
             pk.conv24s(&d.s24c2, p + ".c2", 24);
-            pk.conv24s(&d.s24c3, p + ".c3", 48);
-            pk.conv24s(&d.s24c3r, p + ".c3", 48, p + ".down_res.bias");
+            pk.conv24s(&d.s24c3r, p + ".c3", 48, p + ".down_res.bias", &d.c3);
         }
     }
     for (int i = 0; i < 5; ++i) {
@@ -536,18 +580,11 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
         pk.conv({p + ".c5"}, &u.c5, u.cin, 1);
         pk.conv({p + ".film1.to_scale", p + ".film1.to_shift"}, &u.film1, u.cin, 1);
         pk.conv({p + ".film2.to_scale", p + ".film2.to_shift"}, &u.film2, u.cin, 1);
-        pk.conv({p + ".film1.to_scale"}, &u.sc1, u.cin, 1);
-        pk.conv({p + ".film1.to_shift"}, &u.sh1, u.cin, 1);
-        pk.conv({p + ".film2.to_scale"}, &u.sc2, u.cin, 1);
-        pk.conv({p + ".film2.to_shift"}, &u.sh2, u.cin, 1);
         if (u.cin == 24) {
             pk.up24s_half(&u.s24a, p + ".c1", p + ".c2", p + ".film1", "", "");
             pk.up24s_half(&u.s24b, p + ".c3", p + ".c4", p + ".film2", p + ".c5", "filter_net.output_layer");
         }
     }
-    pk.conv({"filter_net.output_layer"}, &ctx->flt_out, ch[4], 7);
-    pk.raw("filter_net.output_layer.weight", &ctx->flt_out_w, (size_t)ch[4] * 7);
-    pk.raw("filter_net.output_layer.bias", &ctx->flt_out_b, 1);
 
     const std::string missing_dec = pk.missing;
     snprintf(ctx->enc_missing, sizeof(ctx->enc_missing), "%s", missing_enc.c_str());

@@ -1,21 +1,34 @@
-// Conv1d (k = 1 or 3, dilated, replicate padding) as an implicit GEMM on the bf16 matrix pipe with
-// fp32-equivalent accuracy: every fp32 operand is split into three bf16 parts (x = x1 + x2 + x3, each
-// residual exact in fp32) and the product is accumulated in fp32 from the six part-products of order
-// <= 2^-16 (x1 w1, x1 w2, x2 w1, x1 w3, x2 w2, x3 w1; the dropped ones are <= 2^-24 relative).
-// v_mfma_f32_32x32x16_bf16 runs 16x the fp32 MFMA rate, so six of them cost 3/8 of the fp32 tile.
+// Conv1d (k = 1 or 3, dilated, replicate padding) as an implicit GEMM on the fp16 matrix pipe with
+// fp32-equivalent accuracy.  Every fp32 operand is split into TWO fp16 parts, x = h1 + 2^-11 h2 with
+// h1 = fp16(x), h2 = fp16((x - h1) * 2^11) (the residual is exact in fp32; the 2^11 keeps it out of fp16's subnormal range),
+// 22 significand bits in all, and a product is accumulated in fp32 from THREE part-products: h1 w1 into one accumulator,
+// h1 w2 + h2 w1 (the 2^-11-order terms, in units of 2^-11) into a second one; out = acc_hi + 2^-11 acc_lo.  The dropped
+// h2 w2 term is <= 2^-24 relative.  Measured against fp64 on the part (tools/micro/f16split.hip, K = 768): 1.9e-7 rel rms,
+// vs 4.9e-7 for the fp32 MFMA and 4.2e-7 for the bf16 x 3 / six-product split this replaces (which spent twice the
+// matrix-pipe cycles, 1.5x the LDS bytes and 1.5x the split arithmetic).  v_mfma_f32_32x32x16_f16 keeps fp16 subnormals
+// (measured), so the absolute error floor of an operand is 2^-36 of its scale unit.
+//
+// Range guard (block floating point).  fp16 tops out at 65504, so every operand travels with a power-of-two scale:
+//   weights      normalised per 32-row m-tile at pack time (largest |w| of the tile in [1, 2)), the exponent comes back
+//                in the epilogue (PackedW::wscale);
+//   activations  every tensor that is read as a B operand has a per-utterance |max| slot, written by the kernel that
+//                produces it (running max of the values it stores, one atomicMax per wave when it grows); the consuming
+//                kernel multiplies by 2^-e while staging and by 2^e in its epilogue, e = floor(log2 amax), whenever amax
+//                is outside [2^-10, 2^15) - inside that window e = 0 and nothing is scaled.  Intermediates that never leave
+//                the CU (fused blocks) use the bound sum|w| * amax_in + max|b| instead of a measured maximum.
 // FilterNet Downsample/Upsample convs (decoder.py:143-146, 166-171) and their FiLM (decoder.py:94-97).
 //
 // Layout.  K is walked in slabs of 16 input channels; a K16 step is (slab, tap).
-//   weights   pre-split on the host (api.hip Packer::a6): image [step][m-tile][part][lane][8 bf16], one
+//   weights   pre-split on the host (api.hip Packer::a6): image [step][m-tile][part][lane][8 fp16], one
 //             1 KiB piece per (step, m-tile, part) already in MFMA lane order (row = lane & 31,
 //             k = 8 * (lane >> 5) + j); a piece is one 16-byte load + one ds_write_b128 per lane.
 //   input     the slab's halo tile is staged once: each thread loads 8 channels of one sample (coalesced
-//             along time), applies the pre-activation, splits, and writes three 16-byte rows
-//             Xs[part][channel-group][position][8 bf16]; a tap is a row offset, so every ds_read_b128 of
+//             along time), applies the pre-activation, splits, and writes two 16-byte rows
+//             Xs[part][channel-group][position][8 fp16]; a tap is a row offset, so every ds_read_b128 of
 //             the MFMA loop is a contiguous 1 KiB wave access.
 //   tile      a wave owns all MTB m-tiles of the workgroup for one 32-sample n-tile.
 // Pipeline.  Persistent workgroups: conv launches run ONE 12-wave workgroup per CU (3 m-tiles x 4 column groups, 96 x 128
-// or 96 x 256 output tile, ~100 KB of LDS, dominated by the parked output tile), GEMM launches two 8-wave workgroups per
+// or 96 x 256 output tile, LDS dominated by the parked output tile), GEMM launches two 8-wave workgroups per
 // CU at a 128-register budget.  Per slab: barrier, registers -> LDS (weights copied, activations split), request the next
 // slab (its loads fly across this slab's MFMAs; the first slab of the next phase / tile is requested behind the last
 // one), barrier, MFMAs.  Barriers are raw s_barrier + lgkmcnt(0): __syncthreads() also drains vmcnt, i.e. it would wait
@@ -29,53 +42,27 @@
 
 namespace tvc {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register-friendly 16-byte value (HIP's uint4 struct defeats SROA in arrays)
 
-#ifndef S_WPE
-#define S_WPE 3     // waves per SIMD the register budget is sized for (plain / FiLM-fused kernels): 12-wave workgroups, no spills
-#endif
-#ifndef S_WPE_G
-#define S_WPE_G 4     // 8-wave (GEMM) workgroups: two per CU need <= 128 registers
-#endif
-#ifndef S_WPE_F
-#define S_WPE_F 3
-#endif
-#ifndef TVC_S_CKG
-#define TVC_S_CKG 1     // 2: two channel groups per slab for the plain conv launches with Cin % 32 == 0 (measured: no gain)
-#endif
-#ifndef TVC_S_MTB2
-#define TVC_S_MTB2 0
-#endif
-#ifndef TVC_S_KG
-#define TVC_S_KG 2     // deepest K slab (in 16-channel groups) the GEMM launches may use (3 spills at the 128-register budget: slower)
-#endif
-#ifndef TVC_S_FLAT
-#define TVC_S_FLAT 1   // GEMM launches tile the flattened B * T column axis instead of every utterance separately
-#endif
-#ifndef S_XCD_MAP
-#define S_XCD_MAP 1   // row blocks of one column tile walk on the same XCD (shared L2)
-#endif
-#ifndef S_BPC
-#define S_BPC 1     // persistent workgroups per CU
-#endif
-#ifndef S_FB
-#define S_FB 2   // fragment register sets: 2 = next tap's LDS reads under this tap's MFMAs, 1 = read, then multiply
-#endif
-#ifndef S_FB_G
-#define S_FB_G 1   // 8-wave (GEMM) workgroups: single fragment set (128-register budget)
-#endif
-#ifndef S_FB_F
-#define S_FB_F 1   // FiLM-fused kernels: two accumulator sets live, single fragment set keeps the slab loops spill-free
-#endif
-#ifndef S_FB_FW
-#define S_FB_FW 2   // conv phase of the wide FiLM tile
-#endif
-#ifndef S_PF
-#define S_PF 2   // residual rows requested at a time by the lerp epilogue
-#endif
+constexpr int kParts = 2;                 // fp16 parts per fp32 operand
+constexpr int kPU4 = kParts * 64;         // uint4 per (K16 step, m-tile) of a weight image
+constexpr float kLoScale = 2048.f;        // h2 = fp16((x - h1) * 2^11)
+constexpr float kLoInv = 1.f / 2048.f;
+
+// schedule constants (each was swept on the part; the losing settings are described in DESIGN.md section 4)
+constexpr int S_WPE = 3;      // waves per SIMD the register budget is sized for (plain / FiLM-fused kernels): 12-wave workgroups, no spills
+constexpr int S_WPE_G = 4;    // 8-wave (GEMM) workgroups: two per CU need <= 128 registers
+constexpr int S_WPE_F = 3;
+constexpr int TVC_S_KG = 2;   // deepest K slab (in 16-channel groups) the GEMM launches use
+constexpr int S_BPC = 1;      // persistent workgroups per CU
+constexpr int S_FB = 2;       // fragment register sets: 2 = next tap's LDS reads under this tap's MFMAs, 1 = read, then multiply
+constexpr int S_FB_G = 1;     // 8-wave (GEMM) workgroups: single fragment set (128-register budget)
+constexpr int S_FB_F = 1;     // FiLM-fused kernels: more accumulator sets live, single fragment set keeps the slab loops spill-free
+constexpr int S_FB_FW = 2;    // conv phase of the wide FiLM tile
+constexpr int S_PF = 2;       // residual rows requested at a time by the lerp epilogue
 
 
 // epilogues that ask for a second, 1x1 phase over another tensor accumulated into the SAME tile (Downsample: c3(h2) + down_res(xi))
@@ -94,16 +81,16 @@ struct SplitTile {
     static_assert(MTB % WM == 0, "wave rows must tile the workgroup");
     static constexpr int BM = MTB * 32, BN = NWV * WN * 32;
     static constexpr int MAXD = MAXD_, XROW = BN + 2 * MAXD;                    // largest dilation the halo tile must hold (0 for plain GEMMs)
-    static constexpr int XG_U4 = 3 * 2 * XROW;                                  // one channel group: [part][8-channel half][position]
+    static constexpr int XG_U4 = kParts * 2 * XROW;                             // one channel group: [part][8-channel half][position]
     static constexpr int X_U4 = KG * XG_U4;
     static constexpr int X_PER = (KG * 2 * XROW + NTHR - 1) / NTHR;             // staging items per thread
-    static constexpr int a_u4(int taps) { return taps * KG * MTB * 3 * 64; }
+    static constexpr int a_u4(int taps) { return taps * KG * MTB * kPU4; }
     static constexpr int stage_u4(int taps) { return a_u4(taps) + X_U4; }
     static constexpr int KS_MAX = 2 * 768;                                      // SCALED launch: factors of <= 768 input channels for the <= 2 utterances a tile touches
     static constexpr int OS = BN + 4;                                           // row stride (floats) of the output tile parked in LDS
     static constexpr int lds_bytes(int taps) {
         const int stage = stage_u4(taps) * 16, out = BM * OS * 4;
-        return (stage > out ? stage : out) + 2 * 3 * BM * 4 + KS_MAX * 4;  // + bias / FiLM-bias rows of this workgroup (two tiles' worth) + input-channel factors
+        return (stage > out ? stage : out) + 2 * 6 * BM * 4 + KS_MAX * 4 + 64;  // + per-row tables of this workgroup (bias, FiLM biases, weight scales; two tiles' worth) + input-channel factors + the |max| exchange
     }
     static constexpr int bias_off(int taps) {                  // float offset of that area
         const int stage = stage_u4(taps) * 16, out = BM * OS * 4;
@@ -113,6 +100,7 @@ struct SplitTile {
 
 struct ConvSArgs {
     const uint4* A6;     // split weight image
+    const float* wsc;    // its per-m-tile power-of-two scales (PackedW::wscale): out = acc * wsc[m-tile]
     int MT;              // m-tiles in the image
     const float* x;      // [B][Cin][len], utterance b at x + b * xstride
     long xstride;
@@ -123,10 +111,62 @@ struct ConvSArgs {
     int flatT = 0;       // > 0: flat GEMM tiles over the B * flatT columns (len = B * flatT, B = 1 for the tile walk)
     const float* kscale = nullptr;   // optional per-(utterance, input channel) factor applied while staging (SCALED kernels), [B][Cin]
     const uint4* sc6 = nullptr;   // stacked FiLM [to_scale ; to_shift] image (1x1 over cond), FILM kernels only
-    const uint4* sh6 = nullptr;
+    const float* fsc = nullptr;   // per-m-tile scales of sc6 (the residual 1x1's image shares A6's scales: packed jointly)
     const float* cond = nullptr;
     int Ccond = 0;
+    // block-floating-point guard of the fp16 split: per-utterance |max| slots [B] of x / cond (read; nullptr = no scaling) and of
+    // the output tensor (written; nullptr = nobody reads it as a B operand)
+    const float* amax_x = nullptr;
+    const float* amax_c = nullptr;
+    float* amax_y = nullptr;
 };
+
+// power-of-two input scale from a tensor's per-utterance |max|: identity while amax is inside [2^-10, 2^15), else 2^-floor(log2 amax)
+struct Bfp {
+    float s, inv;
+};
+__device__ __forceinline__ Bfp bfp_from_amax(float amax) {
+    const unsigned u = __builtin_bit_cast(unsigned, amax);
+    int e = (int)(u >> 23) - 127;
+    Bfp r{1.f, 1.f};
+    if (u != 0u && u < 0x7f800000u && (e >= 15 || e < -10)) {     // zero, Inf and NaN carry no information: no scaling
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        r.s = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);
+        r.inv = __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
+    }
+    return r;
+}
+__device__ __forceinline__ Bfp bfp_load(const float* amax, int b) { return amax ? bfp_from_amax(amax[b]) : Bfp{1.f, 1.f}; }
+// the smaller of two scales (two tensors accumulated into one tile share it)
+__device__ __forceinline__ Bfp bfp_min(const Bfp& a, const Bfp& b) { return a.s < b.s ? a : b; }
+// Publishing a |max| slot.  Same-address device-scope atomics complete at ~3 per microsecond on this part (measured: one
+// atomicMax per wave and tile - 200 k per launch on 64 slots - added 1 ms to a 0.3 ms kernel), so they are kept to a handful per
+// slot and launch: persistent kernels walk CONTIGUOUS tile ranges (a workgroup meets one or two utterances), every wave keeps a
+// running maximum in a register, and when the workgroup moves on to another utterance (and at its end) the waves' maxima meet in
+// LDS and ONE thread issues ONE atomic, fire-and-forget (reading the slot first to skip it made the wave wait for that load and,
+// with it, for the next tile's prefetch).  Non-negative floats order like their bit patterns; NaNs never enter a maximum (fmaxf).
+__device__ __forceinline__ float wave_max(float mx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    return mx;
+}
+// every thread of the workgroup calls it (it contains a barrier); red = LDS scratch of >= (workgroup waves) floats
+__device__ __forceinline__ void amax_flush_wg(float* slot, float mx, float* red) {
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));
+    }
+    // (red is rewritten at this workgroup's next flush, at least one tile - several barriers - later)
+}
+// contiguous tile range of persistent workgroup w of g: [first, last)
+__device__ __forceinline__ void tile_range(int ntiles, int& first, int& last) {
+    first = (int)((long)ntiles * blockIdx.x / gridDim.x);
+    last = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);
+}
 
 // Global accesses as uniform base (SGPR pair) + 32-bit byte offset per lane (the global_load saddr form): the row bases are
 // pinned into SGPRs through an empty asm, otherwise the compiler re-associates base + row stride into chains of 64-bit
@@ -150,25 +190,26 @@ __device__ __forceinline__ u32x4 ldg_so4(const uint4* base, unsigned byte_off) {
     return *reinterpret_cast<gcu4>(reinterpret_cast<const __attribute__((address_space(1))) char*>(p) + byte_off);
 }
 
-// three bf16 parts of 8 fp32 values, packed for one 16-byte LDS row each
-__device__ __forceinline__ void split8(const float (&v)[8], uint4& p1, uint4& p2, uint4& p3) {
-    unsigned o1[4], o2[4], o3[4];
+
+// two fp16 parts of 8 fp32 values (v = h1 + 2^-11 h2), packed for one 16-byte LDS row each
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& p1, uint4& p2) {
+    unsigned o1[4], o2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x2 a = {v[2 * j], v[2 * j + 1]};
-        bf16x2 h1 = __builtin_convertvector(a, bf16x2);
-        f32x2 r = a - __builtin_convertvector(h1, f32x2);
-        bf16x2 h2 = __builtin_convertvector(r, bf16x2);
-        f32x2 r2 = r - __builtin_convertvector(h2, f32x2);
-        bf16x2 h3 = __builtin_convertvector(r2, bf16x2);
+        f16x2v h1 = __builtin_convertvector(a, f16x2v);
+        f32x2 r = (a - __builtin_convertvector(h1, f32x2)) * kLoScale;
+        f16x2v h2 = __builtin_convertvector(r, f16x2v);
         o1[j] = __builtin_bit_cast(unsigned, h1);
         o2[j] = __builtin_bit_cast(unsigned, h2);
-        o3[j] = __builtin_bit_cast(unsigned, h3);
     }
     p1 = make_uint4(o1[0], o1[1], o1[2], o1[3]);
     p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
-    p3 = make_uint4(o3[0], o3[1], o3[2], o3[3]);
 }
+// acc_hi += w1 x1;  acc_lo += w2 x1 + w1 x2   (one K16 step of one 32 x 32 tile)
+#define TVC_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+// out = acc_hi * c + acc_lo * (c / 2048)
+__device__ __forceinline__ float comb(float hi, float lo, float c, float clo) { return fmaf(lo, clo, hi * c); }
 
 // workgroup barrier that drains this wave's LDS traffic but not its global loads
 __device__ __forceinline__ void slab_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -200,7 +241,7 @@ static __device__ unsigned g_trace_slot;
 // Staging registers of one thread (one slab in flight) and its share of the halo tile.
 template <class TL>
 struct SlabRegs {
-    static constexpr int A_MAX = (3 * TL::KG * TL::MTB * 3 + TL::NW - 1) / TL::NW;   // up to 3 taps x KG channel groups of weight pieces
+    static constexpr int A_MAX = (3 * TL::KG * TL::MTB * kParts + TL::NW - 1) / TL::NW;   // up to 3 taps x KG channel groups of weight pieces
     u32x4 ar[A_MAX];
     float xr[TL::X_PER][8];
     float xr2[TL::X_PER][8];   // LERP staging: the second interpolation tap
@@ -217,12 +258,13 @@ struct SlabMap {
     int xk[TL::X_PER];         // flat GEMM tiles: factor-row offset of the item's utterance inside the staged Ks
     unsigned xo1[TL::X_PER];   // LERP staging: offset of the second tap; w0 / w1 = the two weights (xo = first tap)
     float w0[TL::X_PER], w1[TL::X_PER];
+    float xs[TL::X_PER];       // block-floating-point scale of the item's utterance (1 unless its |max| is outside the fp16 window)
 };
 // fT > 0 = flat GEMM tiles: the tile's columns are positions n = b * fT + t of the flattened [B * fT] axis (len = B * fT),
 // utterance b starts at element b * fstride, channels are fT apart; a tile may straddle utterances.
 template <class TL, bool LERP = false>
 __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t0, int fT = 0, unsigned fstride = 0, int kcin = 0, int lin = 0,
-                                         float lscale = 0.f) {
+                                         float lscale = 0.f, float xs = 1.f, const float* amax = nullptr) {
     const int xw = TL::BN + 2 * dil;
 #pragma unroll
     for (int i = 0; i < TL::X_PER; ++i) {
@@ -235,10 +277,12 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
         const int ks = gk >> 1, g = gk & 1;
         m.xdst[i] = live ? ks * TL::XG_U4 + g * TL::XROW + c : -1;
         m.xg8[i] = ks * 16 + 8 * g;
+        m.xs[i] = xs;
         if (fT > 0) {
             const int b = p / fT, t = p - b * fT;
             m.xo[i] = (unsigned)b * fstride + (unsigned)(m.xg8[i] * fT + t);
             m.xk[i] = (b - t0 / fT) * kcin;
+            m.xs[i] = bfp_load(amax, b).s;                   // flat tiles straddle utterances: the scale is the column's
         } else if (LERP) {
             // the conv input at position p (already clamped = replicate padding of the interpolated signal) is
             // w0 * x[i0] + w1 * x[i1] of the low-rate row (ATen linear, align_corners = False: small_kernels.h)
@@ -260,18 +304,18 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
                                           const float* __restrict__ xb, int Cin, int len, int s, int fT = 0, int cmax = 0, int lin = 0) {
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER, STEPS = TAPS * TL::KG;
     const int cs = LERP ? lin : (fT > 0 ? fT : len);     // channel stride
-    constexpr int PIECES = STEPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
+    constexpr int PIECES = STEPS * MTB * kParts, A_PER = (PIECES + NW - 1) / NW;
     static_assert(A_PER <= SlabRegs<TL>::A_MAX, "weight pieces must fit the staging registers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ci0 = s * 16 * TL::KG;
     {
-        const uint4* a_src = A6 + (long)mt0 * 192;
+        const uint4* a_src = A6 + (long)mt0 * kPU4;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int q = wave + i * NW;
             q = q < PIECES ? q : PIECES - 1;
-            const int tap = q / (MTB * 3), rem = q - tap * (MTB * 3);
-            r.ar[i] = ldg_so4(a_src + (long)s * STEPS * MT * 192, 16u * (unsigned)(tap * MT * 192 + rem * 64 + lane));   // uniform slab base + this wave's piece
+            const int tap = q / (MTB * kParts), rem = q - tap * (MTB * kParts);
+            r.ar[i] = ldg_so4(a_src + (long)s * STEPS * MT * kPU4, 16u * (unsigned)(tap * MT * kPU4 + rem * 64 + lane));   // uniform slab base + this wave's piece
         }
     }
     const float* xc = xb + (long)ci0 * cs;               // uniform base, 32-bit lane offsets
@@ -312,24 +356,26 @@ __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restr
     slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT, cmax, lin);
 }
 
-// acc += W (.) x over all slabs of one input tensor.  Slab 0 is already in flight in `r` (first_load); `next()`
-// is called in its place behind the last slab, so the following phase or tile starts without a cold load.
+// (hi, lo) += W (.) x over all slabs of one input tensor (hi: the h1 w1 products, lo: h1 w2 + h2 w1 in units of 2^-11).
+// Slab 0 is already in flight in `r` (first_load); `next()` is called in its place behind the last slab, so the following
+// phase or tile starts without a cold load.  xs = the tile's block-floating-point input scale (flat GEMM tiles: per column,
+// from `amax`), applied while staging; the caller's epilogue multiplies by its inverse.
 struct NoMid { __device__ __forceinline__ void operator()() const {} };
 // TWO: the same input tile is multiplied with two row blocks of the image one after the other (mt0, then mt0b) in ONE slab loop -
-// FiLM's scale and shift on wide tiles, `mid()` is called between the two (it folds the first result away and clears `acc`)
+// FiLM's scale and shift on wide tiles, `mid()` is called between the two (it folds the first result away and clears the accumulators)
 template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false, bool LERP = false, bool CLAMP = false, bool TWO = false, class Next, class Mid = NoMid>
-__device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
-                                            const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next,
+__device__ __forceinline__ void split_phase(f32x16 (&hi)[TL::WM][TL::WN], f32x16 (&lo)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
+                                            const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next, float xs,
                                             const float* Ks = nullptr, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0, float lscale = 0.f,
-                                            int mt0b = 0, Mid mid = Mid()) {
+                                            int mt0b = 0, Mid mid = Mid(), const float* amax = nullptr) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NWV, wn = wave - wm * NWV;
     SlabMap<TL> m;
-    make_map<TL, LERP>(m, len, dil, t0, fT, fstride, Cin, lin, lscale);
+    make_map<TL, LERP>(m, len, dil, t0, fT, fstride, Cin, lin, lscale, xs, amax);
     constexpr int STEPS = TAPS * TL::KG;               // K16 steps per slab: (channel group, tap)
-    constexpr int PIECES = STEPS * MTB * 3, A_PER = (PIECES + NW - 1) / NW;
+    constexpr int PIECES = STEPS * MTB * kParts, A_PER = (PIECES + NW - 1) / NW;
     auto lstore = [&](int sl) __attribute__((always_inline)) {
         uint4* Asb = As;
         uint4* Xsb = Xs;
@@ -355,17 +401,18 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
                     r.xr[i][0] *= k0.x; r.xr[i][1] *= k0.y; r.xr[i][2] *= k0.z; r.xr[i][3] *= k0.w;
                     r.xr[i][4] *= k1.x; r.xr[i][5] *= k1.y; r.xr[i][6] *= k1.z; r.xr[i][7] *= k1.w;
                 }
-                uint4 p1, p2, p3;
-                split8(r.xr[i], p1, p2, p3);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r.xr[i][j] *= m.xs[i];                                     // power of two: exact
+                uint4 p1, p2;
+                split8(r.xr[i], p1, p2);
                 Xsb[m.xdst[i]] = p1;
                 Xsb[2 * XROW + m.xdst[i]] = p2;
-                Xsb[4 * XROW + m.xdst[i]] = p3;
             }
     };
 
     const int nslab1 = Cin / (16 * TL::KG);
     const int nslab = TWO ? 2 * nslab1 : nslab1;
-    const uint4* as0 = As + wm * WM * 192 + lane;
+    const uint4* as0 = As + wm * WM * kPU4 + lane;
     const uint4* xs0 = Xs + lh * XROW + wn * WN * 32 + l31;
     for (int s = 0; s < nslab; ++s) {
         TR_STAMP(r, 0);
@@ -382,19 +429,19 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
         slab_barrier();
         TR_STAMP(r, 4);
         const uint4* as = as0;
-        const uint4* xs = xs0;
+        const uint4* xs_ = xs0;
         // fragments of tap t+1 are read while the MFMAs of tap t run
-        bf16x8 af[2][WM][3], bf[2][WN][3];
+        f16x8 af[2][WM][kParts], bf[2][WN][kParts];
         auto frags = [&](int tap, int fb) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    bf[fb][j][p] = __builtin_bit_cast(bf16x8, xs[(tap / TAPS) * TL::XG_U4 + 2 * p * XROW + j * 32 + (tap % TAPS) * dil]);
+                for (int p = 0; p < kParts; ++p)
+                    bf[fb][j][p] = __builtin_bit_cast(f16x8, xs_[(tap / TAPS) * TL::XG_U4 + 2 * p * XROW + j * 32 + (tap % TAPS) * dil]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) af[fb][i][p] = __builtin_bit_cast(bf16x8, as[(tap * MTB * 3 + i * 3 + p) * 64]);
+                for (int p = 0; p < kParts; ++p) af[fb][i][p] = __builtin_bit_cast(f16x8, as[(tap * MTB * kParts + i * kParts + p) * 64]);
         };
         if (FB == 2) frags(0, 0);
 #pragma unroll
@@ -406,15 +453,19 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
             } else {
                 frags(tap, 0);
             }
-            // part-products from the smallest order up; independent accumulators interleaved
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+            // three part-products per tile, the two accumulators of a tile alternate (independent MFMAs back to back)
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
+                for (int j = 0; j < WN; ++j) lo[i][j] = TVC_MFMA16(af[fb][i][1], bf[fb][j][0], lo[i][j]);
 #pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][i][PA[q]], bf[fb][j][PB[q]], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) hi[i][j] = TVC_MFMA16(af[fb][i][0], bf[fb][j][0], hi[i][j]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) lo[i][j] = TVC_MFMA16(af[fb][i][0], bf[fb][j][1], lo[i][j]);
             if (FB == 2) __builtin_amdgcn_sched_barrier(0);
         }
         TR_STAMP(r, 5);
@@ -423,12 +474,12 @@ __device__ __forceinline__ void split_phase(f32x16 (&acc)[TL::WM][TL::WN], SlabR
 
 // FiLM scale and shift in ONE 1x1 phase over the cond tile: the stacked [to_scale ; to_shift] weight image supplies two
 // m-tile groups (rows mt0.. and mtoff + mt0..) that share every staged input slab and every B fragment, so the cond
-// tile is loaded, split and written once instead of twice and a slab carries 12 MFMAs per wave instead of 6.
+// tile is loaded, split and written once instead of twice and a slab carries 6 MFMAs per wave instead of 3.
 template <class TL>
 __device__ __forceinline__ void film_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ F6, int MT, int mt0, int mtoff,
                                           const float* __restrict__ xb, int len, int s) {
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER;
-    constexpr int KG = TL::KG, GP = 2 * MTB * 3, PIECES = KG * GP, A_PER = (PIECES + NW - 1) / NW;   // per 16-channel group: scale and shift pieces of MTB m-tiles
+    constexpr int KG = TL::KG, GP = 2 * MTB * kParts, PIECES = KG * GP, A_PER = (PIECES + NW - 1) / NW;   // per 16-channel group: scale and shift pieces of MTB m-tiles
     static_assert(A_PER <= SlabRegs<TL>::A_MAX, "FiLM weight pieces must fit the staging registers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -436,8 +487,8 @@ __device__ __forceinline__ void film_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
         int q = wave + i * NW;
         q = q < PIECES ? q : PIECES - 1;
         const int kg = q / GP, q2 = q - kg * GP;
-        const int grp = q2 / (MTB * 3), rem = q2 - grp * (MTB * 3);
-        r.ar[i] = ldg_so4(F6 + ((long)s * KG * MT + mt0) * 192, 16u * (unsigned)((kg * MT + grp * mtoff) * 192 + rem * 64 + lane));
+        const int grp = q2 / (MTB * kParts), rem = q2 - grp * (MTB * kParts);
+        r.ar[i] = ldg_so4(F6 + ((long)s * KG * MT + mt0) * kPU4, 16u * (unsigned)((kg * MT + grp * mtoff) * kPU4 + rem * 64 + lane));
     }
     const float* xc = xb + (long)s * 16 * KG * len;
 #pragma unroll
@@ -452,19 +503,20 @@ __device__ __forceinline__ void film_first_load(SlabRegs<TL>& r, const uint4* __
     make_map<TL>(m, len, 0, t0);
     film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, 0);
 }
+// (sc, sh) accumulator pairs: [0] = hi, [1] = lo
 template <class TL, class Next>
-__device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16 (&ash)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ F6,
+__device__ __forceinline__ void film_phase(f32x16 (&asc)[2][TL::WM][TL::WN], f32x16 (&ash)[2][TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ F6,
                                            int MT, int mt0, int mtoff, const float* __restrict__ xb, int Cin, int len, int t0, uint4* As, uint4* Xs,
-                                           Next next) {
+                                           Next next, float xs) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
-    constexpr int KG = TL::KG, GP = 2 * MTB * 3, PIECES = KG * GP, A_PER = (PIECES + NW - 1) / NW;
+    constexpr int KG = TL::KG, GP = 2 * MTB * kParts, PIECES = KG * GP, A_PER = (PIECES + NW - 1) / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NWV, wn = wave - wm * NWV;
     SlabMap<TL> m;
     make_map<TL>(m, len, 0, t0);
     const int nslab = Cin / (16 * KG);
-    const uint4* as0 = As + wm * WM * 192 + lane;
+    const uint4* as0 = As + wm * WM * kPU4 + lane;
     const uint4* xs0 = Xs + lh * XROW + wn * WN * 32 + l31;
     auto lstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -475,11 +527,12 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
 #pragma unroll
         for (int i = 0; i < X_PER; ++i)
             if (m.xdst[i] >= 0) {
-                uint4 p1, p2, p3;
-                split8(r.xr[i], p1, p2, p3);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r.xr[i][j] *= xs;
+                uint4 p1, p2;
+                split8(r.xr[i], p1, p2);
                 Xs[m.xdst[i]] = p1;
                 Xs[2 * XROW + m.xdst[i]] = p2;
-                Xs[4 * XROW + m.xdst[i]] = p3;
             }
     };
     for (int s = 0; s < nslab; ++s) {
@@ -489,32 +542,32 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
         else next();
         slab_barrier();
         const uint4* as = as0;
-        const uint4* xs = xs0;
+        const uint4* xq = xs0;
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
-            bf16x8 fc[WM][3], fh[WM][3], bf[WN][3];
+            f16x8 fc[WM][kParts], fh[WM][kParts], bf[WN][kParts];
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bf[j][p] = __builtin_bit_cast(bf16x8, xs[kg * TL::XG_U4 + 2 * p * XROW + j * 32]);
+                for (int p = 0; p < kParts; ++p) bf[j][p] = __builtin_bit_cast(f16x8, xq[kg * TL::XG_U4 + 2 * p * XROW + j * 32]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    fc[i][p] = __builtin_bit_cast(bf16x8, as[(kg * GP + i * 3 + p) * 64]);
-                    fh[i][p] = __builtin_bit_cast(bf16x8, as[(kg * GP + MTB * 3 + i * 3 + p) * 64]);
+                for (int p = 0; p < kParts; ++p) {
+                    fc[i][p] = __builtin_bit_cast(f16x8, as[(kg * GP + i * kParts + p) * 64]);
+                    fh[i][p] = __builtin_bit_cast(f16x8, as[(kg * GP + MTB * kParts + i * kParts + p) * 64]);
                 }
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                    {
-                        asc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[i][PA[q]], bf[j][PB[q]], asc[i][j], 0, 0, 0);
-                        ash[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i][PA[q]], bf[j][PB[q]], ash[i][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < WN; ++j) {
+                    asc[1][i][j] = TVC_MFMA16(fc[i][1], bf[j][0], asc[1][i][j]);
+                    ash[1][i][j] = TVC_MFMA16(fh[i][1], bf[j][0], ash[1][i][j]);
+                    asc[0][i][j] = TVC_MFMA16(fc[i][0], bf[j][0], asc[0][i][j]);
+                    ash[0][i][j] = TVC_MFMA16(fh[i][0], bf[j][0], ash[0][i][j]);
+                    asc[1][i][j] = TVC_MFMA16(fc[i][0], bf[j][1], asc[1][i][j]);
+                    ash[1][i][j] = TVC_MFMA16(fh[i][0], bf[j][1], ash[1][i][j]);
+                }
         }
     }
 }
@@ -522,9 +575,11 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
 // Output tile -> HBM through LDS: the accumulator layout gives a lane one sample of 16 different rows (4-byte
 // stores, 128 B per row and instruction); parked as Ot[row][sample] the tile leaves as 16-byte stores (and the
 // residual arrives as 16-byte loads) along time.  v already holds everything but the residual.
+// mx: the wave's running |max| of the values it stores (the decimated copy y2 is a subset / two-sample mean of them), published
+// by the kernel when the workgroup leaves the utterance.
 template <class TL, bool RES>
 __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][TL::WN], float* __restrict__ y, const float* __restrict__ res,
-                                           int b, int M, int len, int mt0, int t0, float* __restrict__ y2 = nullptr, int f2 = 0, int rlin = 0, float rscale = 0.f) {
+                                           int b, int M, int len, int mt0, int t0, float& mx, float* __restrict__ y2 = nullptr, int f2 = 0, int rlin = 0, float rscale = 0.f) {
     constexpr int WM = TL::WM, WN = TL::WN, BM = TL::BM, BN = TL::BN, OS = TL::OS, NTHR = TL::NTHR;
     // The thread index is laundered through an empty asm: everything below depends on it only, so the compiler would hoist
     // all of the store pass's index math (64-bit offsets included) out of the persistent tile loop and keep ~25 registers
@@ -593,7 +648,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
             __builtin_amdgcn_sched_barrier(0);     // the requests stay below the FiLM combine: hoisted above it they overlap the three live accumulator sets
             request(0);
             park();
-            if (!live) return;
+            if (live) {
 #pragma unroll
             for (int k0 = 0; k0 < NR; k0 += PF) {
                 float w[PF][4];
@@ -611,12 +666,17 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
                     const int off = row * len + c;
                     if (full) {
                         *reinterpret_cast<float4*>(yb + off) = make_float4(e[0], e[1], e[2], e[3]);
+                        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(e[0]), fabsf(e[1]))), fmaxf(fabsf(e[2]), fabsf(e[3])));
                     } else {
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (t0 + c + u < len) yb[off + u] = e[u];
+                            if (t0 + c + u < len) {
+                                yb[off + u] = e[u];
+                                mx = fmaxf(mx, fabsf(e[u]));
+                            }
                     }
                 }
+            }
             }
             return;
         }
@@ -640,6 +700,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
                 float4 w = *reinterpret_cast<const float4*>(Ot + row * OS + c);
                 w.x += q[k].x; w.y += q[k].y; w.z += q[k].z; w.w += q[k].w;
                 *reinterpret_cast<float4*>(yb + row * len + c) = w;
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
                 if (y2b) {
                     const float e[4] = {w.x, w.y, w.z, w.w};
                     if (f2 == 4) {
@@ -674,10 +735,14 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
             }
             if (vec && t0 + c + 3 < len) {
                 *reinterpret_cast<float4*>(yb + off) = make_float4(w[0], w[1], w[2], w[3]);
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
             } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (t0 + c + u < len) yb[off + u] = w[u];
+                    if (t0 + c + u < len) {
+                        yb[off + u] = w[u];
+                        mx = fmaxf(mx, fabsf(w[u]));
+                    }
             }
         } else if (vec && t0 + c + 3 < len) {
             float4 w = o;
@@ -686,6 +751,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
                 w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w;
             }
             *reinterpret_cast<float4*>(yb + off) = w;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
             if (y2b) {
                 const float e[4] = {w.x, w.y, w.z, w.w};
                 if (f2 == 4) {
@@ -705,6 +771,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
                 if (t0 + c + u < len) {
                     const float ov = RES ? e[u] + rb[off + u] : e[u];
                     yb[off + u] = ov;
+                    mx = fmaxf(mx, fabsf(ov));
                     if (y2b && f2 != 4) {
                         const int t = t0 + c + u, q = t / f2;
                         if (t - q * f2 == (f2 >> 1)) y2b[row * len2 + q] = ov;
@@ -728,36 +795,20 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     const int len = a.len;
     const int ntiles = a.ntiles;
 
-    // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the first slab of every phase - including the
+    // persistent: a workgroup walks a CONTIGUOUS range of tiles; the first slab of every phase - including the
     // first phase of the NEXT tile - is loaded behind the last slab of the one before it, so only the very first
-    // load of a workgroup is cold and the output stores of a tile overlap the next tile's input loads
-    // Tile walk order.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8) and the persistent grid is a
-    // multiple of 8, so virtual tile v always runs on XCD v % 8.  All `mblocks` row blocks of one column tile re-read the
-    // same input tile: give them the same v % 8, i.e. the same L2 (the XCD L2s do not share), instead of spreading them
-    // over mblocks different ones:  v = ((nt / 8) * mblocks + mb) * 8 + nt % 8.
-    const int ncoltiles = ntiles / mblocks;
-    const int vtiles = S_XCD_MAP ? (ncoltiles + 7) / 8 * 8 * mblocks : ntiles;
-    auto coords = [&](int v, int& mt0, int& b, int& t0) __attribute__((always_inline)) -> bool {
-        int mb, nt_id;
-        if (S_XCD_MAP) {
-            const int r = v & 7, u = v >> 3;
-            mb = u % mblocks;
-            nt_id = (u / mblocks) * 8 + r;
-        } else {
-            mb = v % mblocks;
-            nt_id = v / mblocks;
-        }
+    // load of a workgroup is cold and the output stores of a tile overlap the next tile's input loads.
+    // Tile order: column tiles in utterance order, the `mblocks` row blocks of one column tile next to each other - they re-read
+    // the same input tile, now from the same workgroup's L2 a few microseconds apart - and a workgroup meets one or two
+    // utterances (the |max| slot of the output is published once per utterance and workgroup, see amax_flush_wg).
+    auto coords = [&](int v, int& mt0, int& b, int& t0) __attribute__((always_inline)) {
+        const int nt_id = v / mblocks, mb = v - nt_id * mblocks;
         mt0 = mb * MTB;
         b = nt_id / a.tiles_per_utt;
         t0 = (nt_id - b * a.tiles_per_utt) * TL::BN;
-        return nt_id < ncoltiles;
     };
-    const int stride = gridDim.x;
-    auto next_valid = [&](int v) __attribute__((always_inline)) -> int {   // first valid virtual tile at or after v on this workgroup's walk
-        int m_, b_, t_;
-        while (v < vtiles && !coords(v, m_, b_, t_)) v += stride;
-        return v;
-    };
+    int tile, vtiles;
+    tile_range(ntiles, tile, vtiles);
     SlabRegs<TL> regs;
 #ifdef S_TRACE
     __shared__ unsigned long long tr_lds[256];
@@ -767,14 +818,24 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_mem), "=s"(t0_real)::"memory");
     }
 #endif
-    int tile = next_valid(blockIdx.x), mt0 = 0, b = 0, t0 = 0;
+    int mt0 = 0, b = 0, t0 = 0;
     if (tile >= vtiles) return;
     coords(tile, mt0, b, t0);
+    float mx_run = 0.f;                  // this wave's |max| of what it stored for utterance mx_b
+    int mx_b = b;
+    float* const red = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS) + 12 * TL::BM + TL::KS_MAX;
     const int fT = a.flatT;
     const unsigned fstride = (unsigned)a.xstride;
     first_load<TL, TAPS, LERP, CLAMP>(regs, a.A6, a.MT, mt0, fT ? a.x : a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0, fT, fstride, a.cmax, a.lin, a.lscale);
     for (int tile_no = 0; tile < vtiles; ++tile_no) {
-        const int nxt = next_valid(tile + stride);
+        const int nxt = tile + 1;
+        if constexpr (!Epi::kIgemm) {
+            if (a.amax_y && b != mx_b) {          // the workgroup moves on to another utterance (uniform)
+                amax_flush_wg(a.amax_y + mx_b, mx_run, red);
+                mx_run = 0.f;
+                mx_b = b;
+            }
+        }
         auto load_next_tile = [&]() __attribute__((always_inline)) {
             if (nxt < vtiles) {
                 int mt0n, bn, t0n;
@@ -787,19 +848,22 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         // this tile's bias rows -> LDS: read back with ds_read (lgkmcnt), so the epilogue math never waits on vmcnt
         // while the next phase's prefetch is in flight (a global bias load would drag that whole prefetch with it)
         // (two copies by tile parity: without the LDS park no barrier separates a fast wave's next tile from a slow wave's epilogue)
-        float* Bs = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS) + (tile_no & 1) * 3 * TL::BM;
+        float* Bs = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS) + (tile_no & 1) * 6 * TL::BM;
         if constexpr (!Epi::kIgemm) {
             for (int i = threadIdx.x; i < TL::BM; i += TL::NTHR) {
                 int m = mt0 * 32 + i;
                 m = m < ep.M ? m : ep.M - 1;
                 Bs[i] = ep.bias[m];
+                Bs[3 * TL::BM + i] = a.wsc[mt0 + (i >> 5)];               // the weight image's power-of-two scale of this row's m-tile
                 if constexpr (FILM) {
                     Bs[TL::BM + i] = ep.bsc[m];
                     Bs[2 * TL::BM + i] = ep.bsh[m];
+                    Bs[4 * TL::BM + i] = a.fsc[mt0 + (i >> 5)];
+                    Bs[5 * TL::BM + i] = a.fsc[a.MT + mt0 + (i >> 5)];
                 }
             }
         }
-        float* Ks = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS) + 6 * TL::BM;
+        float* Ks = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS) + 12 * TL::BM;
         if constexpr (SCALED) {
             // first use is behind the first slab's barrier; the previous tile's last use is behind its last one
             const int b0 = fT ? t0 / fT : b;                      // flat tiles: the (at most two) utterances this tile touches
@@ -807,34 +871,50 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             for (int i = threadIdx.x; i < nrow; i += TL::NTHR) Ks[i] = a.kscale[(long)b0 * a.Cin + i];
         }
         const int rl = wm * WM * 32 + 4 * lh;                     // local row of accumulator register r of m-tile i: rl + 32 i + (r & 3) + 8 (r >> 2)
-        f32x16 acc[WM][WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-        if constexpr (FILM && TL::WN > 1) {
-            // Wide tiles (two n-tiles per wave): three accumulator sets do not fit the register budget, so scale and shift are the two
-            // halves of ONE slab loop over the cond tile (split_phase<TWO>) sharing one extra set: out = ((h + b)(sc + b_sc)) + (sh + b_sh)
-            // in the same order as below, (h + b)(sc + b_sc) replaces h between the halves.  The cond tile is staged twice; in exchange
-            // the conv phase (3/5 of the MFMAs) runs on the 96 x 256 tile of the plain convs.
-            const float* cb = a.cond + (long)b * a.Ccond * len;
-            const int mtoff = a.MT;
-            split_phase<TL, TAPS, A_U4, LRELU, S_FB_FW, false, LERP, false>(      // only one accumulator set is live here: two fragment sets fit
-                acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
-                [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, 2 * a.MT, mt0, cb, a.Ccond, len, 0, t0); }, nullptr, 0, 0u, 0, a.lin, a.lscale);
-            f32x16 af[WM][WN];
+        // block-floating-point scales of this tile's inputs (identity unless an utterance's |max| leaves the fp16 window)
+        const Bfp sx = fT ? Bfp{1.f, 1.f} : bfp_load(a.amax_x, b);      // flat GEMM tiles: per column (make_map / the epilogue below)
+        f32x16 hi[WM][WN], lo[WM][WN];
+        auto clear = [&](f32x16 (&u)[WM][WN]) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) af[i][j][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) u[i][j][r] = 0.f;
+        };
+        clear(hi);
+        clear(lo);
+        // hi <- (hi + 2^-11 lo) * wscale(row) * inv  (the conv result without its bias); wtab = the per-row weight-scale table
+        auto fold = [&](f32x16 (&h)[WM][WN], const f32x16 (&l)[WM][WN], const float* wtab, float inv) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float c = wtab[rl + i * 32 + (r & 3) + 8 * (r >> 2)] * inv, cl = c * kLoInv;
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) h[i][j][r] = comb(h[i][j][r], l[i][j][r], c, cl);
+                }
+        };
+
+        if constexpr (FILM && TL::WN > 1) {
+            // Wide tiles (two n-tiles per wave): the accumulator sets of conv, scale and shift do not fit the register budget together, so
+            // scale and shift are the two halves of ONE slab loop over the cond tile (split_phase<TWO>) sharing one extra pair:
+            // out = ((h + b)(sc + b_sc)) + (sh + b_sh) in the same order as below, (h + b)(sc + b_sc) replaces h between the halves.  The cond
+            // tile is staged twice; in exchange the conv phase (3/5 of the MFMAs) runs on the 96 x 256 tile of the plain convs.
+            const float* cb = a.cond + (long)b * a.Ccond * len;
+            const int mtoff = a.MT;
+            const Bfp sc = bfp_load(a.amax_c, b);
+            split_phase<TL, TAPS, A_U4, LRELU, S_FB_FW, false, LERP, false>(      // only one accumulator pair is live here: two fragment sets fit
+                hi, lo, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+                [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, 2 * a.MT, mt0, cb, a.Ccond, len, 0, t0); }, sx.s, nullptr, 0, 0u, 0, a.lin, a.lscale);
+            fold(hi, lo, Bs + 3 * TL::BM, sx.inv);
+            f32x16 fh[WM][WN];
+            clear(fh);
+            clear(lo);
             split_phase<TL, 1, A_U4, false, S_FB_F, false, false, false, true>(
-                af, regs, a.sc6, 2 * a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile, nullptr, 0, 0u, 0, 0, 0.f, mtoff + mt0,
+                fh, lo, regs, a.sc6, 2 * a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile, sc.s, nullptr, 0, 0u, 0, 0, 0.f, mtoff + mt0,
                 [&]() __attribute__((always_inline)) {
+                    fold(fh, lo, Bs + 4 * TL::BM, sc.inv);
 #pragma unroll
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -843,36 +923,40 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                             const float bm = Bs[row], bs = Bs[TL::BM + row];
 #pragma unroll
                             for (int j = 0; j < WN; ++j) {
-                                acc[i][j][r] = __fmul_rn(acc[i][j][r] + bm, af[i][j][r] + bs);
-                                af[i][j][r] = 0.f;
+                                hi[i][j][r] = __fmul_rn(hi[i][j][r] + bm, fh[i][j][r] + bs);
+                                fh[i][j][r] = 0.f;
+                                lo[i][j][r] = 0.f;
                             }
                         }
                 });
+            fold(fh, lo, Bs + 5 * TL::BM, sc.inv);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float bh = Bs[2 * TL::BM + rl + i * 32 + (r & 3) + 8 * (r >> 2)];
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) acc[i][j][r] = __fadd_rn(acc[i][j][r], af[i][j][r] + bh);
+                    for (int j = 0; j < WN; ++j) hi[i][j][r] = __fadd_rn(hi[i][j][r], fh[i][j][r] + bh);
                 }
-            tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
+            tile_store<TL, true>(reinterpret_cast<float*>(smem_s), hi, ep.y, ep.res, b, ep.M, len, mt0, t0, mx_run, nullptr, 0, ep.res_lin, ep.res_scale);
         } else if constexpr (FILM) {
             // conv -> FiLM -> + residual (decoder.py:94-97,181-182): scale and shift come from one more 1x1 phase over
             // the cond tile on the same output tiles; (conv, scale, shift) combine in registers.
             const float* cb = a.cond + (long)b * a.Ccond * len;
             const int mtoff = a.MT;                                   // the stacked FiLM image has 2 * a.MT m-tiles: scale rows, then shift rows
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : S_FB, false, LERP, false>(
-                acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
-                [&]() __attribute__((always_inline)) { film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, len, t0); }, nullptr, 0, 0u, 0, a.lin, a.lscale);
-            f32x16 asc[WM][WN], ash[WM][WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) asc[i][j][r] = ash[i][j][r] = 0.f;
-            film_phase<TL>(asc, ash, regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, a.Ccond, len, t0, As, Xs, load_next_tile);
+            const Bfp sc = bfp_load(a.amax_c, b);
+            split_phase<TL, TAPS, A_U4, LRELU, S_FB_F, false, LERP, false>(
+                hi, lo, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+                [&]() __attribute__((always_inline)) { film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, len, t0); }, sx.s, nullptr, 0, 0u, 0, a.lin, a.lscale);
+            fold(hi, lo, Bs + 3 * TL::BM, sx.inv);                    // the conv result: frees `lo` before the FiLM phase
+            f32x16 asc[2][WM][WN], ash[2][WM][WN];
+            clear(asc[0]);
+            clear(asc[1]);
+            clear(ash[0]);
+            clear(ash[1]);
+            film_phase<TL>(asc, ash, regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, a.Ccond, len, t0, As, Xs, load_next_tile, sc.s);
+            fold(asc[0], asc[1], Bs + 4 * TL::BM, sc.inv);
+            fold(ash[0], ash[1], Bs + 5 * TL::BM, sc.inv);
             // out = ((h + b)(sc + b_sc)) + (sh + b_sh), + residual in the store pass
             {
 #pragma unroll
@@ -883,58 +967,74 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                         const float bm = Bs[row], bs = Bs[TL::BM + row], bh = Bs[2 * TL::BM + row];
 #pragma unroll
                         for (int j = 0; j < WN; ++j)
-                            acc[i][j][r] = __fadd_rn(__fmul_rn(acc[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
+                            hi[i][j][r] = __fadd_rn(__fmul_rn(hi[i][j][r] + bm, asc[0][i][j][r] + bs), ash[0][i][j][r] + bh);
                     }
-                tile_store<TL, true>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, nullptr, 0, ep.res_lin, ep.res_scale);
+                tile_store<TL, true>(reinterpret_cast<float*>(smem_s), hi, ep.y, ep.res, b, ep.M, len, mt0, t0, mx_run, nullptr, 0, ep.res_lin, ep.res_scale);
             }
         } else {
+            float inv = sx.inv;
             if constexpr (wants_res_conv<Epi>::value) {
                 // Downsample (decoder.py:148-157): out = c3(lrelu(h2)) + down_res(xi).  Both are linear into the same output tile:
                 // the 1x1 runs as a second K phase over xi (a.cond, a.Ccond channels, image a.sc6) on the same accumulators, so
                 // the residual tensor is never written or read back and its launch disappears (ep.bias = the two biases summed).
+                // One accumulator pair, one unit: the two images are packed with JOINT per-m-tile scales (api.hip) and the two
+                // inputs share the smaller of their block-floating-point scales.
                 const float* cb = a.cond + (long)b * a.Ccond * len;
+                const Bfp s2 = bfp_min(sx, bfp_load(a.amax_c, b));
+                inv = s2.inv;
                 split_phase<TL, TAPS, A_U4, LRELU, S_FB, false, false, false>(
-                    acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
-                    [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0); });
-                split_phase<TL, 1, A_U4, false, S_FB, false, false, false>(acc, regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile);
+                    hi, lo, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+                    [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0); }, s2.s);
+                split_phase<TL, 1, A_U4, false, S_FB, false, false, false>(hi, lo, regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile, s2.s);
             } else
-            split_phase<TL, TAPS, A_U4, LRELU, FILM ? S_FB_F : (Epi::kIgemm ? S_FB_G : S_FB), SCALED, LERP, CLAMP>(acc, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
-                                                                                                   load_next_tile, Ks, fT, fstride, a.cmax, a.lin, a.lscale);
+            split_phase<TL, TAPS, A_U4, LRELU, Epi::kIgemm ? S_FB_G : S_FB, SCALED, LERP, CLAMP>(hi, lo, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
+                                                                                                  load_next_tile, sx.s, Ks, fT, fstride, a.cmax, a.lin, a.lscale, 0, NoMid(),
+                                                                                                  a.amax_x);
             if constexpr (Epi::kIgemm) {
                 // plain GEMM use (B = 1, len = all columns): the gemm_epi.h epilogue functors finish the element
                 const int l31 = lane & 31, wn = wave - wm * TL::NWV;
+                const int mtw = __builtin_amdgcn_readfirstlane(mt0 + wm * WM);
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i) {
+                    const float cw = a.wsc[mtw + i];
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
-                        const int n = b * len + t0 + (wn * WN + j) * 32 + l31;
-                        if (t0 + (wn * WN + j) * 32 + l31 < len) {
+                        const int col = t0 + (wn * WN + j) * 32 + l31;
+                        const int n = b * len + col;
+                        if (col < len) {
+                            const float c = cw * (fT ? bfp_load(a.amax_x, col / fT).inv : inv), cl = c * kLoInv;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                                const float v[4] = {comb(hi[i][j][4 * q], lo[i][j][4 * q], c, cl), comb(hi[i][j][4 * q + 1], lo[i][j][4 * q + 1], c, cl),
+                                                    comb(hi[i][j][4 * q + 2], lo[i][j][4 * q + 2], c, cl), comb(hi[i][j][4 * q + 3], lo[i][j][4 * q + 3], c, cl)};
                                 ep.store(n, (mt0 + wm * WM + i) * 32 + 8 * q + 4 * lh, v);
                             }
                         }
                     }
+                }
                 tile = nxt;
                 if (tile < vtiles) coords(tile, mt0, b, t0);
                 continue;
             }
             if constexpr (!Epi::kIgemm) {
+                fold(hi, lo, Bs + 3 * TL::BM, inv);
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float bm = Bs[rl + i * 32 + (r & 3) + 8 * (r >> 2)];
 #pragma unroll
-                        for (int j = 0; j < WN; ++j) acc[i][j][r] += bm;
+                        for (int j = 0; j < WN; ++j) hi[i][j][r] += bm;
                     }
-                tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), acc, ep.y, ep.res, b, ep.M, len, mt0, t0, ep.y2, ep.f2);
+                tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), hi, ep.y, ep.res, b, ep.M, len, mt0, t0, mx_run, ep.y2, ep.f2);
             }
         }
         TR_STAMP(regs, 7);
         tile = nxt;
         if (tile < vtiles) coords(tile, mt0, b, t0);
+    }
+    if constexpr (!Epi::kIgemm) {
+        if (a.amax_y) amax_flush_wg(a.amax_y + mx_b, mx_run, red);
     }
 #ifdef S_TRACE
     if (regs.tr) {
@@ -951,10 +1051,18 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
 #endif
 }
 
+// per-utterance |max| slots of a launch's tensors (block-floating-point guard, see the top of this file): x / cond are read
+// (nullptr = the tensor is known to sit inside the fp16 window: no scaling), y is written (nullptr = nobody needs it)
+struct BfpSlots {
+    const float* x = nullptr;
+    const float* c = nullptr;
+    float* y = nullptr;
+};
+
 template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false, bool CLAMP = false>
 inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
                            const PackedW* wsc, const PackedW* wsh, const float* cond, int Ccond, long xstride = 0, int bpc = S_BPC,
-                           const float* kscale = nullptr, bool flat = false, int cmax = 0, int lin = 0, float lscale = 0.f) {
+                           const float* kscale = nullptr, bool flat = false, int cmax = 0, int lin = 0, float lscale = 0.f, const BfpSlots& bfp = {}) {
     if (Cin % (16 * TL::KG) != 0 || (FILM && Ccond % (16 * TL::KG) != 0)) return fail(ctx, TVC_ERR_ARG, "conv3s: channel counts must be multiples of the slab depth");
     if (Cin / 16 > w.S6) return fail(ctx, TVC_ERR_ARG, "conv3s: weight image has fewer K16 steps than the launch walks");
     static bool ready_dev[64] = {};                 // the attribute is per (function, device): one flag per device of this process
@@ -968,7 +1076,12 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     }
     ConvSArgs a;
     a.A6 = reinterpret_cast<const uint4*>(w.A6);
+    a.wsc = w.wscale;
     a.MT = w.MT6;
+    a.amax_x = bfp.x;
+    a.amax_c = bfp.c;
+    a.amax_y = bfp.y;
+    if (Epi::kIgemm && bfp.y) return fail(ctx, TVC_ERR_ARG, "conv3s: GEMM launches finish their elements in the epilogue functor and cannot track the output's |max|");
     if (SCALED && (!kscale || Cin > 768)) return fail(ctx, TVC_ERR_ARG, "conv3s: scaled launch needs factors for <= 768 channels");
     a.kscale = kscale;
     a.cmax = cmax;
@@ -991,6 +1104,7 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     if (wants_res_conv<Epi>::value) {
         if (FILM || !wsc || wsc->MT6 != w.MT6 || wsc->taps != 1 || Ccond % 16 != 0 || Ccond / 16 > wsc->S6 || !cond)
             return fail(ctx, TVC_ERR_ARG, "conv3s: the residual 1x1 phase needs a matching 1x1 image and its input");
+        if (wsc->wjoint != w.A6) return fail(ctx, TVC_ERR_STATE, "conv3s: the residual 1x1's image must be packed with the conv's per-m-tile scales");
         a.sc6 = reinterpret_cast<const uint4*>(wsc->A6);
         a.cond = cond;
         a.Ccond = Ccond;
@@ -998,7 +1112,7 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     if (FILM) {
         if (wsc->MT6 != 2 * w.MT6) return fail(ctx, TVC_ERR_ARG, "conv3s: FiLM image must stack scale and shift rows");
         a.sc6 = reinterpret_cast<const uint4*>(wsc->A6);   // stacked [to_scale ; to_shift] image (wsh unused)
-        a.sh6 = nullptr;
+        a.fsc = wsc->wscale;
         a.cond = cond;
         a.Ccond = Ccond;
     }
@@ -1010,116 +1124,101 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
         if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv3s: device properties");
         ncu = prop.multiProcessorCount;
     }
-    const int slots = (ncu * bpc) / 8 * 8;        // persistent: one resident workgroup per slot walks the tiles (multiple of 8: see the XCD walk)
-    const int mblocks = a.MT / TL::MTB;
-    const int vtiles = S_XCD_MAP ? (a.ntiles / mblocks + 7) / 8 * 8 * mblocks : a.ntiles;
-    dim3 g((unsigned)(vtiles < slots ? vtiles : slots));
+    const int slots = ncu * bpc;        // persistent: one resident workgroup per slot walks a contiguous range of the tiles
+    dim3 g((unsigned)(a.ntiles < slots ? a.ntiles : slots));
     hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED, LERP, CLAMP>), g, dim3(TL::NTHR), lds, s, a, ep);
     return 0;
 }
 
-#ifndef TVC_S_WN
-#define TVC_S_WN 2   // plain convs of the 96..384-channel levels: a wave owns two 32-sample n-tiles (96 x 256 workgroup tile); every weight fragment and every slab's staging round trip serves twice the columns (6.73 -> 6.56 ms)
-#endif
-#ifndef TVC_S48_NWV   // waves (= 32-sample n-tiles) per m-tile of the 48-channel workgroups
-#define TVC_S48_NWV 6
-#endif
-#ifndef TVC_S48_WN    // 32-sample n-tiles per wave of the 48-channel workgroups
-#define TVC_S48_WN 1
-#endif
-#ifndef TVC_S48F_WN
-#define TVC_S48F_WN 1
-#endif
-#ifndef TVC_S48F_NWV
-#define TVC_S48F_NWV 6
-#endif
-#ifndef TVC_SF_WM   // tile of the FiLM-fused kernels (two accumulator sets live)
-#define TVC_SF_WM 1
-#endif
-#ifndef TVC_SF_NWV
-#define TVC_SF_NWV 4
-#endif
-#ifndef TVC_SF_KG
-#define TVC_SF_KG 1   // FiLM-fused kernels: 16-channel groups per staged slab (conv and FiLM phases); 2 measured -0.03 ms with 48 B of scratch: not worth it
-#endif
-#ifndef TVC_SF_WN
-#define TVC_SF_WN 1
-#endif
-#ifndef TVC_SF_WIDE
-#define TVC_SF_WIDE 1   // FiLM-fused launches: 0 = always the 96 x 128 tile, 1 = the 96 x 256 tile where rounds x tile cost favours it, 2 = always wide
-#endif
-#ifndef TVC_S_WM
-#define TVC_S_WM 1
-#endif
-#ifndef TVC_S_NWV
-#define TVC_S_NWV 4
-#endif
-
-// k3 conv on the split path; Mpad = 64 (48 channels) or a multiple of 96 (FilterNet levels with C = 96, 192, 384)
+// k3 conv on the split path; Mpad = 64 (48 channels) or a multiple of 96 (FilterNet levels with C = 96, 192, 384).
+// Tiles (each swept on the part): plain convs 96 x 256 (a wave owns two 32-sample n-tiles: every weight
+// fragment and every slab's staging round trip serves twice the columns), 48-output-channel convs 64 x 192 (six waves per m-tile),
+// FiLM-fused convs 96 x 128 or 96 x 256.
 template <bool LRELU, class Epi, bool FILM = false, bool LERP = false>
 inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, const Epi& ep,
-                         const PackedW* wsc = nullptr, const PackedW* wsh = nullptr, const float* cond = nullptr, int Ccond = 0, int lin = 0,
+                         const BfpSlots& bfp, const PackedW* wsc = nullptr, const PackedW* wsh = nullptr, const float* cond = nullptr, int Ccond = 0, int lin = 0,
                          float lscale = 0.f) {
-    if (w.MT6 == 2) {   // 48 output channels: two m-tiles, the second half empty (still 1.4x fewer MFMA cycles than exact fp32 tiles)
-        if constexpr (FILM)
-            return conv3s_launch_t<SplitTile<2, 1, TVC_S48F_NWV, TVC_S48F_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC,
-                                                                                                      nullptr, false, 0, lin, lscale);
-        else
-            return conv3s_launch_t<SplitTile<2, 1, TVC_S48_NWV, TVC_S48_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC,
-                                                                                                     nullptr, false, 0, lin, lscale);
-    }
-    if constexpr (FILM)
-    {
-        // Two tiles for the FiLM-fused launches.  96 x 128: scale and shift in one phase, three accumulator sets.  96 x 256 (the plain
-        // convs' tile): the conv phase stages a slab for twice the columns, scale and shift run one after the other on one extra set
-        // (split_phase<TWO>) and the cond tile is staged twice - per column ~7 % cheaper (measured: C = 384 level 0.950 -> 0.915 ms,
-        // C = 96 level 0.725 -> 0.698), unless the wide tiles leave the last round of the 256 persistent workgroups underfilled (C = 192
-        // level, 640 tiles: 0.675 -> 0.712).  Rounds x per-tile cost decides; a launch that cannot fill the chip keeps the narrow tile.
+    if (w.MT6 == 2)     // 48 output channels: two m-tiles, the second half empty
+        return conv3s_launch_t<SplitTile<2, 1, 6, 1>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC, nullptr, false, 0,
+                                                                                       lin, lscale, bfp);
+    if constexpr (FILM) {
+        // Two tiles for the FiLM-fused launches.  96 x 128: scale and shift in one phase.  96 x 256 (the plain convs' tile): the conv
+        // phase stages a slab for twice the columns, scale and shift run one after the other on one extra accumulator pair
+        // (split_phase<TWO>) and the cond tile is staged twice - per column cheaper, unless the wide tiles leave the last round of the
+        // 256 persistent workgroups underfilled.  Rounds x per-tile cost decides; a launch that cannot fill the chip keeps the narrow tile.
         const long mb = w.MT6 / 3;
         const long tiles_n = mb * ((len + 127) / 128) * B, tiles_w = mb * ((len + 255) / 256) * B;
         const long slots = 256 * S_BPC;
         const long rounds_n = (tiles_n + slots - 1) / slots, rounds_w = (tiles_w + slots - 1) / slots;
-        const bool wide = TVC_SF_WIDE == 2 || (TVC_SF_WIDE == 1 && tiles_w >= slots && rounds_w * 186 < rounds_n * 100);
+        const bool wide = tiles_w >= slots && rounds_w * 186 < rounds_n * 100;
         if (wide)
             return conv3s_launch_t<SplitTile<3, 1, 4, 2>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC, nullptr, false,
-                                                                                           0, lin, lscale);
-        return conv3s_launch_t<SplitTile<3, TVC_SF_WM, TVC_SF_NWV, TVC_SF_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0,
-                                                                                                                S_BPC, nullptr, false, 0, lin, lscale);
-    }
-    else
-        return conv3s_launch_t<SplitTile<3, TVC_S_WM, TVC_S_NWV, TVC_S_WN>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC,
-                                                                                                             nullptr, false, 0, lin, lscale);
+                                                                                           0, lin, lscale, bfp);
+        return conv3s_launch_t<SplitTile<3, 1, 4, 1>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC, nullptr, false, 0,
+                                                                                       lin, lscale, bfp);
+    } else
+        return conv3s_launch_t<SplitTile<3, 1, 4, 2>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC, nullptr, false, 0,
+                                                                                       lin, lscale, bfp);
 }
 
 // Plain GEMM on the split path: out(m, n) = sum_k W[m][k] x[b][k][t], n = b * len + t, finished by a gemm_epi.h epilogue
 // functor (store(n, m, v[4])).  Cin must be a multiple of 16 and rows [K, Cin) must be readable (weights there are 0).
 template <int MTB, int NWV, int BPC, int KG, class Epi, bool SCALED, bool CLAMP>
 inline int gemm_s_launch_k(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
-                           const float* kscale, int cmax) {
+                           const float* kscale, int cmax, const float* amax_x) {
     using TL = SplitTile<MTB, (MTB >= 4 ? 2 : 1), NWV, 1, KG, 0>;     // MTB >= 4: a wave owns two m-tiles (64 x 32), 8 waves cover 128 x 128
     // flat column tiles unless a tile could touch more than two utterances of a SCALED launch (factors of two are staged)
     // or the element offsets would not fit 32 bits
     const long xs = xstride ? xstride : (long)Cin * len;
-    const bool flat = TVC_S_FLAT && B > 1 && xs * B < (1L << 30) && (!SCALED || len >= TL::BN);
+    const bool flat = B > 1 && xs * B < (1L << 30) && (!SCALED || len >= TL::BN);
     return conv3s_launch_t<TL, 1, false, Epi, false, SCALED, false, CLAMP>(ctx, s, w, x, B, Cin, len, 0, ep, nullptr, nullptr, nullptr, 0, xstride, BPC, kscale, flat,
-                                                                           cmax);
+                                                                           cmax, 0, 0.f, BfpSlots{amax_x, nullptr, nullptr});
 }
 template <int MTB, int NWV, int BPC, class Epi, bool SCALED = false>
 inline int gemm_s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, long xstride, const Epi& ep,
-                         const float* kscale = nullptr) {
+                         const float* amax_x, const float* kscale = nullptr) {
     if (w.MT6 % MTB != 0) return fail(ctx, TVC_ERR_ARG, "gemm_s: row tiles do not divide");
-    // deepest slab the channel count allows: 48, 32 or 16 input channels per load -> LDS -> barrier round trip
-    if (TVC_S_KG >= 3 && Cin % 48 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 3, Epi, SCALED, false>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, 0);
-    if (TVC_S_KG >= 2 && Cin % 32 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 2, Epi, SCALED, false>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, 0);
-    return gemm_s_launch_k<MTB, NWV, BPC, 1, Epi, SCALED, false>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, 0);
+    // deepest slab the channel count allows: 32 or 16 input channels per load -> LDS -> barrier round trip
+    if (TVC_S_KG >= 2 && Cin % 32 == 0) return gemm_s_launch_k<MTB, NWV, BPC, 2, Epi, SCALED, false>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, 0, amax_x);
+    return gemm_s_launch_k<MTB, NWV, BPC, 1, Epi, SCALED, false>(ctx, s, w, x, B, Cin, len, xstride, ep, kscale, 0, amax_x);
 }
 // The input has only `krows` channel rows per utterance (not a multiple of the slab depth): K is rounded up to whole 32-channel
 // slabs and the loads of the missing rows are clamped to the last real one (their weights are zero).  Its own instantiation:
 // a second load path inside the shared kernels cost them 4 % (waitcnt placement), measured.
 template <int MTB, int NWV, int BPC, class Epi>
-inline int gemm_s_launch_ragged(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int krows, int len, long xstride, const Epi& ep) {
+inline int gemm_s_launch_ragged(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int krows, int len, long xstride, const Epi& ep,
+                                const float* amax_x) {
     if (w.MT6 % MTB != 0) return fail(ctx, TVC_ERR_ARG, "gemm_s: row tiles do not divide");
-    return gemm_s_launch_k<MTB, NWV, BPC, 2, Epi, false, true>(ctx, s, w, x, B, (krows + 31) / 32 * 32, len, xstride, ep, nullptr, krows - 1);
+    return gemm_s_launch_k<MTB, NWV, BPC, 2, Epi, false, true>(ctx, s, w, x, B, (krows + 31) / 32 * 32, len, xstride, ep, nullptr, krows - 1, amax_x);
+}
+
+// Per-utterance |max| of a contiguous [B][n] tensor into slot[b] (zeroed first): the block-floating-point slot of a tensor whose
+// producer does not track it (tensors that enter a stage through the C ABI, epilogue-functor outputs).  One pass over the tensor.
+static __global__ __launch_bounds__(256) void amax_rows_kernel(const float* __restrict__ x, long n, float* __restrict__ slot) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const float* p = x + (long)b * n;
+    float mx = 0.f;
+    if ((n & 3) == 0) {                      // rows are whole float4s (and 16-byte aligned: workspace tensors are 256-byte aligned)
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < (n >> 2); i += (long)gridDim.x * 256) {
+            const float4 v = reinterpret_cast<const float4*>(p)[i];
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) mx = fmaxf(mx, fabsf(p[i]));
+    }
+    amax_flush_wg(slot + b, mx, red);
+}
+// slot must have been zeroed (one memset per stage covers all of a stage's slots); rows of n floats must be 16-byte aligned
+inline int run_amax_rows(tvc_ctx* ctx, hipStream_t s, const float* x, int B, long n, float* slot) {
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(ctx, TVC_ERR_ARG, "amax_rows: the tensor must be 16-byte aligned");
+    // one atomic per workgroup: a few per utterance while the launch still fills the chip
+    long gx = (n / 4 + 255) / 256 / 8;                     // >= 8 float4 per thread
+    const long cap = B >= 64 ? 8 : 512 / (B > 0 ? B : 1);
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(amax_rows_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, s, x, n, slot);
+    return launch_check(ctx, "amax_rows");
 }
 
 }  // namespace tvc

@@ -1,12 +1,13 @@
 // 48-channel k3 dilated convs of FilterNet (ups.3's c1..c4 with their FiLM, Downsample 2's c1 / c2; decoder.py:143-190) with
 // the layer's weights RESIDENT in LDS.  At 48 channels a conv is only three 16-channel K slabs: the generic split kernel
-// (conv3s.h) restages 27 KiB of weights and passes two barriers per slab for 18 MFMAs per wave, and its matrix pipe sat idle
-// two thirds of the time.  Here a persistent 8-wave workgroup loads the conv's 54 weight pieces (and FiLM's 36) once, stages
-// the whole 48-channel halo tile of 128 samples in one go and then issues the tile's 54 (+36) MFMAs per wave back to back:
-// one staging round trip and two barriers per tile instead of per slab.
-//   weights   the same pre-split images as conv3s (PackedW::A6: [K16 step = slab*3 + tap][m-tile][part][lane][8 bf16];
+// (conv3s.h) restages its weights and passes two barriers per slab for a handful of MFMAs per wave, and its matrix pipe sat idle
+// two thirds of the time.  Here a persistent 8-wave workgroup loads the conv's 36 weight pieces (and FiLM's 24) once, stages
+// the whole 48-channel halo tile of 128 samples in one go and then issues the tile's 27 (+18) MFMAs per wave back to back:
+// one staging round trip and two barriers per tile instead of per slab.  Two-term fp16 split, accumulator pairs and the
+// block-floating-point guard as in conv3s.h.
+//   weights   the same pre-split images as conv3s (PackedW::A6: [K16 step = slab*3 + tap][m-tile][part][lane][8 fp16];
 //             stacked FiLM image [slab][scale mt0, mt1, shift mt0, mt1][part]) - no new packing;
-//   input     Xs[part][8-channel group (6)][position][8 bf16]: lrelu (and, for c1, F.interpolate) applied while depositing;
+//   input     Xs[part][8-channel group (6)][position][8 fp16]: lrelu (and, for c1, F.interpolate) applied while depositing;
 //   waves     wave w = m-tile (w >> 2) x 32-sample n-tile (w & 3); FiLM's cond fragments come from HBM straight into
 //             B-fragment order and are split in registers; (conv, scale, shift) combine in registers;
 //   epilogue  bias / FiLM / residual (direct, or F.interpolate of the low-rate tensor evaluated in place), 128-byte runs
@@ -23,19 +24,16 @@ constexpr int kC48 = 48, kBN48 = 128, kXP48 = kBN48 + 2 * 27, kNT48 = 512;
 typedef float f32x4s_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
-// three bf16 parts of 4 fp32 values (8 bytes each)
-__device__ __forceinline__ void split4_48(const float (&v)[4], u32x2_t& p1, u32x2_t& p2, u32x2_t& p3) {
+// two fp16 parts of 4 fp32 values (8 bytes each)
+__device__ __forceinline__ void split4_48(const float (&v)[4], u32x2_t& p1, u32x2_t& p2) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         f32x2 a = {v[2 * j], v[2 * j + 1]};
-        bf16x2 h1 = __builtin_convertvector(a, bf16x2);
-        f32x2 r = a - __builtin_convertvector(h1, f32x2);
-        bf16x2 h2 = __builtin_convertvector(r, bf16x2);
-        f32x2 r2 = r - __builtin_convertvector(h2, f32x2);
-        bf16x2 h3 = __builtin_convertvector(r2, bf16x2);
+        f16x2v h1 = __builtin_convertvector(a, f16x2v);
+        f32x2 r = (a - __builtin_convertvector(h1, f32x2)) * kLoScale;
+        f16x2v h2 = __builtin_convertvector(r, f16x2v);
         p1[j] = __builtin_bit_cast(unsigned, h1);
         p2[j] = __builtin_bit_cast(unsigned, h2);
-        p3[j] = __builtin_bit_cast(unsigned, h3);
     }
 }
 
@@ -44,14 +42,21 @@ struct Conv48Args {
     const float* cond;     // FILM: [B][48][len]
     const float* res;      // RES 1: [B][48][len]; RES 2: low-rate [B][48][rlin], interpolated here
     float* out;            // [B][48][len]
-    const u32x4* A6;       // conv image, 54 pieces
-    const u32x4* F6;       // stacked FiLM image, 36 pieces
-    const u32x4* W5;       // C5: c5's image (1 m-tile, 3 K16 steps: 9 pieces) and bias [32]
+    const u32x4* A6;       // conv image, 36 pieces
+    const u32x4* F6;       // stacked FiLM image, 24 pieces
+    const u32x4* W5;       // C5: c5's image (1 m-tile, 3 K16 steps: 6 pieces) and bias [32]
     const float* b5;
     float* out5;           // C5: [B][24][len]
-    const float* bias;     // [64]
-    const float* bsc;      // FiLM to_scale / to_shift biases [64]
+    const float* bias;     // [>= 48]
+    const float* bsc;      // FiLM to_scale / to_shift biases [48]
     const float* bsh;
+    const float* wsc;      // per-m-tile power-of-two scales of the images: conv [2], FiLM [4] (scale mt0, mt1, shift mt0, mt1), c5 [1]
+    const float* fsc;
+    const float* w5sc;
+    // block-floating-point guard (conv3s.h): per-utterance |max| slots of x / cond (read, nullable) and of the output (written, nullable)
+    const float* amax_x;
+    const float* amax_c;
+    float* amax_y;
     int len, dil, lin, rlin, tiles_per_utt, ntiles;
     float lscale, rscale;
 };
@@ -62,11 +67,11 @@ template <bool FILM, bool LERP, int RES, bool C5 = false>
 __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void conv48s_kernel(Conv48Args a) {
     constexpr int C = kC48, BN = kBN48, XP = kXP48, NT = kNT48;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_q[];
-    u32x4* Xs = reinterpret_cast<u32x4*>(smem_q);              // [3 parts][6 groups][XP]
-    u32x4* Wt = Xs + 18 * XP;                                  // 54 pieces
-    u32x4* Ft = Wt + 54 * 64;                                  // 36 pieces (FILM)
-    u32x4* W5t = Ft + (FILM ? 36 * 64 : 0);                   // 9 pieces (C5)
-    float* Bi = reinterpret_cast<float*>(W5t + (C5 ? 9 * 64 : 0));    // bias, bsc, bsh [64 each], b5 [32]
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem_q);              // [2 parts][6 groups][XP]
+    u32x4* Wt = Xs + 12 * XP;                                  // 36 pieces
+    u32x4* Ft = Wt + 36 * 64;                                  // 24 pieces (FILM)
+    u32x4* W5t = Ft + (FILM ? 24 * 64 : 0);                   // 6 pieces (C5)
+    float* Bi = reinterpret_cast<float*>(W5t + (C5 ? 6 * 64 : 0));    // bias, bsc, bsh [64 each], b5 [32], [224] = the C5 tile's |max| (LDS atomic), [228..235] = |max| exchange
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int mt = wave >> 2, nt = wave & 3;
@@ -74,20 +79,24 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
     const int XW = BN + 2 * dil;
     const int lin = LERP ? a.lin : len;
 
-    for (int i = tid; i < 54 * 64; i += NT) Wt[i] = a.A6[i];
+    for (int i = tid; i < 36 * 64; i += NT) Wt[i] = a.A6[i];
     if (FILM)
-        for (int i = tid; i < 36 * 64; i += NT) Ft[i] = a.F6[i];
+        for (int i = tid; i < 24 * 64; i += NT) Ft[i] = a.F6[i];
     if (C5) {
-        for (int i = tid; i < 9 * 64; i += NT) W5t[i] = a.W5[i];
+        for (int i = tid; i < 6 * 64; i += NT) W5t[i] = a.W5[i];
         if (tid < 32) Bi[192 + tid] = a.b5[tid];
+        if (tid == 0) Bi[224] = 0.f;
     }
     if (tid < 64) {
-        Bi[tid] = a.bias[tid];
+        const int tc = tid < C ? tid : C - 1;                  // rows 48..63 do not exist
+        Bi[tid] = a.bias[tc];
         if (FILM) {
-            Bi[64 + tid] = a.bsc[tid];
-            Bi[128 + tid] = a.bsh[tid];
+            Bi[64 + tid] = a.bsc[tc];
+            Bi[128 + tid] = a.bsh[tc];
         }
     }
+    // this wave's m-tile: power-of-two scales of its weight rows
+    const float cw = a.wsc[mt], cwsc = FILM ? a.fsc[mt] : 1.f, cwsh = FILM ? a.fsc[2 + mt] : 1.f, cw5 = C5 ? a.w5sc[0] : 1.f;
 
     // staging items (8-channel group, column): 6 * XW <= 1092 of them, three per thread
     constexpr int XPER = 3;
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
             }
         }
     };
-    auto deposit = [&]() __attribute__((always_inline)) {
+    auto deposit = [&](float xs) __attribute__((always_inline)) {      // xs = the tile's block-floating-point input scale
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
             if (ig[i] > 5) continue;
@@ -133,28 +142,37 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float t = LERP ? fmaf(1.f - lam[i], xr0[i][j], __fmul_rn(lam[i], xr1[i][j])) : xr0[i][j];   // = lerp_eval
-                v[j] = fmaxf(t, 0.1f * t);                                                                  // = leaky_relu(x, 0.1)
+                v[j] = fmaxf(t, 0.1f * t) * xs;                                                             // = leaky_relu(x, 0.1), scaled
             }
-            uint4 p1, p2, p3;
-            split8(v, p1, p2, p3);
+            uint4 p1, p2;
+            split8(v, p1, p2);
             Xs[(0 + ig[i]) * XP + ic[i]] = __builtin_bit_cast(u32x4, p1);
             Xs[(6 + ig[i]) * XP + ic[i]] = __builtin_bit_cast(u32x4, p2);
-            Xs[(12 + ig[i]) * XP + ic[i]] = __builtin_bit_cast(u32x4, p3);
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile >= a.ntiles) return;
+    // persistent: a contiguous range of tiles per workgroup (one or two utterances: the output's |max| slot is published once
+    // per utterance and workgroup, conv3s.h amax_flush_wg)
+    int tile, tend;
+    tile_range(a.ntiles, tile, tend);
+    if (tile >= tend) return;
     fetch(tile);
-    deposit();
-    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+    deposit(bfp_load(a.amax_x, tile / a.tiles_per_utt).s);
+    if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
+    float mx_run = 0.f;
+    int mx_b = tile / a.tiles_per_utt;
 
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-    for (; tile < a.ntiles; tile += gridDim.x) {
+    for (; tile < tend; ++tile) {
         const int b = tile / a.tiles_per_utt;
+        if (a.amax_y && b != mx_b) {
+            amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 228);
+            mx_run = 0.f;
+            mx_b = b;
+        }
+        const Bfp sx = bfp_load(a.amax_x, b), sc = FILM ? bfp_load(a.amax_c, b) : Bfp{1.f, 1.f};
         const int t0 = (tile - b * a.tiles_per_utt) * BN;
-        const int next = tile + gridDim.x;
+        const int next = tile + 1;
         const int n = nt * 32 + l31;
         const int t = t0 + n;
         const int tc = t < len ? t : len - 1;
@@ -196,18 +214,18 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         }
 
         // ---- conv: 9 K16 steps (slab, tap), this wave's m-tile x n-tile ------------------------------------
-        f32x16 acc;
+        f32x16 acc, alo;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = alo[r] = 0.f;
         {
-            bf16x8 af[2][3], bf[2][3];
+            f16x8 af[2][2], bf[2][2];
             auto frags = [&](int s, int fb) __attribute__((always_inline)) {
                 const int sl = s / 3, tap = s - sl * 3;
                 const int row = (2 * sl + lh) * XP + n + tap * dil;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    bf[fb][p] = __builtin_bit_cast(bf16x8, Xs[p * 6 * XP + row]);
-                    af[fb][p] = __builtin_bit_cast(bf16x8, Wt[((s * 2 + mt) * 3 + p) * 64 + lane]);
+                for (int p = 0; p < 2; ++p) {
+                    bf[fb][p] = __builtin_bit_cast(f16x8, Xs[p * 6 * XP + row]);
+                    af[fb][p] = __builtin_bit_cast(f16x8, Wt[((s * 2 + mt) * 2 + p) * 64 + lane]);
                 }
             };
             frags(0, 0);
@@ -216,37 +234,54 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
                 const int fb = s & 1;
                 if (s + 1 < 9) frags(s + 1, fb ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][PA[q]], bf[fb][PB[q]], acc, 0, 0, 0);
+                alo = TVC_MFMA16(af[fb][1], bf[fb][0], alo);
+                acc = TVC_MFMA16(af[fb][0], bf[fb][0], acc);
+                alo = TVC_MFMA16(af[fb][0], bf[fb][1], alo);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        {   // the conv result without its bias
+            const float c = cw * sx.inv, cl = c * kLoInv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = comb(acc[r], alo[r], c, cl);
         }
         // ---- FiLM scale / shift over cond: 3 K16 steps ----------------------------------------------------
         f32x16 asc, ash;
         if (FILM) {
+            f32x16 lsc, lsh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) asc[r] = ash[r] = 0.f;
+            for (int r = 0; r < 16; ++r) asc[r] = ash[r] = lsc[r] = lsh[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                uint4 p1, p2, p3;
-                split8(cr[s], p1, p2, p3);
-                const bf16x8 cf[3] = {__builtin_bit_cast(bf16x8, p1), __builtin_bit_cast(bf16x8, p2), __builtin_bit_cast(bf16x8, p3)};
-                bf16x8 fa[2][3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    fa[0][p] = __builtin_bit_cast(bf16x8, Ft[((s * 4 + mt) * 3 + p) * 64 + lane]);
-                    fa[1][p] = __builtin_bit_cast(bf16x8, Ft[((s * 4 + 2 + mt) * 3 + p) * 64 + lane]);
-                }
+                for (int j = 0; j < 8; ++j) cr[s][j] *= sc.s;
+                uint4 p1, p2;
+                split8(cr[s], p1, p2);
+                const f16x8 cf[2] = {__builtin_bit_cast(f16x8, p1), __builtin_bit_cast(f16x8, p2)};
+                f16x8 fa[2][2];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    asc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][PA[q]], cf[PB[q]], asc, 0, 0, 0);
-                    ash = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][PA[q]], cf[PB[q]], ash, 0, 0, 0);
+                for (int p = 0; p < 2; ++p) {
+                    fa[0][p] = __builtin_bit_cast(f16x8, Ft[((s * 4 + mt) * 2 + p) * 64 + lane]);
+                    fa[1][p] = __builtin_bit_cast(f16x8, Ft[((s * 4 + 2 + mt) * 2 + p) * 64 + lane]);
                 }
+                lsc = TVC_MFMA16(fa[0][1], cf[0], lsc);
+                lsh = TVC_MFMA16(fa[1][1], cf[0], lsh);
+                asc = TVC_MFMA16(fa[0][0], cf[0], asc);
+                ash = TVC_MFMA16(fa[1][0], cf[0], ash);
+                lsc = TVC_MFMA16(fa[0][0], cf[1], lsc);
+                lsh = TVC_MFMA16(fa[1][0], cf[1], lsh);
+            }
+            const float c1 = cwsc * sc.inv, c2 = cwsh * sc.inv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                asc[r] = comb(asc[r], lsc[r], c1, c1 * kLoInv);
+                ash[r] = comb(ash[r], lsh[r], c2, c2 * kLoInv);
             }
         }
 
         // ---- epilogue ---------------------------------------------------------------------------------------
         float xv[C5 ? 4 : 1][4];
+        float mx = 0.f;                   // |max| of what this lane stores (C5: of its part of the finished tile)
         {
             float* ob = C5 ? nullptr : a.out + (long)b * C * len;
 #pragma unroll
@@ -263,80 +298,97 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
                     float v = acc[4 * g + q] + bv[q];
                     if (FILM) v = __fadd_rn(__fmul_rn(v, asc[4 * g + q] + bs[q]), ash[4 * g + q] + bh[q]);
                     if (RES) v = __fadd_rn(v, rv[g][q]);
-                    if (C5) xv[g][q] = v;
-                    else if (t < len) stg_so(ob + (long)(8 * g + q) * len, oo, v);
+                    if (C5) {
+                        xv[g][q] = v;
+                        mx = fmaxf(mx, fabsf(v));
+                    } else if (t < len) {
+                        stg_so(ob + (long)(8 * g + q) * len, oo, v);
+                        mx = fmaxf(mx, fabsf(v));
+                    }
                 }
             }
         }
+        if (!C5) mx_run = fmaxf(mx_run, mx);
         if (C5) {
             // the finished 48 x 128 tile goes back into the (now idle) input tile as c5's B operand: split, rows
-            // [part][group 4 mt + g][column], this lane's four channels are one 8-byte half of a row
-            slab_barrier();                               // every wave is done reading Xs
+            // [part][group 4 mt + g][column], this lane's four channels are one 8-byte half of a row.
+            // Per-tile power-of-two pre-scale: the tile's |max| meets in LDS (one ds_max per wave) behind the barrier that is
+            // needed anyway, so the split never leaves fp16's range whatever the block produced.
+            {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(Bi + 224), __builtin_bit_cast(unsigned, mx));
+            }
+            slab_barrier();                               // every wave is done reading Xs; the tile |max| is complete
+            const Bfp s5 = bfp_from_amax(Bi[224]);
             // (a row = [lanes 0-31's four channels | lanes 32-63's four]: 8-byte stores from the two lane halves are 2-way bank
             // conflicts; v_permlane32_swap gives the lower half of the wave both halves of one row and the upper half both halves of
-            // another - part 1 / part 2 of a group, part 3 of two neighbouring groups - so every store is 16 bytes)
-            u32x2_t p3s[4];
+            // another - part 1 / part 2 of a group - so every store is 16 bytes)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (32 * mt + 8 * g >= C) continue;
                 u32x2_t p1, p2;
-                split4_48(xv[g], p1, p2, p3s[g]);
-                const auto sx = __builtin_amdgcn_permlane32_swap(p1[0], p2[0], false, false);
-                const auto sy = __builtin_amdgcn_permlane32_swap(p1[1], p2[1], false, false);
-                const u32x4 row = {sx[0], sy[0], sx[1], sy[1]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xv[g][q] *= s5.s;
+                split4_48(xv[g], p1, p2);
+                const auto sx_ = __builtin_amdgcn_permlane32_swap(p1[0], p2[0], false, false);
+                const auto sy_ = __builtin_amdgcn_permlane32_swap(p1[1], p2[1], false, false);
+                const u32x4 row = {sx_[0], sy_[0], sx_[1], sy_[1]};
                 *reinterpret_cast<u32x4*>(Xs + (6 * lh + 4 * mt + g) * XP + n) = row;
             }
-#pragma unroll
-            for (int g = 0; g < 4; g += 2) {
-                if (32 * mt + 8 * g >= C) continue;
-                const auto sx = __builtin_amdgcn_permlane32_swap(p3s[g][0], p3s[g + 1][0], false, false);
-                const auto sy = __builtin_amdgcn_permlane32_swap(p3s[g][1], p3s[g + 1][1], false, false);
-                const u32x4 row = {sx[0], sy[0], sx[1], sy[1]};
-                *reinterpret_cast<u32x4*>(Xs + (12 + 4 * mt + g + lh) * XP + n) = row;
-            }
             slab_barrier();
+            if (tid == 0) Bi[224] = 0.f;                  // next use is behind the next tile's barriers
             if (mt == 0) {                                // 24 output rows = one m-tile: the first four waves, one n-tile each
-                f32x16 a5;
+                f32x16 a5, l5;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a5[r] = 0.f;
+                for (int r = 0; r < 16; ++r) a5[r] = l5[r] = 0.f;
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
-                    bf16x8 fa[3], fb[3];
+                    f16x8 fa[2], fb[2];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        fb[p] = __builtin_bit_cast(bf16x8, Xs[(p * 6 + 2 * s + lh) * XP + n]);
-                        fa[p] = __builtin_bit_cast(bf16x8, W5t[(s * 3 + p) * 64 + lane]);
+                    for (int p = 0; p < 2; ++p) {
+                        fb[p] = __builtin_bit_cast(f16x8, Xs[(p * 6 + 2 * s + lh) * XP + n]);
+                        fa[p] = __builtin_bit_cast(f16x8, W5t[(s * 2 + p) * 64 + lane]);
                     }
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) a5 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]], fb[PB[q]], a5, 0, 0, 0);
+                    l5 = TVC_MFMA16(fa[1], fb[0], l5);
+                    a5 = TVC_MFMA16(fa[0], fb[0], a5);
+                    l5 = TVC_MFMA16(fa[0], fb[1], l5);
                 }
+                float m5 = 0.f;
                 if (t < len) {
                     float* o5 = a.out5 + (long)b * 24 * len;
                     const unsigned o5o = 4u * (unsigned)(4 * lh * len + t);
+                    const float c = cw5 * s5.inv, cl = c * kLoInv;
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
                         const f32x4s_t b5v = *reinterpret_cast<const f32x4s_t*>(Bi + 192 + 8 * g + 4 * lh);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) stg_so(o5 + (long)(8 * g + q) * len, o5o, a5[4 * g + q] + b5v[q]);
+                        for (int q = 0; q < 4; ++q) {
+                            const float v = comb(a5[4 * g + q], l5[4 * g + q], c, cl) + b5v[q];
+                            stg_so(o5 + (long)(8 * g + q) * len, o5o, v);
+                            m5 = fmaxf(m5, fabsf(v));
+                        }
                     }
                 }
+                mx_run = fmaxf(mx_run, m5);
             }
         }
         // ---- next tile's input: registers -> LDS, then request the one after --------------------------------
         slab_barrier();                                   // every wave is done reading Xs
-        if (next < a.ntiles) {
-            deposit();
-            if (next + (int)gridDim.x < a.ntiles) fetch(next + gridDim.x);
+        if (next < tend) {
+            deposit(bfp_load(a.amax_x, next / a.tiles_per_utt).s);
+            if (next + 1 < tend) fetch(next + 1);
         }
         slab_barrier();
     }
+    if (a.amax_y) amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 228);
 }
 
 template <bool FILM, bool LERP, int RES, bool C5 = false>
 int launch48(tvc_ctx* ctx, hipStream_t s, Conv48Args a, int B) {
     static int ncu_dev[64] = {};
     int& ncu = ncu_dev[ctx->device & 63];
-    constexpr size_t lds = (size_t)(18 * kXP48 + 54 * 64 + (FILM ? 36 * 64 : 0) + (C5 ? 9 * 64 : 0)) * 16 + 224 * 4;
+    constexpr size_t lds = (size_t)(12 * kXP48 + 36 * 64 + (FILM ? 24 * 64 : 0) + (C5 ? 6 * 64 : 0)) * 16 + 240 * 4;
     if (!ncu) {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
@@ -356,8 +408,8 @@ int launch48(tvc_ctx* ctx, hipStream_t s, Conv48Args a, int B) {
 // mode bits: 1 = the input is the low-rate tensor [B][48][lin] (F.interpolate fused into the staging), 2 = FiLM over cond,
 // residual: rlin == 0 and res != nullptr -> direct, rlin > 0 -> F.interpolate(res low-rate)
 int run_conv48s(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int lin, float lscale, const PackedW* film, const float* bsc,
-                const float* bsh, const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil, const PackedW* c5,
-                float* out5) {
+                const float* bsh, const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil, const float* amax_x,
+                const float* amax_c, float* amax_y, const PackedW* c5, float* out5) {
     if (w.cin != kC48 || w.M != kC48 || w.taps != 3 || w.MT6 != 2 || !w.A6) return fail(ctx, TVC_ERR_ARG, "conv48s: 48 -> 48 channel k3 convs only");
     if (dil < 1 || dil > 27) return fail(ctx, TVC_ERR_ARG, "conv48s: dilation must be 1..27");
     if ((long)len * kC48 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "conv48s: utterance too long for 32-bit byte offsets");
@@ -367,6 +419,9 @@ int run_conv48s(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, i
     a.A6 = reinterpret_cast<const u32x4*>(w.A6);
     a.F6 = film ? reinterpret_cast<const u32x4*>(film->A6) : nullptr;
     a.bias = w.bias; a.bsc = bsc; a.bsh = bsh;
+    a.wsc = w.wscale;
+    a.fsc = film ? film->wscale : nullptr;
+    a.amax_x = amax_x; a.amax_c = amax_c; a.amax_y = amax_y;
     a.len = len; a.dil = dil; a.lin = lin; a.rlin = rlin; a.lscale = lscale; a.rscale = rscale;
     if (lin > 0) {
         if (film || res) return fail(ctx, TVC_ERR_ARG, "conv48s: the interpolating variant is a plain conv");
@@ -379,6 +434,7 @@ int run_conv48s(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, i
                 return fail(ctx, TVC_ERR_ARG, "conv48s: the fused c5 is the 48 -> 24 1x1 after the second FiLM");
             a.W5 = reinterpret_cast<const u32x4*>(c5->A6);
             a.b5 = c5->bias;
+            a.w5sc = c5->wscale;
             a.out5 = out5;
             return launch48<true, false, 1, true>(ctx, s, a, B);
         }

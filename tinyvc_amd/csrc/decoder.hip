@@ -5,10 +5,6 @@
 #include "small_kernels.h"
 #include "tvc_common.h"
 
-#ifndef DEC_G2
-#define DEC_G2 1     // the two 768-channel input contractions on the pipelined GEMM kernel (gemm_s2.h)
-#endif
-
 namespace tvc {
 
 // =================================================================================================
@@ -137,12 +133,15 @@ static __global__ void angle_fill_kernel(float* __restrict__ angle, long n, uint
     }
 }
 
-static __global__ void noise_ola_kernel(const float* __restrict__ frames, float* __restrict__ source, int B, int T) {
+// grid (x, B): blockIdx.y = utterance; smax[b] = per-utterance |max| slot of `source` (block-floating-point guard of
+// FilterNet's first conv, conv3s.h): one atomic per workgroup
+static __global__ __launch_bounds__(256) void noise_ola_kernel(const float* __restrict__ frames, float* __restrict__ source, int B, int T, float* __restrict__ smax) {
+    __shared__ float red[4];
     const long L = (long)T * kHop;
-    long total = (long)B * L;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long b = i / L;
-        int p = (int)(i - b * L);
+    const long b = blockIdx.y;
+    float mx = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < L; i += (long)gridDim.x * blockDim.x) {
+        int p = (int)i;
         int q = p + kNfft / 2;  // position in the untrimmed signal; frame f (0..T) covers [480 f, 480 f + 1920)
         int f_hi = q / kHop;
         if (f_hi > T) f_hi = T;
@@ -151,62 +150,77 @@ static __global__ void noise_ola_kernel(const float* __restrict__ frames, float*
         float s = 0.f;
         for (int f = f_lo > 1 ? f_lo : 1; f <= f_hi; ++f)  // frame 0 is the zero pad (decoder.py:81)
             s = __fadd_rn(s, frames[((long)b * T + (f - 1)) * kNfft + (q - f * kHop)]);
-        source[(b * 16 + 15) * L + p] = s / (float)(f_hi - f_lo + 1);
+        const float v = s / (float)(f_hi - f_lo + 1);
+        source[(b * 16 + 15) * L + p] = v;
+        mx = fmaxf(mx, fabsf(v));
     }
+    amax_flush_wg(smax + b, mx, red);
 }
 
 // =================================================================================================
 // SourceNet + dsp
 // =================================================================================================
+// cmax: per-utterance |max| slot of `content` (block-floating-point guard of the fp16 split, conv3s.h)
 static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
-                          const float* energy, float* amps, float* kern, int B, int T) {
+                          const float* energy, float* amps, float* kern, int B, int T, const float* cmax) {
     const int ncols = B * T;
     float* ef = ws.get<float>((size_t)B * T);
     float* x = ws.get<float>((size_t)B * kSrcCh * T);
+    float* xmax = ws.get<float>((size_t)B);
     if (!dry) {
         hipLaunchKernelGGL(window_max_kernel, dim3(grid_for((long)ncols * 64)), dim3(256), 0, s, energy, ef, (long)B, T, kHop);
         EpiSumCond ep{x, ctx->src_content_in.bias, ef, f0, ctx->src_e_w, ctx->src_e_b, ctx->src_f_w, ctx->src_f_b, kSrcCh, T, ncols};
         int rc = 0;
-        if (!(DEC_G2 && gemm_s2_try(&rc, ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep))) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep);
+        if (!gemm_s2_try(&rc, ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep, cmax)) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep, cmax);
         TVC_CHECK(rc);
     }
     for (int i = 0; i < 3; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->src_mid[i], x, B, T));
     if (dry) return 0;
+    TVC_HIP(ctx, hipMemsetAsync(xmax, 0, (size_t)B * sizeof(float), s));
+    TVC_CHECK(run_amax_rows(ctx, s, x, B, (long)kSrcCh * T, xmax));
     // to_amps (128 -> 15 rows: one 32-row m-tile)
     EpiBias<ACT_ELU1, false> ea{amps, ctx->src_to_amps.bias, nullptr, kHarm, T, ncols, (long)kHarm * T, 0};
-    TVC_CHECK((gemm_s_launch<1, 4, 2>(ctx, s, ctx->src_to_amps, x, B, kSrcCh, T, 0, ea)));
+    TVC_CHECK((gemm_s_launch<1, 4, 2>(ctx, s, ctx->src_to_amps, x, B, kSrcCh, T, 0, ea, xmax)));
     // to_kernel (128 -> 961 rows): the one sizeable contraction of the net, on the split-precision path
     EpiBias<ACT_ELU1, false> ek{kern, ctx->src_to_kernel.bias, nullptr, kBins, T, ncols, (long)kBins * T, 0};
-    TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_to_kernel, x, B, kSrcCh, T, 0, ek)));
+    TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_to_kernel, x, B, kSrcCh, T, 0, ek, xmax)));
     return launch_check(ctx, "source_net");
 }
 
 // Decoder.dsp (decoder.py:259-266): f0 [B,1,T], amps [B,15,T], kernel [B,961,T] -> source [B,16,L]
+// smax (nullable): per-utterance |max| slot [B] of `source`, zeroed by the caller; the two kernels that write `source` publish into it
 int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, const float* amps, const float* kern,
-            const float* angle, uint64_t seed, float* source, int B, int T) {
+            const float* angle, uint64_t seed, float* source, int B, int T, float* smax) {
     const long L = (long)T * kHop;
     double* csum = ws.get<double>((size_t)B * kHarm * T);
     float* frames = ws.get<float>((size_t)B * T * kNfft);
     float* ang = angle ? nullptr : ws.get<float>((size_t)B * kBins * T);
+    float* smax_own = smax ? nullptr : ws.get<float>((size_t)B);
     if (dry) return 0;
+    if (!smax) {
+        smax = smax_own;
+        TVC_HIP(ctx, hipMemsetAsync(smax, 0, (size_t)B * sizeof(float), s));
+    }
     // harmonics -> source[:, 0:15]
     const float scale_size = (float)T / (float)L;         // F.interpolate(f0, Lw): size given
     const float scale_amp = (float)(1.0 / (double)kHop);  // F.interpolate(amps, scale_factor=480)
     hipLaunchKernelGGL(harm_frame_sum_kernel, dim3(T, B), dim3(256), 0, s, f0, csum, T, scale_size);
     hipLaunchKernelGGL(harm_frame_scan_kernel, dim3(kHarm, B), dim3(64), 0, s, csum, T);
     hipLaunchKernelGGL(harm_synth_kernel, dim3(T, B), dim3(256), 0, s, f0, amps, csum, source, T, scale_size, scale_amp);
+    // the 15 harmonic rows are sin(.) * voiced gate * interpolated amps: bounded by the amplitudes' own |max| (3 000 values per utterance)
+    TVC_CHECK(run_amax_rows(ctx, s, amps, B, (long)kHarm * T, smax));
     // noise -> source[:, 15]: kernel * exp(i angle) -> inverse 1920-point FFT per frame (fft.hip) -> overlap-add
     if (!angle) {
         hipLaunchKernelGGL(angle_fill_kernel, dim3(grid_for((long)B * kBins * T)), dim3(256), 0, s, ang, (long)B * kBins * T, seed);
         angle = ang;
     }
     TVC_CHECK(run_noise_ifft(ctx, s, kern, angle, frames, B, T));
-    hipLaunchKernelGGL(noise_ola_kernel, dim3(grid_for((long)B * L)), dim3(256), 0, s, frames, source, B, T);
+    hipLaunchKernelGGL(noise_ola_kernel, dim3(grid_for(L / 4, 256, B >= 32 ? 16 : 512 / B), B), dim3(256), 0, s, frames, source, B, T, smax);
     return launch_check(ctx, "dsp");
 }
 
 // =================================================================================================
-// FilterNet (decoder.py:193-233).  Every Conv1d runs on the split-precision bf16x3 MFMA path:
+// FilterNet (decoder.py:193-233).  Every Conv1d runs on the split-precision fp16 MFMA path (conv3s.h):
 //   level (channels @ rate)     kernels
 //   24 @ L        downs[0]      down0s_kernel (+ the 1/5-rate pick Downsample 1 starts from)
 //   24 -> 48 @ L/5  Downsample 1  conv24s_kernel x3 (c3 also accumulates down_res(xi) and writes Downsample 2's 1/4-rate input)
@@ -218,10 +232,13 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
 //   24 @ L        Upsample 4    up24s_kernel x2 (second half = c3, c4, FiLM2, and c5 folded into the k7 output conv)
 // F.interpolate is never materialised: Downsample's 1/f pick / two-sample mean is written by the producing conv's
 // epilogue, Upsample's xf is evaluated while c1 stages its input and again by c2's epilogue for the residual.
+// Every tensor a conv reads has a per-utterance |max| slot (block-floating-point guard of the fp16 split): the producing
+// kernel's epilogue publishes it; tensors finished by an epilogue functor (the c5 GEMMs, content_in) get one pass of amax_rows.
 // The architecture is fixed (the module mirror only accepts the reference's default channels / factors).
 // =================================================================================================
+// cmax / smax (nullable): |max| slots of `content` / of cat[source, energy] if the caller already has them
 int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
-               const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps) {
+               const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps, const float* cmax, const float* smax) {
     const long L = (long)T * kHop;
     static const int ch[5] = {384, 192, 96, 48, 24};
     const long len_dn[5] = {L, L / 5, L / 20, L / 80, L / 240};   // skip i lives at len_dn[i]
@@ -231,16 +248,36 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
     // Downsample i's input = interpolate(skip[i-1], 1/f), written by the conv that produces skip[i-1]
     float* xi_pre[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     for (int i = 1; i <= 4; ++i) xi_pre[i] = ws.get<float>((size_t)B * ctx->downs[i - 1].cin * len_dn[i]);
+    for (int i = 1; i < 4; ++i)
+        if (len_dn[i] % ctx->downs[i].factor != 0 || (ctx->downs[i].factor == 4 && len_dn[i] % 4 != 0))
+            return fail(ctx, TVC_ERR_ARG, "filter_net: level lengths must divide by the next Downsample factor");   // (the epilogues' 1/f-rate copies rely on it)
+
+    // |max| slots, [B] floats each, one memset
+    enum { S_CONTENT = 0, S_SRC, S_X, S_SKIP0, S_DH1 = S_SKIP0 + 5, S_DH2 = S_DH1 + 4, S_UHA = S_DH2 + 4, S_UX1 = S_UHA + 5, S_UHB = S_UX1 + 5, S_UXU = S_UHB + 5,
+           S_LEV = S_UXU + 5, S_COUNT = S_LEV + 5 };
+    float* slots = ws.get<float>((size_t)S_COUNT * B);
+    auto slot = [&](int i) { return slots + (size_t)i * B; };
 
     if (!dry) {
         ProfScope ps(ctx, s, dry, "filter.in+down0");
+        TVC_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)S_COUNT * B * sizeof(float), s));
+        if (!cmax) {
+            TVC_CHECK(run_amax_rows(ctx, s, content, B, (long)kSslDim * T, slot(S_CONTENT)));
+            cmax = slot(S_CONTENT);
+        }
+        if (!smax) {
+            TVC_CHECK(run_amax_rows(ctx, s, source, B, 16 * L, slot(S_SRC)));
+            TVC_CHECK(run_amax_rows(ctx, s, energy, B, L, slot(S_SRC)));
+            smax = slot(S_SRC);
+        }
         EpiSumCond ep{x, ctx->flt_content_in.bias, nullptr, f0, nullptr, nullptr, ctx->flt_f_w, ctx->flt_f_b, ch[0], T, B * T};
         int rc = 0;
-        if (!(DEC_G2 && gemm_s2_try(&rc, ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep))) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep);
+        if (!gemm_s2_try(&rc, ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax)) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax);
         TVC_CHECK(rc);
-        TVC_CHECK(run_down0_split(ctx, s, ctx->flt_down0s, source, energy, skip[0], xi_pre[1], B, (int)L));
+        TVC_CHECK(run_amax_rows(ctx, s, x, B, (long)ch[0] * T, slot(S_X)));
+        TVC_CHECK(run_down0_split(ctx, s, ctx->flt_down0s, source, energy, skip[0], xi_pre[1], B, (int)L, smax, slot(S_SKIP0)));
     }
-    // down path
+    // down path (xi = the 1/f-rate pick / two-sample mean of skip[i-1]: bounded by skip[i-1]'s |max|, same slot)
     for (int i = 1; i <= 4; ++i) {
         const DownW& d = ctx->downs[i - 1];
         const int len = (int)len_dn[i];
@@ -253,20 +290,22 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
             ProfScope ps(ctx, s, dry, names[i - 1]);
             float* y2 = i < 4 ? xi_pre[i + 1] : nullptr;              // the next block's 1/f-rate input
             const int f2 = i < 4 ? ctx->downs[i].factor : 0;
+            const float* mxi = slot(S_SKIP0 + i - 1);
+            float *mh1 = slot(S_DH1 + i - 1), *mh2 = slot(S_DH2 + i - 1), *mout = slot(S_SKIP0 + i);
             if (d.cin == 24) {   // the whole 24-channel block in three conv24s launches; c3 folds down_res(xi) in and writes y2
-                TVC_CHECK(run_down24_split(ctx, s, d, xi, nullptr, h1, h2, skip[i], y2, B, len));
+                TVC_CHECK(run_down24_split(ctx, s, d, xi, h1, h2, skip[i], y2, B, len, mxi, mh1, mh2, mout));
             } else {
                 if (d.cin == 48) {   // weights resident in LDS, one staging round trip per tile (conv48s.hip)
-                    TVC_CHECK(run_conv48s(ctx, s, d.c1, xi, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h1, B, len, 1));
-                    TVC_CHECK(run_conv48s(ctx, s, d.c2, h1, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h2, B, len, 2));
+                    TVC_CHECK(run_conv48s(ctx, s, d.c1, xi, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h1, B, len, 1, mxi, nullptr, mh1));
+                    TVC_CHECK(run_conv48s(ctx, s, d.c2, h1, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h2, B, len, 2, mh1, nullptr, mh2));
                 } else {
-                    TVC_CHECK(conv3s_launch<true>(ctx, s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len}));
-                    TVC_CHECK(conv3s_launch<true>(ctx, s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len}));
+                    TVC_CHECK(conv3s_launch<true>(ctx, s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len}, BfpSlots{mxi, nullptr, mh1}));
+                    TVC_CHECK(conv3s_launch<true>(ctx, s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len}, BfpSlots{mh1, nullptr, mh2}));
                 }
                 // c3 + down_res(xi) as a second K phase on the same accumulators: no residual tensor, no 1x1 launch
                 TVC_CHECK((conv3s_launch<true, C3EpiBiasResConv>(ctx, s, d.c3, h2, B, d.cin, len, 4,
                                                                  C3EpiBiasResConv{{skip[i], d.c3res_bias, nullptr, d.cout, len, y2, f2}},
-                                                                 &d.res, nullptr, xi, d.cin)));
+                                                                 BfpSlots{mh2, mxi, mout}, &d.res, nullptr, xi, d.cin)));
             }
         }
         ws.release(mk);
@@ -281,12 +320,14 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
         }
     }
     long len = T;
+    const float* mx_in = slot(S_X);                                   // |max| slot of the level's input
     for (int i = 0; i < 5; ++i) {
         const UpW& u = ctx->ups[i];
         const int lin = (int)len;
         len *= u.factor;
         const int lo = (int)len, C = u.cin, nc = B * lo;
         const float* cond = skip[4 - i];
+        const float* mcond = slot(S_SKIP0 + 4 - i);
         size_t mk = ws.mark();
         float* xu = ws.get<float>((size_t)B * C * lo);
         float* h = ws.get<float>((size_t)B * C * lo);
@@ -294,7 +335,7 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
         if (!dry && C == 24) {
             // last level: Upsample block + output_layer in two launches, waveform written directly
             ProfScope ps(ctx, s, dry, "filter.up4+out");
-            TVC_CHECK(run_up24_split(ctx, s, u, x, cond, x1, wave, B, lo));
+            TVC_CHECK(run_up24_split(ctx, s, u, x, cond, x1, wave, B, lo, mx_in, mcond, slot(S_UX1 + i)));
         } else if (!dry) {
             static const char* names[4] = {"filter.up0", "filter.up1", "filter.up2", "filter.up3"};
             ProfScope ps(ctx, s, dry, names[i]);
@@ -303,40 +344,45 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
                 const PackedW& ca = half ? u.c3 : u.c1;
                 const PackedW& cb = half ? u.c4 : u.c2;
                 const PackedW& fw = half ? u.film2 : u.film1;      // stacked [to_scale ; to_shift] rows, each group padded to whole 32-row tiles
-                const PackedW& wsc = half ? u.sc2 : u.sc1;
-                const PackedW& wsh = half ? u.sh2 : u.sh1;
+                const float* bsc = fw.bias;                        // its bias row: [b_scale (C) ; b_shift (C)]
+                const float* bsh = fw.bias + C;
                 const int da = half ? 9 : 1, db = half ? 27 : 3;
                 float* xout = half ? xu : x1;   // first half: x1 = FiLM1(c2(c1(xf))) + xf; second half: xu = FiLM2(c4(c3(x1))) + x1
+                const float* ma_in = half ? slot(S_UX1 + i) : mx_in;             // input of the half's first conv
+                float* mh = slot((half ? S_UHB : S_UHA) + i);                    // its output h
+                float* mout = slot((half ? S_UXU : S_UX1) + i);                  // the half's output
                 if (C == 48) {   // LDS-resident weights (conv48s.hip)
                     if (half == 0) {
-                        TVC_CHECK(run_conv48s(ctx, s, ca, x, lin, lscale, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h, B, lo, da));
-                        TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, wsc.bias, wsh.bias, cond, x, lin, lscale, xout, B, lo, db));
+                        TVC_CHECK(run_conv48s(ctx, s, ca, x, lin, lscale, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h, B, lo, da, ma_in, nullptr, mh));
+                        TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, bsc, bsh, cond, x, lin, lscale, xout, B, lo, db, mh, mcond, mout));
                     } else {
-                        TVC_CHECK(run_conv48s(ctx, s, ca, x1, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h, B, lo, da));
-                        // c4 + FiLM2 + residual + c5 (48 -> 24) in one launch: the level's output is written directly
-                        TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, wsc.bias, wsh.bias, cond, x1, 0, 0.f, nullptr, B, lo, db, &u.c5, xlev[i]));
+                        TVC_CHECK(run_conv48s(ctx, s, ca, x1, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h, B, lo, da, ma_in, nullptr, mh));
+                        // c4 + FiLM2 + residual + c5 (48 -> 24) in one launch: the level's output (and its |max|) is written directly
+                        TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, bsc, bsh, cond, x1, 0, 0.f, nullptr, B, lo, db, mh, mcond, slot(S_LEV + i), &u.c5, xlev[i]));
                     }
                 } else if (half == 0) {
                     TVC_CHECK((conv3s_launch<true, C3EpiBias<false>, false, true>(ctx, s, ca, x, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo},
-                                                                                  nullptr, nullptr, nullptr, 0, lin, lscale)));
+                                                                                  BfpSlots{ma_in, nullptr, mh}, nullptr, nullptr, nullptr, 0, lin, lscale)));
                     TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
-                                                                          C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, x, C, lo, lin, lscale},
-                                                                          &fw, &fw, cond, C)));
+                                                                          C3EpiFilmFused{xout, cb.bias, bsc, bsh, x, C, lo, lin, lscale},
+                                                                          BfpSlots{mh, mcond, mout}, &fw, &fw, cond, C)));
                 } else {
-                    TVC_CHECK(conv3s_launch<true>(ctx, s, ca, x1, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo}));
+                    TVC_CHECK(conv3s_launch<true>(ctx, s, ca, x1, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo}, BfpSlots{ma_in, nullptr, mh}));
                     TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
-                                                                          C3EpiFilmFused{xout, cb.bias, wsc.bias, wsh.bias, x1, C, lo},
-                                                                          &fw, &fw, cond, C)));
+                                                                          C3EpiFilmFused{xout, cb.bias, bsc, bsh, x1, C, lo},
+                                                                          BfpSlots{mh, mcond, mout}, &fw, &fw, cond, C)));
                 }
             }
-            if (C != 48) {   // c5 (1x1, C -> C/2) as a split-precision GEMM launch
+            if (C != 48) {   // c5 (1x1, C -> C/2) as a split-precision GEMM launch; its output's |max| in one pass (the functor finishes the elements)
                 EpiBias<ACT_NONE, false> ep{xlev[i], u.c5.bias, nullptr, u.cout, lo, nc, (long)u.cout * lo, 0};
-                if (u.c5.MT6 % 3 == 0) TVC_CHECK((gemm_s_launch<3, 4, 1>(ctx, s, u.c5, xu, B, C, lo, 0, ep)));
-                else TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, u.c5, xu, B, C, lo, 0, ep)));
+                if (u.c5.MT6 % 3 == 0) TVC_CHECK((gemm_s_launch<3, 4, 1>(ctx, s, u.c5, xu, B, C, lo, 0, ep, slot(S_UXU + i))));
+                else TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, u.c5, xu, B, C, lo, 0, ep, slot(S_UXU + i))));
+                TVC_CHECK(run_amax_rows(ctx, s, xlev[i], B, (long)u.cout * lo, slot(S_LEV + i)));
             }
         }
         ws.release(mk);
         x = xlev[i];
+        mx_in = slot(S_LEV + i);
     }
     if (!dry && taps) {   // parity taps: the block outputs are still live in the workspace
         for (int i = 0; i < 5; ++i)
@@ -359,19 +405,27 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
     float* amps = amps_out ? amps_out : ws.get<float>((size_t)B * kHarm * T);
     float* kern = kernel_out ? kernel_out : ws.get<float>((size_t)B * kBins * T);
     float* source = source_out ? source_out : ws.get<float>((size_t)B * 16 * L);
+    // |max| slots shared by the stages: content (SourceNet's and FilterNet's input contraction), cat[source, energy] (FilterNet's first conv)
+    float* cmax = ws.get<float>((size_t)2 * B);
+    float* smax = cmax + B;
+    if (!dry) {
+        TVC_HIP(ctx, hipMemsetAsync(cmax, 0, (size_t)2 * B * sizeof(float), s));
+        TVC_CHECK(run_amax_rows(ctx, s, content, B, (long)kSslDim * T, cmax));
+        TVC_CHECK(run_amax_rows(ctx, s, energy, B, L, smax));
+    }
     size_t mk = ws.mark();
     {
         ProfScope ps(ctx, s, dry, "source_net");
-        TVC_CHECK(run_source_net(ctx, s, ws, dry, content, f0, energy, amps, kern, B, T));
+        TVC_CHECK(run_source_net(ctx, s, ws, dry, content, f0, energy, amps, kern, B, T, cmax));
     }
     ws.release(mk);
     {
         ProfScope ps(ctx, s, dry, "dsp");
-        TVC_CHECK(run_dsp(ctx, s, ws, dry, f0, amps, kern, angle, seed, source, B, T));
+        TVC_CHECK(run_dsp(ctx, s, ws, dry, f0, amps, kern, angle, seed, source, B, T, smax));
     }
     ws.release(mk);
     ProfScope ps(ctx, s, dry, "filter_net");
-    TVC_CHECK(run_filter(ctx, s, ws, dry, content, f0, energy, source, wave, B, T));
+    TVC_CHECK(run_filter(ctx, s, ws, dry, content, f0, energy, source, wave, B, T, nullptr, cmax, smax));
     ws.release(mk);
     return 0;
 }

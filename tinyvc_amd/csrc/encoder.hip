@@ -6,14 +6,8 @@
 
 namespace tvc {
 
-#ifndef ENC_G2
-#define ENC_G2 7     // the ConvNeXt / output 1x1s on the pipelined GEMM kernel (gemm_s2.h); 0 = the conv3s TAPS = 1 launches
-#endif
-#ifndef ENC_NWV
-#define ENC_MTB 4
-#define ENC_NWV 4
-#define ENC_BPC 2
-#endif
+// conv3s tile of the GEMM launches gemm_s2's preconditions exclude (the ragged 961-row input layer): 128 x 128, two workgroups per CU
+constexpr int ENC_MTB = 4, ENC_NWV = 4, ENC_BPC = 2;
 
 // -------------------------------------------------------------------------------------------------
 // [depthwise k7 dilated replicate-padded conv] + LayerNorm over channels, per time column.
@@ -113,9 +107,12 @@ static __global__ void grn_norm_kernel(const float* __restrict__ h, float* __res
 
 // s[b][c] = 1 + gamma[c] * gx[b][c] / (mean_c gx[b][:] + 1e-6)   (one workgroup per utterance):
 // GRN(x) = gamma*(x*nx) + beta + x = x*s + beta; the beta term is folded into the next conv's bias.
+// hmax[b] = max_c gx[b][c] |s[b][c]| >= |h s| anywhere in the utterance (a row's largest magnitude is at most its L2 norm): the
+// |max| slot of the second 1x1's input (block-floating-point guard of the fp16 split), without another pass over h.
 static __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* __restrict__ gx, const float* __restrict__ gamma,
-                                                                  float* __restrict__ nx, int C2) {
+                                                                  float* __restrict__ nx, int C2, float* __restrict__ hmax) {
     __shared__ float red[4];
+    __shared__ float redm[4];
     const int b = blockIdx.x;
     const float* g = gx + (long)b * C2;
     float s = 0.f;
@@ -126,7 +123,17 @@ static __global__ __launch_bounds__(256) void grn_finalize_kernel(const float* _
     __syncthreads();
     const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C2;
     const float den = mean + 1e-6f;
-    for (int c = threadIdx.x; c < C2; c += 256) nx[(long)b * C2 + c] = fmaf(gamma[c], g[c] / den, 1.f);
+    float mx = 0.f;
+    for (int c = threadIdx.x; c < C2; c += 256) {
+        const float f = fmaf(gamma[c], g[c] / den, 1.f);
+        nx[(long)b * C2 + c] = f;
+        mx = fmaxf(mx, g[c] * fabsf(f));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) hmax[b] = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
 }
 
 int run_layernorm(tvc_ctx* ctx, hipStream_t s, float* x, const float* g, const float* b, int B, int C, int T) {
@@ -141,26 +148,35 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     float* h = ws.get<float>((size_t)B * C2 * T);
     float* gx = ws.get<float>((size_t)B * C2);
     float* nx = ws.get<float>((size_t)B * C2);
+    float* ymax = ws.get<float>((size_t)B);      // |max| slots of the two 1x1s' inputs (block-floating-point guard, conv3s.h)
+    float* hmax = ws.get<float>((size_t)B);
     ws.release(mk);
     if (dry) return 0;
     {
         TVC_CHECK(dwconv_ln_launch<true>(ctx, s, x, y, w.dw_w, w.dw_b, w.ln_g, w.ln_b, B, C, T, w.dilation));
     }
     {
+        // the LayerNorm output is bounded by the layer's own gamma / beta whatever the data: no slot unless that bound leaves fp16's range
+        const float* ym = nullptr;
+        if (!(w.ln_bound < 32768.f)) {
+            TVC_HIP(ctx, hipMemsetAsync(ymax, 0, (size_t)B * sizeof(float), s));
+            TVC_CHECK(run_amax_rows(ctx, s, y, B, (long)C * T, ymax));
+            ym = ymax;
+        }
         EpiBias<ACT_GELU, false> ep{h, w.c2.bias, nullptr, C2, T, ncols, (long)C2 * T, 0};
         int rc = 0;
-        if (!((ENC_G2 & 1) && gemm_s2_try(&rc, ctx, s, w.c2, y, B, C, T, 0, ep))) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, w.c2, y, B, C, T, 0, ep);
+        if (!gemm_s2_try(&rc, ctx, s, w.c2, y, B, C, T, 0, ep, ym)) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, w.c2, y, B, C, T, 0, ep, ym);
         TVC_CHECK(rc);
     }
     {
         hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)B * C2 * 64)), dim3(256), 0, s, h, gx, (long)B * C2, T);
-        hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, s, gx, w.grn_g, nx, C2);
+        hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, s, gx, w.grn_g, nx, C2, hmax);
     }
     {
         EpiBias<ACT_NONE, true> ep{x, w.c3_bias_grn, x, C, T, ncols, (long)C * T, (long)C * T};
         int rc = 0;
-        if (!((ENC_G2 & 2) && gemm_s2_try<EpiBias<ACT_NONE, true>, true>(&rc, ctx, s, w.c3, h, B, C2, T, 0, ep, nx)))
-            rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC, EpiBias<ACT_NONE, true>, true>(ctx, s, w.c3, h, B, C2, T, 0, ep, nx);
+        if (!gemm_s2_try<EpiBias<ACT_NONE, true>, true>(&rc, ctx, s, w.c3, h, B, C2, T, 0, ep, hmax, nx))
+            rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC, EpiBias<ACT_NONE, true>, true>(ctx, s, w.c3, h, B, C2, T, 0, ep, hmax, nx);
         TVC_CHECK(rc);
     }
     return launch_check(ctx, "convnext");
@@ -261,10 +277,16 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     float* xs = ws.get<float>((size_t)B * kSslCh * T);
     float* xp = ws.get<float>((size_t)B * kPitchCh * T);
     float* lg = logits ? logits : ws.get<float>((size_t)B * kPitchClasses * T);
+    // |max| slots (block-floating-point guard of the fp16 split, conv3s.h): the spectrogram and the two residual streams the output
+    // projections read; the ConvNeXt layers keep their own (run_convnext)
+    float* slots = ws.get<float>((size_t)3 * B);
+    float *spec_max = slots, *xs_max = slots + B, *xp_max = slots + 2 * B;
     if (!dry) {
+        TVC_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)3 * B * sizeof(float), s));
+        TVC_CHECK(run_amax_rows(ctx, s, spec, B, (long)kBins * T, spec_max));
         EpiSplit ep{xs, xp, ctx->enc_in.bias, kSslCh, kPitchCh, T, ncols};
         // 961 input rows: the last slab is clamped to row 960 (zero weights beyond)
-        TVC_CHECK((gemm_s_launch_ragged<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->enc_in, spec, B, kBins, T, (long)kBins * T, ep)));
+        TVC_CHECK((gemm_s_launch_ragged<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->enc_in, spec, B, kBins, T, (long)kBins * T, ep, spec_max)));
         TVC_CHECK(run_layernorm(ctx, s, xs, ctx->ssl_ln_g, ctx->ssl_ln_b, B, kSslCh, T));
         TVC_CHECK(run_layernorm(ctx, s, xp, ctx->pit_ln_g, ctx->pit_ln_b, B, kPitchCh, T));
     }
@@ -284,9 +306,10 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     }
     for (int i = 0; i < 4; ++i) TVC_CHECK(run_convnext(ctx, sp, ws, dry, ctx->pit_mid[i], xp, B, T));
     if (!dry) {
+        TVC_CHECK(run_amax_rows(ctx, sp, xp, B, (long)kPitchCh * T, xp_max));
         EpiBias<ACT_NONE, false> ep{lg, ctx->pit_out.bias, nullptr, kPitchClasses, T, ncols, (long)kPitchClasses * T, 0};
         int rc = 0;
-        if (!((ENC_G2 & 4) && gemm_s2_try(&rc, ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep))) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep);
+        if (!gemm_s2_try(&rc, ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep, xp_max)) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep, xp_max);
         TVC_CHECK(rc);
         hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(kPdWaves * 64), 0, sp, lg, ctx->pitch_freq, f0, B, T);
     }
@@ -295,9 +318,10 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     if (!wssl.ok()) return fail(ctx, TVC_ERR_WORKSPACE, "encoder: SSL scratch block too small");
     if (dry) return 0;
     {
+        TVC_CHECK(run_amax_rows(ctx, s, xs, B, (long)kSslCh * T, xs_max));
         EpiBias<ACT_NONE, false> ep{ssl, ctx->ssl_out.bias, nullptr, kSslDim, T, ncols, (long)kSslDim * T, 0};
         int rc = 0;
-        if (!((ENC_G2 & 4) && gemm_s2_try(&rc, ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep))) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep);
+        if (!gemm_s2_try(&rc, ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep, xs_max)) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep, xs_max);
         TVC_CHECK(rc);
     }
     if (fork) TVC_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));

@@ -1,20 +1,19 @@
-// Split-precision version of the fused 24-channel full-rate block (FilterNet ups[4] + output_layer,
-// decoder.py:173-190,220,233): same fusion as filter_up24.hip, but every conv / FiLM 1x1 runs on
-// v_mfma_f32_32x32x16_bf16 with both operands split into three bf16 parts (six part-products, fp32-equivalent
-// accuracy: conv3s.h), 2.3x fewer matrix-pipe cycles than the fp32 16x16x4 tiles.
+// The fused 24-channel full-rate block (FilterNet ups[4] + output_layer, decoder.py:173-190,220,233): every conv / FiLM 1x1
+// runs on v_mfma_f32_32x32x16_f16 with both operands split into two fp16 parts (three part-products into an accumulator
+// pair, fp32-equivalent accuracy, block-floating-point range guard: conv3s.h).
 //
 //   half A:  x_up = interp(x, x5) -> lrelu -> c1(d1) -> lrelu -> c2(d3) -> FiLM1(cond) -> + x_up          => x1
 //   half B:  x1 -> lrelu -> c3(d9) -> lrelu -> c4(d27) -> FiLM2(cond) -> + x1 -> [c5 . output k7 folded]   => wave
 //
 // One persistent 8-wave workgroup per CU walks tiles of W output samples.
-//   LDS     Xs[part][8-channel group][position][8 bf16]: lrelu(input tile), split while it is deposited;
+//   LDS     Xs[part][8-channel group][position][8 fp16]: lrelu(input tile), split while it is deposited;
 //           Hs, same layout: lrelu(first conv + bias), split by the first conv's epilogue;
 //           R[24][PS] fp32: the raw input tile (residual); half B overwrites it in place with x2 for the output conv;
 //           Wt: the block's weights, pre-split on the host into MFMA A-lane order (api.hip up24s_half), resident.
 //   K order a 24-channel k3 conv has 9 (tap, 8-channel group) units; a K16 step takes two of them, one per lane half
 //           (5 steps, the 10th unit has zero weights).  A tap is a row offset in Xs / Hs, so every B fragment is one
 //           ds_read_b128 of a contiguous 512-byte run per lane half.
-//   tiles   a wave owns 32 output columns x all 24 (padded 32) rows: 30 MFMAs per conv, 24 for FiLM's scale and shift
+//   tiles   a wave owns 32 output columns x all 24 (padded 32) rows: 15 MFMAs per conv, 12 for FiLM's scale and shift
 //           (cond fragments are loaded from HBM straight into B-fragment order and split in registers).
 //   HBM     per tile: input tile + halo and cond in, one tile out; the next tile's input is in flight in registers
 //           across the whole tile (raw s_barrier: __syncthreads would wait for it).
@@ -27,18 +26,7 @@ namespace tvc {
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 
-#ifndef U24S_ABL
-#define U24S_ABL 0   // timing ablations (wrong results): 1 no S1 MFMA, 2 no S2 conv MFMA, 4 no FiLM MFMA, 8 no deposit, 16 no S1 epilogue, 32 no S4, 64 no fetch, 128 no S2 epilogue
-#endif
-#ifndef U24S_S4VEC
-#define U24S_S4VEC 1   // output conv reads its 10 activations per channel as three 16-byte LDS reads on interior tiles
-#endif
-#ifndef U24S_SWAP
-#define U24S_SWAP 1
-#endif
-#ifndef U24S_WPE
-#define U24S_WPE 2     // 8 waves per CU: 256 registers each
-#endif
+constexpr int U24S_WPE = 2;     // 8 waves per CU: 256 registers each
 
 template <int W_, int D1_, int D2_, bool SECOND_, int E_>
 struct U24S {
@@ -53,8 +41,8 @@ struct U24S {
     static constexpr int XP = XW;
     static constexpr int PS = W2r + 16;                        // fp32 residual tile row stride: 272 = the one stride <= 300 for which the output pass's 16-byte reads (8 lanes x 3 rows apart, 4 columns per lane) are conflict-free in all four ds_read_b128 lane groups (W2r + 4 was 3-way)
     static constexpr int ITEMS = 3 * XW, XPER = (ITEMS + NT - 1) / NT;
-    static constexpr int PIECES = 42, FL = 304;
-    static constexpr int LDS_BYTES = (9 * XP + 9 * HP + PIECES * 64) * 16 + (FL + C * PS) * 4;
+    static constexpr int PIECES = 28, FL = 320;      // floats behind the pieces: the blob's 304, then 8 for the |max| exchange
+    static constexpr int LDS_BYTES = (6 * XP + 6 * HP + PIECES * 64) * 16 + (FL + C * PS) * 4;
     static_assert(NT2 <= NWAVES, "one second-conv tile per wave");
     static_assert(XW - H >= W2, "residual columns");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -67,31 +55,29 @@ struct Up24SArgs {
     const u32x4* img;    // weight blob (api.hip up24s_half)
     int len, xf, tiles_per_utt, ntiles;
     float interp_scale;
+    // block-floating-point guard (conv3s.h): per-utterance |max| slots of x / cond (read, nullable) and of `out` (half A: written, nullable)
+    const float* amax_x;
+    const float* amax_c;
+    float* amax_y;
 };
 
-// three bf16 parts of 4 fp32 values (8 bytes each)
-__device__ __forceinline__ void split4(const float (&v)[4], u32x2& p1, u32x2& p2, u32x2& p3) {
+// two fp16 parts of 4 fp32 values (8 bytes each)
+__device__ __forceinline__ void split4(const float (&v)[4], u32x2& p1, u32x2& p2) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         f32x2 a = {v[2 * j], v[2 * j + 1]};
-        bf16x2 h1 = __builtin_convertvector(a, bf16x2);
-        f32x2 r = a - __builtin_convertvector(h1, f32x2);
-        bf16x2 h2 = __builtin_convertvector(r, bf16x2);
-        f32x2 r2 = r - __builtin_convertvector(h2, f32x2);
-        bf16x2 h3 = __builtin_convertvector(r2, bf16x2);
+        f16x2v h1 = __builtin_convertvector(a, f16x2v);
+        f32x2 r = (a - __builtin_convertvector(h1, f32x2)) * kLoScale;
+        f16x2v h2 = __builtin_convertvector(r, f16x2v);
         p1[j] = __builtin_bit_cast(unsigned, h1);
         p2[j] = __builtin_bit_cast(unsigned, h2);
-        p3[j] = __builtin_bit_cast(unsigned, h3);
     }
 }
-// uniform base (SGPR pair) + 32-bit byte offset per lane: the global_load saddr form, no 64-bit vector address arithmetic
-__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
-// acc += W (.) src over the 9 (tap, group) units of a 24-channel k3 conv for this wave's 32 columns.
-// src = Xs / Hs ([part][group][P rows]), wt = the conv's 15 pieces, col = this lane's column of tap 0, clamped to [lo, hi].
+// (hi, lo) += W (.) src over the 9 (tap, group) units of a 24-channel k3 conv for this wave's 32 columns.
+// src = Xs / Hs ([part][group][P rows]), wt = the conv's 10 pieces, col = this lane's column of tap 0, clamped to [lo_c, hi_c].
 template <int P, int DIL>
-__device__ __forceinline__ void conv24_phase(f32x16& acc, const u32x4* src, const u32x4* wt, int col, int lo, int hi, int lane) {
+__device__ __forceinline__ void conv24_phase(f32x16& hi, f32x16& lo, const u32x4* src, const u32x4* wt, int col, int lo_c, int hi_c, int lane) {
     const int lh = lane >> 5;
     // unit u = 2 s + lh -> tap u / 3, group u % 3 (u = 9: zero weights, any valid row)
     constexpr int TAP0[5] = {0, 0, 1, 2, 2}, GRP0[5] = {0, 2, 1, 0, 2};
@@ -100,15 +86,15 @@ __device__ __forceinline__ void conv24_phase(f32x16& acc, const u32x4* src, cons
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
         int c = col + (lh ? TAP1[s] : TAP0[s]) * DIL;
-        c = c < lo ? lo : (c > hi ? hi : c);
+        c = c < lo_c ? lo_c : (c > hi_c ? hi_c : c);
         row[s] = (lh ? GRP1[s] : GRP0[s]) * P + c;
     }
-    bf16x8 af[2][3], bf[2][3];
+    f16x8 af[2][2], bf[2][2];
     auto frags = [&](int s, int fb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            bf[fb][p] = __builtin_bit_cast(bf16x8, src[p * 3 * P + row[s]]);
-            af[fb][p] = __builtin_bit_cast(bf16x8, wt[(s * 3 + p) * 64 + lane]);
+        for (int p = 0; p < 2; ++p) {
+            bf[fb][p] = __builtin_bit_cast(f16x8, src[p * 3 * P + row[s]]);
+            af[fb][p] = __builtin_bit_cast(f16x8, wt[(s * 2 + p) * 64 + lane]);
         }
     };
     frags(0, 0);
@@ -117,9 +103,9 @@ __device__ __forceinline__ void conv24_phase(f32x16& acc, const u32x4* src, cons
         const int fb = s & 1;
         if (s + 1 < 5) frags(s + 1, fb ^ 1);
         __builtin_amdgcn_sched_barrier(0);   // next step's LDS reads stay above this step's MFMAs
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-        for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][PA[q]], bf[fb][PB[q]], acc, 0, 0, 0);
+        lo = TVC_MFMA16(af[fb][1], bf[fb][0], lo);
+        hi = TVC_MFMA16(af[fb][0], bf[fb][0], hi);
+        lo = TVC_MFMA16(af[fb][0], bf[fb][1], lo);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -130,9 +116,9 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     constexpr int XP = CF::XP, HP = CF::HP, PS = CF::PS, XW = CF::XW, XPER = CF::XPER;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u[];
     u32x4* Xs = reinterpret_cast<u32x4*>(smem_u);
-    u32x4* Hs = Xs + 9 * XP;
-    u32x4* Wt = Hs + 9 * HP;
-    float* Fl = reinterpret_cast<float*>(Wt + CF::PIECES * 64);   // ba, bb, bsc, bsh [32 each], w75 [24][7], b75
+    u32x4* Hs = Xs + 6 * XP;
+    u32x4* Wt = Hs + 6 * HP;
+    float* Fl = reinterpret_cast<float*>(Wt + CF::PIECES * 64);   // ba, bb, bsc, bsh [32 each], w75 [24][7], b75, weight scales [297..300], the bound constants [301], [302]
     float* R = Fl + CF::FL;                                       // [24][PS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -140,7 +126,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     const int lin = CF::SECOND ? len : len / a.xf;
 
     // ---- once per workgroup: weights and biases -> LDS -------------------------------------------------
-    for (int i = tid; i < CF::PIECES * 64 + CF::FL / 4; i += NT) Wt[i] = a.img[i];
+    for (int i = tid; i < CF::PIECES * 64 + 304 / 4; i += NT) Wt[i] = a.img[i];
 
     // ---- input tile staging: an item = 8 channels of one position ---------------------------------------
     // Per-thread item geometry is tile-invariant; global addresses are a uniform per-channel base (SGPRs) plus one 32-bit
@@ -180,7 +166,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
             }
         }
     };
-    auto deposit = [&]() __attribute__((always_inline)) {
+    auto deposit = [&](float xs) __attribute__((always_inline)) {      // xs = the tile's block-floating-point input scale
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
             if (!ilive[i]) continue;
@@ -200,28 +186,42 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 for (int j = 0; j < 8; ++j) R[(ig8[i] + j) * PS + rc] = v[j];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.1f * v[j]);   // = leaky_relu(x, 0.1)
-            uint4 p1, p2, p3;
-            split8(v, p1, p2, p3);
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.1f * v[j]) * xs;   // = leaky_relu(x, 0.1), scaled
+            uint4 p1, p2;
+            split8(v, p1, p2);
             Xs[(0 + g) * XP + c] = __builtin_bit_cast(u32x4, p1);
             Xs[(3 + g) * XP + c] = __builtin_bit_cast(u32x4, p2);
-            Xs[(6 + g) * XP + c] = __builtin_bit_cast(u32x4, p3);
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile < a.ntiles) {
+    // persistent: a contiguous range of tiles per workgroup (one or two utterances: x1's |max| slot is published once per
+    // utterance and workgroup, conv3s.h amax_flush_wg)
+    int tile, tend;
+    tile_range(a.ntiles, tile, tend);
+    if (tile < tend) {
         fetch(tile);
-        deposit();
+        deposit(bfp_load(a.amax_x, tile / a.tiles_per_utt).s);
     }
     slab_barrier();
+    const float wsa = Fl[297], wsb = Fl[298], wssc = Fl[299], wssh = Fl[300], wl1 = Fl[301], bamax = Fl[302];
+    float mx_run = 0.f;
+    int mx_b = tile < tend ? tile / a.tiles_per_utt : 0;
 
-    for (; tile < a.ntiles; tile += gridDim.x) {
+    for (; tile < tend; ++tile) {
         const int b = tile / a.tiles_per_utt;
+        if (!CF::SECOND && a.amax_y && b != mx_b) {
+            amax_flush_wg(a.amax_y + mx_b, mx_run, Fl + 304);
+            mx_run = 0.f;
+            mx_b = b;
+        }
+        // block-floating-point scales: input (per-utterance |max| slot), cond, and the on-chip intermediate h = lrelu(conv_a + b_a),
+        // bounded by sum|w_a| * amax_x + max|b_a| (never measured: it does not leave the CU)
+        const Bfp sx = bfp_load(a.amax_x, b), sc = bfp_load(a.amax_c, b);
+        const Bfp sh_ = a.amax_x ? bfp_from_amax(fmaf(wl1, a.amax_x[b], bamax)) : Bfp{1.f, 1.f};
         const int t0 = (tile - b * a.tiles_per_utt) * W;
         const int ph0 = t0 - E - D2;      // position of Hs column 0
         const int p20 = t0 - E;           // position of second-conv column 0
-        const int next = tile + gridDim.x;
+        const int next = tile + 1;
 
         // FiLM cond of this wave's second-conv tile, straight into B-fragment order: step 0 = channels 8 lh + j,
         // step 1 = channels 16 + j for lh = 0 (the other half is the zero unit)
@@ -237,53 +237,36 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 cr1[j] = ldg_so(cb + (long)(16 + j) * len, o1);
             }
         }
-        if (next < a.ntiles && !(U24S_ABL & 64)) fetch(next);   // lands in registers during the whole tile
+        if (next < tend) fetch(next);   // lands in registers during the whole tile
 
         // ---- S1: Hs = split(lrelu(conv_a(lrelu(x)) + ba)) ---------------------------------------------
         for (int nt = wave; nt < CF::NT1; nt += CF::NWAVES) {
-            f32x16 acc;
+            f32x16 acc, alo;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = alo[r] = 0.f;
             const int h = nt * 32 + l31;
-            if (!(U24S_ABL & 1)) conv24_phase<XP, D1>(acc, Xs, Wt, h, 0, XW - 1, lane);      // Xs already holds the replicate-padded input
-            u32x2 p3s[3];
+            conv24_phase<XP, D1>(acc, alo, Xs, Wt, h, 0, XW - 1, lane);      // Xs already holds the replicate-padded input
+            const float c = wsa * sx.inv, cl = c * kLoInv;
 #pragma unroll
-            for (int g = 0; g < ((U24S_ABL & 16) ? 0 : 3); ++g) {
+            for (int g = 0; g < 3; ++g) {
                 const f32x4s bv = *reinterpret_cast<const f32x4s*>(Fl + 8 * g + 4 * lh);
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float t = acc[4 * g + q] + bv[q];
-                    v[q] = fmaxf(t, 0.1f * t);
+                    const float t = comb(acc[4 * g + q], alo[4 * g + q], c, cl) + bv[q];
+                    v[q] = fmaxf(t, 0.1f * t) * sh_.s;
                 }
-                u32x2 p1, p2, p3;
-                split4(v, p1, p2, p3);
-                u32x2* hrow = reinterpret_cast<u32x2*>(Hs);
-#if U24S_SWAP
+                u32x2 p1, p2;
+                split4(v, p1, p2);
                 // A position's 16-byte row = [lanes 0-31's four channels | lanes 32-63's four].  Two 8-byte stores per row from the two
                 // lane halves are 2-way bank conflicts (16-byte stride inside a 16-lane store group); v_permlane32_swap hands the lower
                 // half of the wave both halves of the part-1 row and the upper half both halves of the part-2 row: one 16-byte store
-                // each, conflict-free.  Part 3 keeps its 8-byte stores.
-                const auto sx = __builtin_amdgcn_permlane32_swap(p1[0], p2[0], false, false);
-                const auto sy = __builtin_amdgcn_permlane32_swap(p1[1], p2[1], false, false);
-                const u32x4 row = {sx[0], sy[0], sx[1], sy[1]};
+                // each, conflict-free.
+                const auto qx = __builtin_amdgcn_permlane32_swap(p1[0], p2[0], false, false);
+                const auto qy = __builtin_amdgcn_permlane32_swap(p1[1], p2[1], false, false);
+                const u32x4 row = {qx[0], qy[0], qx[1], qy[1]};
                 *reinterpret_cast<u32x4*>(Hs + (3 * lh + g) * HP + h) = row;
-                p3s[g] = p3;
-#else
-                hrow[((0 + g) * HP + h) * 2 + lh] = p1;
-                hrow[((3 + g) * HP + h) * 2 + lh] = p2;
-                hrow[((6 + g) * HP + h) * 2 + lh] = p3;
-#endif
             }
-#if U24S_SWAP
-            if (!(U24S_ABL & 16)) {   // part 3: the rows of channel groups 0 and 1 the same way (lower half -> group 0, upper half -> group 1), group 2 as two 8-byte stores
-                const auto sx = __builtin_amdgcn_permlane32_swap(p3s[0][0], p3s[1][0], false, false);
-                const auto sy = __builtin_amdgcn_permlane32_swap(p3s[0][1], p3s[1][1], false, false);
-                const u32x4 row = {sx[0], sy[0], sx[1], sy[1]};
-                *reinterpret_cast<u32x4*>(Hs + (6 + lh) * HP + h) = row;
-                reinterpret_cast<u32x2*>(Hs)[((6 + 2) * HP + h) * 2 + lh] = p3s[2];
-            }
-#endif
         }
         slab_barrier();
 
@@ -291,62 +274,82 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         if (wave < CF::NT2) {
             const int n = wave * 32 + l31;
             const int t = p20 + n;
-            bf16x8 cf[2][3];
+            f16x8 cf[2][2];
             {
-                uint4 p1, p2, p3;
-                split8(cr0, p1, p2, p3);
-                cf[0][0] = __builtin_bit_cast(bf16x8, p1);
-                cf[0][1] = __builtin_bit_cast(bf16x8, p2);
-                cf[0][2] = __builtin_bit_cast(bf16x8, p3);
-                split8(cr1, p1, p2, p3);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    cr0[j] *= sc.s;
+                    cr1[j] *= sc.s;
+                }
+                uint4 p1, p2;
+                split8(cr0, p1, p2);
+                cf[0][0] = __builtin_bit_cast(f16x8, p1);
+                cf[0][1] = __builtin_bit_cast(f16x8, p2);
+                split8(cr1, p1, p2);
                 const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-                cf[1][0] = __builtin_bit_cast(bf16x8, lh ? z : p1);
-                cf[1][1] = __builtin_bit_cast(bf16x8, lh ? z : p2);
-                cf[1][2] = __builtin_bit_cast(bf16x8, lh ? z : p3);
+                cf[1][0] = __builtin_bit_cast(f16x8, lh ? z : p1);
+                cf[1][1] = __builtin_bit_cast(f16x8, lh ? z : p2);
             }
-            f32x16 acc, asc, ash;
+            const float cb = wsb * sh_.inv, cbl = cb * kLoInv, c1 = wssc * sc.inv, c1l = c1 * kLoInv, c2 = wssh * sc.inv, c2l = c2 * kLoInv;
+            float hv[3][4];                                                        // conv_b + b_b of this lane's 12 real rows
+            {
+                f32x16 acc, alo;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = asc[r] = ash[r] = 0.f;
-            const int lo = -ph0 > 0 ? -ph0 : 0;                                    // the layer's own replicate padding
-            const int hi = (len - 1 - ph0) < (HP - 1) ? (len - 1 - ph0) : (HP - 1);
-            if (!(U24S_ABL & 2)) conv24_phase<HP, D2>(acc, Hs, Wt + 15 * 64, n, lo, hi, lane);
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+                for (int r = 0; r < 16; ++r) acc[r] = alo[r] = 0.f;
+                const int lo = -ph0 > 0 ? -ph0 : 0;                                // the layer's own replicate padding
+                const int hi = (len - 1 - ph0) < (HP - 1) ? (len - 1 - ph0) : (HP - 1);
+                conv24_phase<HP, D2>(acc, alo, Hs, Wt + 10 * 64, n, lo, hi, lane);
 #pragma unroll
-            for (int s = 0; s < ((U24S_ABL & 4) ? 0 : 2); ++s) {
-                bf16x8 fa[2][3];
+                for (int g = 0; g < 3; ++g) {
+                    const f32x4s bb = *reinterpret_cast<const f32x4s*>(Fl + 32 + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hv[g][q] = comb(acc[4 * g + q], alo[4 * g + q], cb, cbl) + bb[q];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // the conv's accumulator pair is dead before FiLM's two pairs come alive
+            f32x16 asc, lsc, ash, lsh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asc[r] = lsc[r] = ash[r] = lsh[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 fa[2][2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) fa[mt][p] = __builtin_bit_cast(bf16x8, Wt[(30 + (s * 2 + mt) * 3 + p) * 64 + lane]);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    asc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][PA[q]], cf[s][PB[q]], asc, 0, 0, 0);
-                    ash = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][PA[q]], cf[s][PB[q]], ash, 0, 0, 0);
-                }
+                    for (int p = 0; p < 2; ++p) fa[mt][p] = __builtin_bit_cast(f16x8, Wt[(20 + (s * 2 + mt) * 2 + p) * 64 + lane]);
+                lsc = TVC_MFMA16(fa[0][1], cf[s][0], lsc);
+                lsh = TVC_MFMA16(fa[1][1], cf[s][0], lsh);
+                asc = TVC_MFMA16(fa[0][0], cf[s][0], asc);
+                ash = TVC_MFMA16(fa[1][0], cf[s][0], ash);
+                lsc = TVC_MFMA16(fa[0][0], cf[s][1], lsc);
+                lsh = TVC_MFMA16(fa[1][0], cf[s][1], lsh);
             }
             float* ob = CF::SECOND ? nullptr : a.out + (long)b * C * len;
             const unsigned oo = 4u * (unsigned)(4 * lh * len + t);
+            float mx = 0.f;
 #pragma unroll
-            for (int g = 0; g < ((U24S_ABL & 128) ? 0 : 3); ++g) {
-                const f32x4s bb = *reinterpret_cast<const f32x4s*>(Fl + 32 + 8 * g + 4 * lh);
+            for (int g = 0; g < 3; ++g) {
                 const f32x4s bs = *reinterpret_cast<const f32x4s*>(Fl + 64 + 8 * g + 4 * lh);
                 const f32x4s bh = *reinterpret_cast<const f32x4s*>(Fl + 96 + 8 * g + 4 * lh);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int m = 8 * g + 4 * lh + q;
-                    const float hval = acc[4 * g + q] + bb[q];
-                    const float sc = asc[4 * g + q] + bs[q];
-                    const float sh = ash[4 * g + q] + bh[q];
+                    const float hval = hv[g][q];
+                    const float scv = comb(asc[4 * g + q], lsc[4 * g + q], c1, c1l) + bs[q];
+                    const float shv = comb(ash[4 * g + q], lsh[4 * g + q], c2, c2l) + bh[q];
                     const float res = R[m * PS + n];
-                    const float v = __fadd_rn(__fadd_rn(__fmul_rn(hval, sc), sh), res);
+                    const float v = __fadd_rn(__fadd_rn(__fmul_rn(hval, scv), shv), res);
                     if (CF::SECOND)
                         R[m * PS + n] = v;                                     // x2 stays on chip
-                    else if (n < W && t < len)
+                    else if (n < W && t < len) {
                         stg_so(ob + (long)(8 * g + q) * len, oo, v);           // x1 (uniform row base + lane offset)
+                        mx = fmaxf(mx, fabsf(v));
+                    }
                 }
             }
+            mx_run = fmaxf(mx_run, mx);
         }
-        if (CF::SECOND && !(U24S_ABL & 32)) {
+        if (CF::SECOND) {
             slab_barrier();
             // ---- S4: c5 and output_layer folded into one Conv1d(24 -> 1, k7, replicate) on the parked x2 tile ----
             // 8 lanes per group of 4 consecutive outputs, 3 channels each: per channel 10 activations and 7
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                     for (int cc = 0; cc < 3; ++cc) {
                         const int c = part * 3 + cc;
                         float xv[10], wv[7];
-                        if (U24S_S4VEC && E == 3 && interior) {   // columns 4 g .. 4 g + 11 of the row: three 16-byte reads instead of ten 4-byte ones
+                        if (E == 3 && interior) {   // columns 4 g .. 4 g + 11 of the row: three 16-byte reads instead of ten 4-byte ones
                             const f32x4s* rp = reinterpret_cast<const f32x4s*>(R + c * PS + 4 * g);
                             const f32x4s r0 = rp[0], r1 = rp[1], r2 = rp[2];
                             xv[0] = r0[0]; xv[1] = r0[1]; xv[2] = r0[2]; xv[3] = r0[3];
@@ -401,9 +404,10 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         }
         // ---- next tile's input: registers -> LDS ----------------------------------------------------------
         slab_barrier();                                   // every wave is done with Xs, Hs and R
-        if (next < a.ntiles && !(U24S_ABL & 8)) deposit();
+        if (next < tend) deposit(bfp_load(a.amax_x, next / a.tiles_per_utt).s);
         slab_barrier();
     }
+    if (!CF::SECOND && a.amax_y && tend > (int)((long)a.ntiles * blockIdx.x / gridDim.x)) amax_flush_wg(a.amax_y + mx_b, mx_run, Fl + 304);
 }
 
 template <class CF>
@@ -425,16 +429,13 @@ static int launch_up24s(tvc_ctx* ctx, hipStream_t s, Up24SArgs a, int B) {
     return launch_check(ctx, "up24s");
 }
 
-#ifndef U24S_WA
-#define U24S_WA 250
-#endif
-#ifndef U24S_WB
-#define U24S_WB 250
-#endif
+constexpr int U24S_WA = 250, U24S_WB = 250;     // output samples per tile of the two halves
 
 // Upsample block with cin == 24 followed by FilterNet.output_layer:
 // x [B][24][len/f], cond [B][24][len] -> wave [B][len]; x1 is scratch [B][24][len].
-int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, const float* cond, float* x1, float* wave, int B, int len) {
+// amax_x / amax_c: per-utterance |max| slots of x / cond; amax_x1: scratch slot [B] (zeroed) for the block's intermediate x1.
+int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, const float* cond, float* x1, float* wave, int B, int len,
+                   const float* amax_x, const float* amax_c, float* amax_x1) {
     if (!u.s24a || !u.s24b) return fail(ctx, TVC_ERR_STATE, "up24s: the split weight blobs of the 24-channel block are missing");
     if ((long)len * 24 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "up24s: utterance too long for 32-bit element offsets");
     using CA = U24S<U24S_WA, 1, 3, false, 0>;
@@ -444,12 +445,17 @@ int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, co
     a.xf = u.factor;
     a.interp_scale = (float)(1.0 / (double)u.factor);
     a.cond = cond;
+    a.amax_c = amax_c;
     a.x = x;
+    a.amax_x = amax_x;
     a.out = x1;
+    a.amax_y = amax_x1;
     a.img = reinterpret_cast<const u32x4*>(u.s24a);
     TVC_CHECK(launch_up24s<CA>(ctx, s, a, B));
     a.x = x1;
+    a.amax_x = amax_x1;
     a.out = wave;
+    a.amax_y = nullptr;
     a.img = reinterpret_cast<const u32x4*>(u.s24b);
     return launch_up24s<CB>(ctx, s, a, B);
 }
@@ -457,7 +463,7 @@ int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, co
 // ---------------------------------------------------------------------------------------------------------------------
 // FilterNet.downs[0] (decoder.py:206,224,227): Conv1d(17 -> 24, k3, replicate) over cat[source (16 ch), energy (1 ch)] at
 // the full sample rate, on the same split-precision machinery: the 17 channels are three 8-channel groups (rows 17..23
-// zero), 9 (tap, group) units = 5 K16 steps, 30 MFMAs per 32 samples.  HBM-bound (reads 17 rows, writes 24 + the
+// zero), 9 (tap, group) units = 5 K16 steps, 15 MFMAs per 32 samples.  HBM-bound (reads 17 rows, writes 24 + the
 // 1/5-rate copy Downsample 1 starts from): persistent workgroups, two LDS input tiles, the input of tile i + 2 in flight in
 // registers while tile i multiplies, one barrier per tile.
 struct Down0SArgs {
@@ -465,20 +471,22 @@ struct Down0SArgs {
     const float* energy;   // [B][1][L]
     float* out;            // [B][24][L]
     float* y2;             // optional [B][24][L / 5]: F.interpolate(out, scale_factor = 1/5) = the sample at 5 d + 2
-    const u32x4* img;      // 15 weight pieces + 32 bias floats (api.hip down0s)
+    const u32x4* img;      // 10 weight pieces + 32 floats: bias, [31] = the image's scale (api.hip down0s)
     int len, tiles_per_utt, ntiles;
+    const float* amax_x;   // per-utterance |max| of cat[source, energy] (block-floating-point guard, conv3s.h), nullable
+    float* amax_y;         // ... of the output (written), nullable
 };
 
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void down0s_kernel(Down0SArgs a) {
     constexpr int W = 254, XW = 256, XP = XW, NT = 512;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_d[];
-    u32x4* Xs = reinterpret_cast<u32x4*>(smem_d);              // [2 buffers][3 parts][3 groups][XP]
-    u32x4* Wt = Xs + 2 * 9 * XP;                               // 15 pieces
-    float* Bi = reinterpret_cast<float*>(Wt + 15 * 64);        // bias [32]
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem_d);              // [2 buffers][2 parts][3 groups][XP]
+    u32x4* Wt = Xs + 2 * 6 * XP;                               // 10 pieces
+    float* Bi = reinterpret_cast<float*>(Wt + 10 * 64);        // bias [32] ([31] = weight scale), [32..39] = |max| exchange
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int len = a.len;
-    for (int i = tid; i < 15 * 64 + 8; i += NT) Wt[i] = a.img[i];
+    for (int i = tid; i < 10 * 64 + 8; i += NT) Wt[i] = a.img[i];
 
     // staging: thread -> (group tid >> 8 of the 16 source rows, column tid & 255); threads 0..255 also carry the energy row
     const int g = tid >> 8, c = tid & 255;
@@ -493,41 +501,52 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
         for (int j = 0; j < 8; ++j) xa[j] = ldg_so(sb + (long)j * len, o);
         xe = ldg_so(a.energy + (long)b * len, 4u * (unsigned)p);
     };
-    auto deposit = [&](int buf) __attribute__((always_inline)) {
-        u32x4* X = Xs + buf * 9 * XP;
-        uint4 p1, p2, p3;
-        split8(xa, p1, p2, p3);
+    auto deposit = [&](int buf, float xs) __attribute__((always_inline)) {
+        u32x4* X = Xs + buf * 6 * XP;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xa[j] *= xs;
+        uint4 p1, p2;
+        split8(xa, p1, p2);
         X[(0 + g) * XP + c] = __builtin_bit_cast(u32x4, p1);
         X[(3 + g) * XP + c] = __builtin_bit_cast(u32x4, p2);
-        X[(6 + g) * XP + c] = __builtin_bit_cast(u32x4, p3);
         if (tid < 256) {                                       // group 2 = [energy, 0 x 7]
-            const float ve[8] = {xe, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            split8(ve, p1, p2, p3);
+            const float ve[8] = {xe * xs, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            split8(ve, p1, p2);
             X[(0 + 2) * XP + c] = __builtin_bit_cast(u32x4, p1);
             X[(3 + 2) * XP + c] = __builtin_bit_cast(u32x4, p2);
-            X[(6 + 2) * XP + c] = __builtin_bit_cast(u32x4, p3);
         }
     };
 
-    int tile = blockIdx.x, cur = 0;
-    if (tile >= a.ntiles) return;
+    int tile, tend, cur = 0;                             // a contiguous range of tiles per workgroup (amax_flush_wg, conv3s.h)
+    tile_range(a.ntiles, tile, tend);
+    if (tile >= tend) return;
     fetch(tile);
-    deposit(0);
-    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+    deposit(0, bfp_load(a.amax_x, tile / a.tiles_per_utt).s);
+    if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
     const int len2 = len / 5;
-    for (; tile < a.ntiles; tile += gridDim.x, cur ^= 1) {
+    const float cw = Bi[31];
+    float mx_run = 0.f;
+    int mx_b = tile / a.tiles_per_utt;
+    for (; tile < tend; ++tile, cur ^= 1) {
         const int b = tile / a.tiles_per_utt;
+        if (a.amax_y && b != mx_b) {
+            amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 32);
+            mx_run = 0.f;
+            mx_b = b;
+        }
         const int t0 = (tile - b * a.tiles_per_utt) * W;
-        const int next = tile + gridDim.x, next2 = next + gridDim.x;
-        if (next < a.ntiles) deposit(cur ^ 1);            // tile i + 1 (requested one tile ago) -> the other buffer
-        if (next2 < a.ntiles) fetch(next2);               // tile i + 2 flies across this tile
-        f32x16 acc;
+        const int next = tile + 1, next2 = next + 1;
+        if (next < tend) deposit(cur ^ 1, bfp_load(a.amax_x, next / a.tiles_per_utt).s);            // tile i + 1 (requested one tile ago) -> the other buffer
+        if (next2 < tend) fetch(next2);               // tile i + 2 flies across this tile
+        f32x16 acc, alo;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = alo[r] = 0.f;
         const int n = wave * 32 + l31;
-        conv24_phase<XP, 1>(acc, Xs + cur * 9 * XP, Wt, n, 0, XW - 1, lane);
+        conv24_phase<XP, 1>(acc, alo, Xs + cur * 6 * XP, Wt, n, 0, XW - 1, lane);
+        const float cc = cw * bfp_load(a.amax_x, b).inv, ccl = cc * kLoInv;
         const int t = t0 + n;
+        float mx = 0.f;
         if (n < W && t < len) {
             float* ob = a.out + (long)b * 24 * len;
             const unsigned oo = 4u * (unsigned)(4 * lh * len + t);
@@ -538,23 +557,27 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
                 const f32x4s bv = *reinterpret_cast<const f32x4s*>(Bi + 8 * gg + 4 * lh);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = acc[4 * gg + q] + bv[q];
+                    const float v = comb(acc[4 * gg + q], alo[4 * gg + q], cc, ccl) + bv[q];
                     stg_so(ob + (long)(8 * gg + q) * len, oo, v);
+                    mx = fmaxf(mx, fabsf(v));
                     if (pick) a.y2[((long)b * 24 + 8 * gg + 4 * lh + q) * len2 + q5] = v;
                 }
             }
         }
+        mx_run = fmaxf(mx_run, mx);
         slab_barrier();
     }
+    if (a.amax_y) amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 32);
 }
 
-int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len) {
+int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len,
+                    const float* amax_x, float* amax_y) {
     if (!blob) return fail(ctx, TVC_ERR_STATE, "down0s: the split weight blob of downs.0 is missing");
     if ((long)len * 24 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "down0s: utterance too long for 32-bit byte offsets");
     if (y2 && len % 5 != 0) return fail(ctx, TVC_ERR_ARG, "down0s: the 1/5-rate copy needs len % 5 == 0");
     static int ncu_dev[64] = {};
     int& ncu = ncu_dev[ctx->device & 63];
-    constexpr size_t lds = (2 * 9 * 256 + 15 * 64 + 8) * 16;
+    constexpr size_t lds = (2 * 6 * 256 + 10 * 64 + 8 + 2) * 16;
     if (!ncu) {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
@@ -562,7 +585,7 @@ int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float*
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "down0s setup: %s", hipGetErrorString(e));
         ncu = prop.multiProcessorCount;
     }
-    Down0SArgs a{source, energy, out, y2, reinterpret_cast<const u32x4*>(blob), len, (len + 253) / 254, 0};
+    Down0SArgs a{source, energy, out, y2, reinterpret_cast<const u32x4*>(blob), len, (len + 253) / 254, 0, amax_x, amax_y};
     a.ntiles = a.tiles_per_utt * B;
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     hipLaunchKernelGGL(down0s_kernel, dim3(grid), dim3(512), lds, s, a);
@@ -571,35 +594,40 @@ int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float*
 
 // ---------------------------------------------------------------------------------------------------------------------
 // One 24-input-channel k3 conv (Downsample 1's c1 / c2 / c3, decoder.py:143-158) on the same machinery: 24 -> 24 (one
-// m-tile) or 24 -> 48 (two), optional leaky_relu on the input, optional residual, optional 1/4-rate copy for the next
-// Downsample block (mean of samples 4 d + 1 and 4 d + 2, see C3EpiBias).  Persistent, double-buffered input tiles.
-// RES: 0 none, 1 a residual tensor is added, 2 the residual is a 1x1 conv of a second 24-channel tensor (Downsample's
-// down_res(xi)), accumulated on the same tile from B fragments loaded straight from HBM
-template <int MT_, int DIL_, bool LRELU_, int RES_>
+// m-tile) or 24 -> 48 (two), optional leaky_relu on the input, optional 1/4-rate copy for the next Downsample block (mean of
+// samples 4 d + 1 and 4 d + 2, see C3EpiBias).  Persistent, double-buffered input tiles.
+// RESCONV: the block's residual down_res(xi), a 1x1 conv of a second 24-channel tensor, is accumulated on the same tile from B
+// fragments loaded straight from HBM (the two weight images share their per-m-tile scales, the two inputs the smaller of their
+// block-floating-point scales: one accumulator pair, one unit).
+template <int MT_, int DIL_, bool LRELU_, bool RESCONV_>
 struct C24S {
-    static constexpr int MT = MT_, DIL = DIL_, RES = RES_;
-    static constexpr bool LRELU = LRELU_;
+    static constexpr int MT = MT_, DIL = DIL_;
+    static constexpr bool LRELU = LRELU_, RESCONV = RESCONV_;
     static constexpr int XW = 256, XP = XW, W = (XW - 2 * DIL) / 4 * 4, NT = 512;
-    static constexpr int PIECES = 15 * MT, RPIECES = RES == 2 ? 6 * MT : 0, FL = 64;
-    static constexpr int LDS_BYTES = (2 * 9 * XP + (PIECES + RPIECES) * 64) * 16 + FL * 4;
+    static constexpr int PIECES = 10 * MT, RPIECES = RESCONV ? 4 * MT : 0, FL = 64;      // + 8 floats behind FL for the |max| exchange
+    static constexpr int LDS_BYTES = (2 * 6 * XP + (PIECES + RPIECES) * 64) * 16 + (FL + 8) * 4;
     static_assert(W % 4 == 0, "the 1/4-rate copy pairs samples inside a tile");
 };
 struct Conv24SArgs {
     const float* x;        // [B][24][len]
-    const float* res;      // RES 1: [B][M][len]; RES 2: the second input xi [B][24][len]
-    const u32x4* rimg;     // RES 2: the 1x1's image (PackedW::A6 of a 24-input 1x1: [2 steps][MT][3 parts])
+    const float* res;      // RESCONV: the second input xi [B][24][len]
+    const u32x4* rimg;     // RESCONV: the 1x1's image (PackedW::A6 of a 24-input 1x1: [2 steps][MT][2 parts])
     float* out;            // [B][M][len]
     float* y2;             // optional [B][M][len / 4]
-    const u32x4* img;      // 15 * MT weight pieces [step][m-tile][part], then 64 bias floats
+    const u32x4* img;      // 10 * MT weight pieces [step][m-tile][part], then 64 floats: bias, [62 + mt] = the m-tiles' scales
     int M, len, tiles_per_utt, ntiles;
+    // block-floating-point guard (conv3s.h): per-utterance |max| slots of x / xi (read, nullable) and of the output (written, nullable)
+    const float* amax_x;
+    const float* amax_r;
+    float* amax_y;
 };
 
 template <class CF>
 __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) void conv24s_kernel(Conv24SArgs a) {
     constexpr int W = CF::W, XW = CF::XW, XP = CF::XP, NT = CF::NT, MT = CF::MT, DIL = CF::DIL;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_c[];
-    u32x4* Xs = reinterpret_cast<u32x4*>(smem_c);              // [2 buffers][3 parts][3 groups][XP]
-    u32x4* Wt = Xs + 2 * 9 * XP;
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem_c);              // [2 buffers][2 parts][3 groups][XP]
+    u32x4* Wt = Xs + 2 * 6 * XP;
     u32x4* Wr = Wt + CF::PIECES * 64;
     float* Bi = reinterpret_cast<float*>(Wr + CF::RPIECES * 64);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -609,6 +637,10 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) voi
     for (int i = tid; i < CF::RPIECES * 64; i += NT) Wr[i] = a.rimg[i];
     for (int i = tid; i < CF::FL; i += NT) Bi[i] = reinterpret_cast<const float*>(a.img + CF::PIECES * 64)[i];
 
+    auto scale_of = [&](int b) __attribute__((always_inline)) -> Bfp {
+        const Bfp sx = bfp_load(a.amax_x, b);
+        return CF::RESCONV ? bfp_min(sx, bfp_load(a.amax_r, b)) : sx;
+    };
     // staging items (group, column): 768 of them, thread -> item tid and (tid < 256) item tid + 512
     float xa[2][8];
     auto fetch = [&](int tile) __attribute__((always_inline)) {
@@ -626,8 +658,8 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) voi
             for (int j = 0; j < 8; ++j) xa[i][j] = ldg_so(xb + (long)j * len, o);
         }
     };
-    auto deposit = [&](int buf) __attribute__((always_inline)) {
-        u32x4* X = Xs + buf * 9 * XP;
+    auto deposit = [&](int buf, float xs) __attribute__((always_inline)) {
+        u32x4* X = Xs + buf * 6 * XP;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * NT;
@@ -635,48 +667,43 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) voi
             const int g = idx >> 8, c = idx & 255;
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = CF::LRELU ? fmaxf(xa[i][j], 0.1f * xa[i][j]) : xa[i][j];
-            uint4 p1, p2, p3;
-            split8(v, p1, p2, p3);
+            for (int j = 0; j < 8; ++j) v[j] = (CF::LRELU ? fmaxf(xa[i][j], 0.1f * xa[i][j]) : xa[i][j]) * xs;
+            uint4 p1, p2;
+            split8(v, p1, p2);
             X[(0 + g) * XP + c] = __builtin_bit_cast(u32x4, p1);
             X[(3 + g) * XP + c] = __builtin_bit_cast(u32x4, p2);
-            X[(6 + g) * XP + c] = __builtin_bit_cast(u32x4, p3);
         }
     };
 
-    int tile = blockIdx.x, cur = 0;
-    if (tile >= a.ntiles) return;
+    int tile, tend, cur = 0;                             // a contiguous range of tiles per workgroup (amax_flush_wg, conv3s.h)
+    tile_range(a.ntiles, tile, tend);
+    if (tile >= tend) return;
     fetch(tile);
-    deposit(0);
-    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+    deposit(0, scale_of(tile / a.tiles_per_utt).s);
+    if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
     const int len2 = len >> 2;
-    for (; tile < a.ntiles; tile += gridDim.x, cur ^= 1) {
+    float mx_run = 0.f;
+    int mx_b = tile / a.tiles_per_utt;
+    for (; tile < tend; ++tile, cur ^= 1) {
         const int b = tile / a.tiles_per_utt;
+        if (a.amax_y && b != mx_b) {
+            amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + CF::FL);
+            mx_run = 0.f;
+            mx_b = b;
+        }
         const int t0 = (tile - b * a.tiles_per_utt) * W;
-        const int next = tile + gridDim.x, next2 = next + gridDim.x;
-        if (next < a.ntiles) deposit(cur ^ 1);            // tile i + 1 (requested one tile ago) -> the other buffer
-        if (next2 < a.ntiles) fetch(next2);               // tile i + 2 flies across this tile
+        const int next = tile + 1, next2 = next + 1;
+        if (next < tend) deposit(cur ^ 1, scale_of(next / a.tiles_per_utt).s);            // tile i + 1 (requested one tile ago) -> the other buffer
+        if (next2 < tend) fetch(next2);               // tile i + 2 flies across this tile
+        const Bfp sx = scale_of(b);
         const int n = wave * 32 + l31;
         const int t = t0 + n;
         const bool live = n < W && t < len;
         const unsigned oo = 4u * (unsigned)(4 * lh * len + (t < len ? t : len - 1));
-        // residual rows of this lane (RES 1) or the second input's B fragments (RES 2), requested before the multiply
-        float rv[CF::RES == 1 ? MT : 1][4][4];
+        // the second input's B fragments (RESCONV), requested before the multiply
         float xq0[8], xq1[8];
-        if (CF::RES == 1) {
-            const float* rb = a.res + (long)b * M * len;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        int m = 32 * mt + 8 * g + q;                     // row of lane half 0; half 1 is 4 further (in oo)
-                        m = m + 4 < M ? m : M - 5;                       // rows past M are never stored: any valid address
-                        rv[mt][g][q] = ldg_so(rb + (long)m * len, oo);
-                    }
-        } else if (CF::RES == 2) {
+        if (CF::RESCONV) {
             const float* xb2 = a.res + (long)b * 24 * len;
             const int tc = t < len ? t : len - 1;
             const unsigned o0 = 4u * (unsigned)(8 * lh * len + tc), o1 = 4u * (unsigned)tc;
@@ -686,26 +713,25 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) voi
                 xq1[j] = ldg_so(xb2 + (long)(16 + j) * len, o1);         // step 1: channels 16 + j on lh = 0, the zero unit on lh = 1
             }
         }
-        f32x16 acc[MT];
+        f32x16 acc[MT], alo[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[mt][r] = alo[mt][r] = 0.f;
         {   // 9 (tap, group) units in 5 K16 steps (conv24_phase), MT m-tiles sharing every B fragment
-            const u32x4* src = Xs + cur * 9 * XP;
+            const u32x4* src = Xs + cur * 6 * XP;
             constexpr int TAP0[5] = {0, 0, 1, 2, 2}, GRP0[5] = {0, 2, 1, 0, 2};
             constexpr int TAP1[5] = {0, 1, 1, 2, 2}, GRP1[5] = {1, 0, 2, 1, 2};
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-            bf16x8 af[2][MT][3], bf[2][3];
+            f16x8 af[2][MT][2], bf[2][2];
             auto frags = [&](int s, int fb) __attribute__((always_inline)) {
                 int c = n + (lh ? TAP1[s] : TAP0[s]) * DIL;
                 c = c > XW - 1 ? XW - 1 : c;
                 const int row = (lh ? GRP1[s] : GRP0[s]) * XP + c;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    bf[fb][p] = __builtin_bit_cast(bf16x8, src[p * 3 * XP + row]);
+                for (int p = 0; p < 2; ++p) {
+                    bf[fb][p] = __builtin_bit_cast(f16x8, src[p * 3 * XP + row]);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) af[fb][mt][p] = __builtin_bit_cast(bf16x8, Wt[((s * MT + mt) * 3 + p) * 64 + lane]);
+                    for (int mt = 0; mt < MT; ++mt) af[fb][mt][p] = __builtin_bit_cast(f16x8, Wt[((s * MT + mt) * 2 + p) * 64 + lane]);
                 }
             };
             frags(0, 0);
@@ -715,57 +741,65 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) voi
                 if (s + 1 < 5) frags(s + 1, fb ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                for (int mt = 0; mt < MT; ++mt) alo[mt] = TVC_MFMA16(af[fb][mt][1], bf[fb][0], alo[mt]);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][mt][PA[q]], bf[fb][PB[q]], acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = TVC_MFMA16(af[fb][mt][0], bf[fb][0], acc[mt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) alo[mt] = TVC_MFMA16(af[fb][mt][0], bf[fb][1], alo[mt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (CF::RES == 2) {   // + down_res(xi): two more K16 steps on the same accumulators
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        if (CF::RESCONV) {   // + down_res(xi): two more K16 steps on the same accumulators
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                uint4 p1, p2, p3;
-                split8(st ? xq1 : xq0, p1, p2, p3);
+                float xq[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xq[j] = (st ? xq1[j] : xq0[j]) * sx.s;
+                uint4 p1, p2;
+                split8(xq, p1, p2);
                 const uint4 z = make_uint4(0u, 0u, 0u, 0u);
                 const bool dead = st == 1 && lh;
-                const bf16x8 xf[3] = {__builtin_bit_cast(bf16x8, dead ? z : p1), __builtin_bit_cast(bf16x8, dead ? z : p2),
-                                      __builtin_bit_cast(bf16x8, dead ? z : p3)};
+                const f16x8 xf[2] = {__builtin_bit_cast(f16x8, dead ? z : p1), __builtin_bit_cast(f16x8, dead ? z : p2)};
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    bf16x8 wf[3];
+                    f16x8 wf[2];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) wf[p] = __builtin_bit_cast(bf16x8, Wr[((st * MT + mt) * 3 + p) * 64 + lane]);
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[PA[q]], xf[PB[q]], acc[mt], 0, 0, 0);
+                    for (int p = 0; p < 2; ++p) wf[p] = __builtin_bit_cast(f16x8, Wr[((st * MT + mt) * 2 + p) * 64 + lane]);
+                    alo[mt] = TVC_MFMA16(wf[1], xf[0], alo[mt]);
+                    acc[mt] = TVC_MFMA16(wf[0], xf[0], acc[mt]);
+                    alo[mt] = TVC_MFMA16(wf[0], xf[1], alo[mt]);
                 }
             }
         }
+        float mx = 0.f;
         {
             float* ob = a.out + (long)b * M * len;
             const bool pair = a.y2 != nullptr && (t & 3) == 1 && t + 1 < len;      // 1/4-rate copy: mean of samples 4 d + 1, 4 d + 2
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+                const float c = Bi[62 + mt] * sx.inv, cl = c * kLoInv;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (32 * mt + 8 * g >= M) continue;                            // uniform
                     const f32x4s bv = *reinterpret_cast<const f32x4s*>(Bi + 32 * mt + 8 * g + 4 * lh);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float v = acc[mt][4 * g + q] + bv[q];
-                        if (CF::RES == 1) v += rv[mt][g][q];
+                        const float v = comb(acc[mt][4 * g + q], alo[mt][4 * g + q], c, cl) + bv[q];
                         const float vn = __shfl_down(v, 1);                        // sample t + 1 (same tile: W % 4 == 0)
                         const int m = 32 * mt + 8 * g + 4 * lh + q;
                         if (live && m < M) {
                             stg_so(ob + (long)(32 * mt + 8 * g + q) * len, oo, v);
+                            mx = fmaxf(mx, fabsf(v));
                             if (pair) a.y2[((long)b * M + m) * len2 + (t >> 2)] = fmaf(0.5f, v, __fmul_rn(0.5f, vn));
                         }
                     }
                 }
+            }
         }
+        mx_run = fmaxf(mx_run, mx);
         slab_barrier();
     }
+    if (a.amax_y) amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + CF::FL);
 }
 
 template <class CF>
@@ -787,30 +821,31 @@ static int launch_conv24s(tvc_ctx* ctx, hipStream_t s, Conv24SArgs a, int B) {
     return launch_check(ctx, "conv24s");
 }
 
-// Downsample block with 24 input channels (decoder.py:143-158) after its interpolate and down_res:
-// xi [B][24][len] -> h1 -> h2 -> out [B][48][len] (+ res), and optionally the next block's 1/4-rate input.
-int run_down24_split(tvc_ctx* ctx, hipStream_t s, const DownW& d, const float* xi, const float* res, float* h1, float* h2, float* out, float* y2, int B,
-                     int len) {
-    if (!d.s24c1 || !d.s24c2 || !d.s24c3) return fail(ctx, TVC_ERR_STATE, "conv24s: the split weight blobs of the 24-channel Downsample block are missing");
+// Downsample block with 24 input channels (decoder.py:143-158) after its interpolate:
+// xi [B][24][len] -> h1 -> h2 -> out [B][48][len] = c3(h2) + down_res(xi), and optionally the next block's 1/4-rate input.
+// slots: per-utterance |max| of xi (read), of h1 / h2 (scratch [B] each, zeroed) and of out (written; nullable).
+int run_down24_split(tvc_ctx* ctx, hipStream_t s, const DownW& d, const float* xi, float* h1, float* h2, float* out, float* y2, int B, int len,
+                     const float* amax_xi, float* amax_h1, float* amax_h2, float* amax_out) {
+    if (!d.s24c1 || !d.s24c2 || !d.s24c3r || !d.res.A6 || d.res.MT6 != 2 || d.res.wjoint != d.c3.A6)
+        return fail(ctx, TVC_ERR_STATE, "conv24s: the split weight blobs of the 24-channel Downsample block are missing");
     if (d.cin != 24 || d.cout != 48) return fail(ctx, TVC_ERR_ARG, "conv24s: 24 -> 48 channels only");
     if ((long)len * 48 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "conv24s: utterance too long for 32-bit byte offsets");
     if (y2 && len % 4 != 0) return fail(ctx, TVC_ERR_ARG, "conv24s: the 1/4-rate copy needs len % 4 == 0");
     Conv24SArgs a{};
     a.len = len;
     a.x = xi; a.out = h1; a.M = 24; a.img = reinterpret_cast<const u32x4*>(d.s24c1);
-    TVC_CHECK((launch_conv24s<C24S<1, 1, true, 0>>(ctx, s, a, B)));
+    a.amax_x = amax_xi; a.amax_y = amax_h1;
+    TVC_CHECK((launch_conv24s<C24S<1, 1, true, false>>(ctx, s, a, B)));
     a.x = h1; a.out = h2; a.img = reinterpret_cast<const u32x4*>(d.s24c2);
-    TVC_CHECK((launch_conv24s<C24S<1, 2, true, 0>>(ctx, s, a, B)));
+    a.amax_x = amax_h1; a.amax_y = amax_h2;
+    TVC_CHECK((launch_conv24s<C24S<1, 2, true, false>>(ctx, s, a, B)));
+    // c3 + down_res(xi): the blob with the summed biases and the joint scales, the 1x1's image, xi as the second input
     a.x = h2; a.out = out; a.y2 = y2; a.M = 48;
-    if (!res) {   // down_res(xi) folded in: the blob with the summed biases, the 1x1's image, xi as the second input
-        if (!d.s24c3r || !d.res.A6 || d.res.MT6 != 2) return fail(ctx, TVC_ERR_STATE, "conv24s: the residual 1x1's image is missing");
-        a.img = reinterpret_cast<const u32x4*>(d.s24c3r);
-        a.rimg = reinterpret_cast<const u32x4*>(d.res.A6);
-        a.res = xi;
-        return launch_conv24s<C24S<2, 4, true, 2>>(ctx, s, a, B);
-    }
-    a.res = res; a.img = reinterpret_cast<const u32x4*>(d.s24c3);
-    return launch_conv24s<C24S<2, 4, true, 1>>(ctx, s, a, B);
+    a.amax_x = amax_h2; a.amax_r = amax_xi; a.amax_y = amax_out;
+    a.img = reinterpret_cast<const u32x4*>(d.s24c3r);
+    a.rimg = reinterpret_cast<const u32x4*>(d.res.A6);
+    a.res = xi;
+    return launch_conv24s<C24S<2, 4, true, true>>(ctx, s, a, B);
 }
 
 }  // namespace tvc

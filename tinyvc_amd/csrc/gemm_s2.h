@@ -1,7 +1,7 @@
 // Plain GEMM on the split-precision path, pipelined:  out(m, n) = sum_k W[m][k] x[b][k][t],  n = b * T + t.
 //
-// Same arithmetic, weight image and epilogue functors as the TAPS = 1 launches of conv3s.h (three bf16 parts per fp32
-// operand, six part-products per product, fp32 accumulation in the same order), different schedule.  The cycle stamps
+// Same arithmetic, weight image and epilogue functors as the TAPS = 1 launches of conv3s.h (two fp16 parts per fp32
+// operand, three part-products per product into an accumulator pair), different schedule.  The cycle stamps
 // of conv3s's slab loop (tools/micro/slab_trace.py) showed its two halves - stage a slab (wait for the loads, split,
 // ds_write, request the next slab: ~1850 cycles) and multiply it (~1840 cycles, matrix-pipe bound) - strictly
 // alternating between two barriers, so the matrix pipe idles half of the time.  Here
@@ -25,12 +25,12 @@
 
 namespace tvc {
 
-#ifndef G2_NWV_MIN
-#define G2_NWV_MIN 2     // narrowest workgroup tile: 32 * G2_NWV_MIN columns
-#endif
+constexpr int G2_NWV_MIN = 2;     // narrowest workgroup tile: 32 * G2_NWV_MIN columns
 
 struct Gemm2Args {
-    const uint4* A6;       // split weight image [K16 step][m-tile][part][lane][8 bf16]
+    const uint4* A6;       // split weight image [K16 step][m-tile][part][lane][8 fp16]
+    const float* wsc;      // its per-m-tile power-of-two scales
+    const float* amax_x;   // per-utterance |max| of x (block-floating-point guard of the fp16 split), or nullptr: no scaling
     int MT;                // m-tiles (32 rows) in the image
     const float* x;        // [B][Cin][T], utterance b at x + b * xstride
     unsigned xstride;
@@ -43,11 +43,11 @@ template <int NWV_, int WN_>
 struct G2Tile {
     static constexpr int NWV = NWV_, WN = WN_, MTB = 4, WM = 2;
     static constexpr int NW = 2 * NWV, NTHR = NW * 64, BM = 128, BN = NWV * WN * 32;
-    static constexpr int A_U4 = 2 * MTB * 3 * 64;          // one buffer's weight pieces: [K16 step][m-tile][part][lane]
-    static constexpr int X_U4 = 2 * 3 * 2 * BN;            // one buffer's input tile: [K16 step][part][8-channel half][column]
+    static constexpr int A_U4 = 2 * MTB * kPU4;            // one buffer's weight pieces: [K16 step][m-tile][part][lane]
+    static constexpr int X_U4 = 2 * kParts * 2 * BN;       // one buffer's input tile: [K16 step][part][8-channel half][column]
     static constexpr int BUF_U4 = A_U4 + X_U4;
     static constexpr int X_PER = WN;                       // staged items (8 channels x 1 column) per thread: 4 * BN / NTHR
-    static constexpr int A_PIECES = 2 * MTB * 3, A_PER = (A_PIECES + NW - 1) / NW;
+    static constexpr int A_PIECES = 2 * MTB * kParts, A_PER = (A_PIECES + NW - 1) / NW;
     static constexpr int lds_bytes = 2 * BUF_U4 * 16;
 };
 
@@ -84,12 +84,13 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
     float xr[X_PER][8];
     u32x4 kr[X_PER][2];
     unsigned xo[X_PER], ko[X_PER];
+    float xsc[X_PER];           // block-floating-point scale of the item's utterance
     int xdst[X_PER];
 #pragma unroll
     for (int i = 0; i < X_PER; ++i) {
         const int idx = tid + i * TL::NTHR;
         const int gk = idx / BN, c = idx - gk * BN;          // gk = 2 * (K16 step) + (8-channel half)
-        xdst[i] = (gk >> 1) * (6 * BN) + (gk & 1) * BN + c;
+        xdst[i] = (gk >> 1) * (2 * kParts * BN) + (gk & 1) * BN + c;
     }
     auto tile_offsets = [&](int n0) __attribute__((always_inline)) {
 #pragma unroll
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
             const int b = p / a.T, t = p - b * a.T;
             xo[i] = (unsigned)b * a.xstride + (unsigned)(gk * 8 * a.T + t);
             ko[i] = (unsigned)(b * a.Cin + gk * 8);
+            xsc[i] = bfp_load(a.amax_x, b).s;
         }
     };
     int lv = next_valid(blockIdx.x), ls = 0, lmt0 = 0, ln0 = 0;
@@ -110,13 +112,13 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
     tile_offsets(ln0);
 
     auto issue_load = [&]() __attribute__((always_inline)) {     // global -> registers only; the values are not touched here
-        const uint4* abase = a.A6 + ((long)ls * 2 * a.MT + lmt0) * 192;
+        const uint4* abase = a.A6 + ((long)ls * 2 * a.MT + lmt0) * kPU4;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int q = wave + i * NW;
             q = q < TL::A_PIECES ? q : TL::A_PIECES - 1;
-            const int kg = q / 12, rem = q - kg * 12;
-            ar[i] = ldg_so4(abase, 16u * (unsigned)(kg * a.MT * 192 + rem * 64 + lane));
+            const int kg = q / (TL::MTB * kParts), rem = q - kg * (TL::MTB * kParts);
+            ar[i] = ldg_so4(abase, 16u * (unsigned)(kg * a.MT * kPU4 + rem * 64 + lane));
         }
         const float* xc = a.x + (long)ls * 32 * a.T;
 #pragma unroll
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int q = wave + i * NW;
-            q = q < TL::A_PIECES ? q : TL::A_PIECES - 1;     // surplus slots of the last round rewrite piece 23 with itself: no branch
+            q = q < TL::A_PIECES ? q : TL::A_PIECES - 1;     // surplus slots of the last round rewrite the last piece with itself: no branch
             *reinterpret_cast<u32x4*>(Ab + q * 64 + lane) = ar[i];
         }
 #pragma unroll
@@ -163,41 +165,47 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
                 xr[i][0] *= k0.x; xr[i][1] *= k0.y; xr[i][2] *= k0.z; xr[i][3] *= k0.w;
                 xr[i][4] *= k1.x; xr[i][5] *= k1.y; xr[i][6] *= k1.z; xr[i][7] *= k1.w;
             }
-            uint4 p1, p2, p3;
-            split8(xr[i], p1, p2, p3);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[i][j] *= xsc[i];                  // power of two: exact
+            uint4 p1, p2;
+            split8(xr[i], p1, p2);
             Xb[xdst[i]] = p1;
             Xb[2 * BN + xdst[i]] = p2;
-            Xb[4 * BN + xdst[i]] = p3;
         }
     };
 
-    f32x16 acc[2][WN];
+    f32x16 hi[2][WN], lo[2][WN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) hi[i][j][r] = lo[i][j][r] = 0.f;
     auto multiply = [&](int buf, int kg) __attribute__((always_inline)) {
-        const uint4* Ab = smem_g2 + buf * TL::BUF_U4 + (kg * 12 + wm * 6) * 64 + lane;
-        const uint4* Xb = smem_g2 + buf * TL::BUF_U4 + TL::A_U4 + kg * 6 * BN + lh * BN + wn * WN * 32 + l31;
-        bf16x8 af[2][3], bf[WN][3];
+        const uint4* Ab = smem_g2 + buf * TL::BUF_U4 + (kg * TL::MTB * kParts + wm * 2 * kParts) * 64 + lane;
+        const uint4* Xb = smem_g2 + buf * TL::BUF_U4 + TL::A_U4 + kg * (2 * kParts * BN) + lh * BN + wn * WN * 32 + l31;
+        f16x8 af[2][kParts], bf[WN][kParts];
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[j][p] = __builtin_bit_cast(bf16x8, Xb[p * 2 * BN + j * 32]);
+            for (int p = 0; p < kParts; ++p) bf[j][p] = __builtin_bit_cast(f16x8, Xb[p * 2 * BN + j * 32]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[i][p] = __builtin_bit_cast(bf16x8, Ab[(i * 3 + p) * 64]);
-        // part-products from the smallest order up; independent accumulators interleaved (same order as conv3s.h)
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+            for (int p = 0; p < kParts; ++p) af[i][p] = __builtin_bit_cast(f16x8, Ab[(i * kParts + p) * 64]);
+        // three part-products per tile; the accumulators alternate (same order as conv3s.h)
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < WN; ++j) lo[i][j] = TVC_MFMA16(af[i][1], bf[j][0], lo[i][j]);
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[j][PB[q]], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) hi[i][j] = TVC_MFMA16(af[i][0], bf[j][0], hi[i][j]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) lo[i][j] = TVC_MFMA16(af[i][0], bf[j][1], lo[i][j]);
     };
 
 #ifdef S_TRACE
@@ -227,18 +235,23 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
         if (++cs == nslab) {
             // epilogue straight from the accumulators (gemm_epi.h functors finish the element)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                const float cw = a.wsc[cmt0 + wm * 2 + i];
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     const int n = cn0 + (wn * WN + j) * 32 + l31;
+                    const int nc = n < a.ncols ? n : a.ncols - 1;
+                    const float c = cw * bfp_load(a.amax_x, nc / a.T).inv, cl = c * kLoInv;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        const float v[4] = {comb(hi[i][j][4 * q], lo[i][j][4 * q], c, cl), comb(hi[i][j][4 * q + 1], lo[i][j][4 * q + 1], c, cl),
+                                            comb(hi[i][j][4 * q + 2], lo[i][j][4 * q + 2], c, cl), comb(hi[i][j][4 * q + 3], lo[i][j][4 * q + 3], c, cl)};
                         ep.store(n, (cmt0 + wm * 2 + i) * 32 + 8 * q + 4 * lh, v);
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) hi[i][j][r] = lo[i][j][r] = 0.f;
                 }
+            }
             cs = 0;
             cv = next_valid(cv + stride);
             if (cv >= a.vtiles) break;
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
 
 template <int NWV, int WN, class Epi, bool SCALED>
 inline int gemm_s2_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int T, long xstride, const Epi& ep,
-                            const float* kscale, int ncu) {
+                            const float* kscale, int ncu, const float* amax_x) {
     using TL = G2Tile<NWV, WN>;
     static bool ready_dev[64] = {};
     bool& ready = ready_dev[ctx->device & 63];
@@ -274,6 +287,8 @@ inline int gemm_s2_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const
     }
     Gemm2Args a;
     a.A6 = reinterpret_cast<const uint4*>(w.A6);
+    a.wsc = w.wscale;
+    a.amax_x = amax_x;
     a.MT = w.MT6;
     a.x = x;
     a.xstride = (unsigned)(xstride ? xstride : (long)Cin * T);
@@ -293,7 +308,7 @@ inline int gemm_s2_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const
 // true = launched (or failed: *rc); false = the shape is outside this kernel's preconditions, use gemm_s_launch
 template <class Epi, bool SCALED = false>
 inline bool gemm_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int T, long xstride, const Epi& ep,
-                        const float* kscale = nullptr) {
+                        const float* amax_x, const float* kscale = nullptr) {
     const long xs = xstride ? xstride : (long)Cin * T;
     if (Cin % 32 != 0 || Cin / 16 > w.S6 || w.MT6 % 4 != 0 || xs * B >= (1L << 29) || (long)B * T >= (1L << 29) || (SCALED && !kscale)) return false;
     static int ncu_dev[64] = {};
@@ -314,11 +329,11 @@ inline bool gemm_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const PackedW& w, 
         const long cost = rounds * (nwv * 32 + 64);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nwv; }
     }
-    if (best == 2) *rc = gemm_s2_launch_t<2, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu);
-    else if (best == 3) *rc = gemm_s2_launch_t<3, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu);
-    else if (best == 4) *rc = gemm_s2_launch_t<4, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu);
-    else if (best == 5) *rc = gemm_s2_launch_t<5, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu);
-    else *rc = gemm_s2_launch_t<6, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu);
+    if (best == 2) *rc = gemm_s2_launch_t<2, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu, amax_x);
+    else if (best == 3) *rc = gemm_s2_launch_t<3, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu, amax_x);
+    else if (best == 4) *rc = gemm_s2_launch_t<4, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu, amax_x);
+    else if (best == 5) *rc = gemm_s2_launch_t<5, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu, amax_x);
+    else *rc = gemm_s2_launch_t<6, 1, Epi, SCALED>(ctx, s, w, x, B, Cin, T, xstride, ep, kscale, ncu, amax_x);
     return true;
 }
 

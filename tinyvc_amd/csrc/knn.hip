@@ -234,8 +234,30 @@ struct Top4 {
     }
 };
 
+// The exact kernel's own split: three bf16 parts per fp32 operand (x = x1 + x2 + x3, residuals exact), six part-products per
+// product on v_mfma_f32_32x32x16_bf16.  (The conv / GEMM kernels moved to the two-term fp16 split of conv3s.h; this kernel only runs
+// for N < 4096 and as the in-call fallback of the two-stage search, whose coarse passes are single fp16 products.)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8_bf3(const float (&v)[8], uint4& p1, uint4& p2, uint4& p3) {
+    unsigned o1[4], o2[4], o3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x2 a = {v[2 * j], v[2 * j + 1]};
+        bf16x2 h1 = __builtin_convertvector(a, bf16x2);
+        f32x2 r = a - __builtin_convertvector(h1, f32x2);
+        bf16x2 h2 = __builtin_convertvector(r, bf16x2);
+        f32x2 r2 = r - __builtin_convertvector(h2, f32x2);
+        bf16x2 h3 = __builtin_convertvector(r2, bf16x2);
+        o1[j] = __builtin_bit_cast(unsigned, h1);
+        o2[j] = __builtin_bit_cast(unsigned, h2);
+        o3[j] = __builtin_bit_cast(unsigned, h3);
+    }
+    p1 = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+    p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+    p3 = make_uint4(o3[0], o3[1], o3[2], o3[3]);
+}
 // two bf16 parts of 8 fp16 values (exact: 11 significant bits fit in 8 + 8), packed for one 16-byte LDS row each
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split8_half(const u32x4 h8, uint4& p1, uint4& p2) {
     const f16x8 hv = __builtin_bit_cast(f16x8, h8);
     unsigned o1[4], o2[4];
@@ -321,7 +343,7 @@ __device__ __forceinline__ void knn_topk_body(const float* __restrict__ blob, lo
             if (a2) *reinterpret_cast<u32x4*>(ab + (wave + 8) * 64 + lane) = ar[1];
         }
         uint4 p1, p2, p3;
-        split8(xr, p1, p2, p3);
+        split8_bf3(xr, p1, p2, p3);
         uint4* xb = Xs + buf * KNN_X_U4;
         xb[xdst] = p1;
         xb[2 * KNN_QT + xdst] = p2;
@@ -600,7 +622,6 @@ constexpr float C_EPS = 1.25e-3f;
 #ifndef KNN_COARSE_MIN
 #define KNN_COARSE_MIN 4096
 #endif
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct Top4V {   // four largest values
     float v[4];

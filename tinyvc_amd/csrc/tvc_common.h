@@ -27,11 +27,14 @@ constexpr int kHarm = 15;  // num_harmonics + 1 sinusoids
 constexpr int kSolaCross = 1920, kSolaSearch = 1920, kSolaDelay = 3840;
 constexpr int kSolaGroups = 8, kSolaPartFloats = 16384;   // lag groups (workgroups) per stream of the correlation search; its scratch in the context's constant arena
 
-// A conv / 1x1 weight packed for the split-precision MFMA kernels (conv3s.h): the bf16x3 image A6 (K16 steps x MT6 = Mpad / 32
-// m-tiles x 3 parts, 1 KiB pieces in MFMA lane order) plus the bias row [Mpad].  M / K = real rows / k = cin * taps.
+// A conv / 1x1 weight packed for the split-precision MFMA kernels (conv3s.h): the two-part fp16 image A6 (K16 steps x MT6 = Mpad / 32
+// m-tiles x 2 parts, 1 KiB pieces in MFMA lane order; every m-tile normalised by a power of two, wscale[MT6] = what the epilogue
+// multiplies back) plus the bias row [Mpad].  M / K = real rows / k = cin * taps.
 struct PackedW {
     const float* bias = nullptr;
     const float* A6 = nullptr;
+    const float* wscale = nullptr;   // [MT6] power-of-two scale of every m-tile: W = image * wscale
+    const float* wjoint = nullptr;   // the A6 of the image this one shares its m-tile scales with (two convs accumulated into one tile), else nullptr
     int M = 0, K = 0, Mpad = 0, Kpad = 0, cin = 0, taps = 1, MT6 = 0, S6 = 0;   // S6 = 16-channel slabs in A6 (zero-padded to a multiple of 6)
 };
 
@@ -44,21 +47,20 @@ struct ConvNeXtW {
     const float* grn_g = nullptr;  // [2C]
     const float* grn_b = nullptr;
     const float* c3_bias_grn = nullptr;  // c3.bias + c3.weight . grn.beta  [Mpad] (GRN's beta folded through the 1x1)
+    float ln_bound = 0.f;                // sqrt(C) max|gamma| + max|beta| >= |LayerNorm output|: the first 1x1's input needs no |max| slot while this is < 2^15
     int C = 0, dilation = 1;
 };
 
 struct DownW {
-    PackedW res, c1, c2, c3;
+    PackedW res, c1, c2, c3;             // c3 and res share their per-m-tile scales (accumulated into one tile)
     const float* c3res_bias = nullptr;   // c3.bias + down_res.bias [c3.Mpad]: c3 launches that fold the residual 1x1 in as a second K phase
     const float* s24c1 = nullptr;   // cin == 24: weight blobs of conv24s_kernel (filter_up24s.hip)
     const float* s24c2 = nullptr;
-    const float* s24c3 = nullptr;
-    const float* s24c3r = nullptr;   // c3's blob with c3.bias + down_res.bias (the launch that folds the residual 1x1 in)
+    const float* s24c3r = nullptr;   // c3's blob with c3.bias + down_res.bias and the joint scales (the launch folds the residual 1x1 in)
     int cin = 0, cout = 0, factor = 1;
 };
 struct UpW {
-    PackedW c1, c2, c3, c4, c5, film1, film2;  // film = [to_scale ; to_shift] stacked on M (2C)
-    PackedW sc1, sh1, sc2, sh2;                // the same FiLM 1x1s packed separately (fused block kernels)
+    PackedW c1, c2, c3, c4, c5, film1, film2;  // film = [to_scale ; to_shift] stacked on M (2C); film.bias = [b_scale (C) ; b_shift (C)]
     const float* s24a = nullptr;               // cin == 24: weight blobs of the two halves of the split-precision fused block (filter_up24s.hip)
     const float* s24b = nullptr;
     int cin = 0, cout = 0, factor = 1;
@@ -114,10 +116,8 @@ struct tvc_ctx {
     const float* src_f_w = nullptr;
     const float* src_f_b = nullptr;
     // filter net
-    tvc::PackedW flt_content_in, flt_down0, flt_out;
+    tvc::PackedW flt_content_in;
     const float* flt_down0s = nullptr;   // downs.0 weight blob of the split-precision kernel (filter_up24s.hip)
-    const float* flt_out_w = nullptr;  // output_layer weight, raw [1][24][7]
-    const float* flt_out_b = nullptr;
     const float* flt_f_w = nullptr;
     const float* flt_f_b = nullptr;
     tvc::DownW downs[4];
@@ -226,10 +226,12 @@ struct FilterTaps {   // optional copies of FilterNet's block outputs (tvc_filte
     float* skips[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float* ups[4] = {nullptr, nullptr, nullptr, nullptr};
 };
+// cmax / smax / the trailing float* of run_dsp: per-utterance |max| slots of content / cat[source, energy] (block-floating-point
+// guard of the fp16 split, conv3s.h); nullptr = the stage computes (or keeps) its own
 int run_filter(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* content, const float* f0, const float* energy,
-               const float* source, float* wave, int B, int T, const FilterTaps* taps = nullptr);
+               const float* source, float* wave, int B, int T, const FilterTaps* taps = nullptr, const float* cmax = nullptr, const float* smax = nullptr);
 int run_dsp(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* f0, const float* amps, const float* kern,
-            const float* angle, uint64_t seed, float* source, int B, int T);
+            const float* angle, uint64_t seed, float* source, int B, int T, float* smax = nullptr);
 int run_sola(tvc_ctx*, hipStream_t, const float* y, float* sola_buf, const float* fade_in, float* out, int32_t* shift_out,
              int S, int64_t Ly, int block, int use_pv);
 int64_t resample_out_len(int64_t n, int orig_freq, int new_freq);
@@ -241,12 +243,16 @@ int run_prepare_index(tvc_ctx*, hipStream_t, const float* index, float* prepared
 int run_prepare_index_f16(tvc_ctx*, hipStream_t, const void* rows_f16, float* prepared, int64_t N);
 
 // fused FilterNet kernels (filter_up24s.hip, conv48s.hip)
-int run_up24_split(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len);
-int run_down0_split(tvc_ctx*, hipStream_t, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len);
-int run_down24_split(tvc_ctx*, hipStream_t, const DownW& d, const float* xi, const float* res, float* h1, float* h2, float* out, float* y2, int B, int len);
+// (the amax_* arguments are the per-utterance |max| slots of the block-floating-point guard, conv3s.h)
+int run_up24_split(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len, const float* amax_x,
+                   const float* amax_c, float* amax_x1);
+int run_down0_split(tvc_ctx*, hipStream_t, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len,
+                    const float* amax_x, float* amax_y);
+int run_down24_split(tvc_ctx*, hipStream_t, const DownW& d, const float* xi, float* h1, float* h2, float* out, float* y2, int B, int len,
+                     const float* amax_xi, float* amax_h1, float* amax_h2, float* amax_out);
 int run_conv48s(tvc_ctx*, hipStream_t, const PackedW& w, const float* x, int lin, float lscale, const PackedW* film, const float* bsc, const float* bsh,
-                const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil, const PackedW* c5 = nullptr,
-                float* out5 = nullptr);
+                const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil, const float* amax_x, const float* amax_c,
+                float* amax_y, const PackedW* c5 = nullptr, float* out5 = nullptr);
 
 // ConvNeXt-v2 layer on x [B, C, T] in place (convnext.py:49-58); tmp buffers from ws.
 int run_convnext(tvc_ctx*, hipStream_t, Ws&, bool dry, const ConvNeXtW& w, float* x, int B, int T);
