@@ -503,9 +503,10 @@ __device__ __forceinline__ void film_first_load(SlabRegs<TL>& r, const uint4* __
     make_map<TL>(m, len, 0, t0);
     film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, 0);
 }
-// (sc, sh) accumulator pairs: [0] = hi, [1] = lo
+// (scale, shift) accumulator pairs: (asc, lsc), (ash, lsh)
 template <class TL, class Next>
-__device__ __forceinline__ void film_phase(f32x16 (&asc)[2][TL::WM][TL::WN], f32x16 (&ash)[2][TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ F6,
+__device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16 (&lsc)[TL::WM][TL::WN], f32x16 (&ash)[TL::WM][TL::WN], f32x16 (&lsh)[TL::WM][TL::WN],
+                                           SlabRegs<TL>& r, const uint4* __restrict__ F6,
                                            int MT, int mt0, int mtoff, const float* __restrict__ xb, int Cin, int len, int t0, uint4* As, uint4* Xs,
                                            Next next, float xs) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
@@ -561,12 +562,12 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[2][TL::WM][TL::WN], f32
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    asc[1][i][j] = TVC_MFMA16(fc[i][1], bf[j][0], asc[1][i][j]);
-                    ash[1][i][j] = TVC_MFMA16(fh[i][1], bf[j][0], ash[1][i][j]);
-                    asc[0][i][j] = TVC_MFMA16(fc[i][0], bf[j][0], asc[0][i][j]);
-                    ash[0][i][j] = TVC_MFMA16(fh[i][0], bf[j][0], ash[0][i][j]);
-                    asc[1][i][j] = TVC_MFMA16(fc[i][0], bf[j][1], asc[1][i][j]);
-                    ash[1][i][j] = TVC_MFMA16(fh[i][0], bf[j][1], ash[1][i][j]);
+                    lsc[i][j] = TVC_MFMA16(fc[i][1], bf[j][0], lsc[i][j]);
+                    lsh[i][j] = TVC_MFMA16(fh[i][1], bf[j][0], lsh[i][j]);
+                    asc[i][j] = TVC_MFMA16(fc[i][0], bf[j][0], asc[i][j]);
+                    ash[i][j] = TVC_MFMA16(fh[i][0], bf[j][0], ash[i][j]);
+                    lsc[i][j] = TVC_MFMA16(fc[i][0], bf[j][1], lsc[i][j]);
+                    lsh[i][j] = TVC_MFMA16(fh[i][0], bf[j][1], lsh[i][j]);
                 }
         }
     }
@@ -826,7 +827,14 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     float* const red = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS) + 12 * TL::BM + TL::KS_MAX;
     const int fT = a.flatT;
     const unsigned fstride = (unsigned)a.xstride;
-    first_load<TL, TAPS, LERP, CLAMP>(regs, a.A6, a.MT, mt0, fT ? a.x : a.x + (long)b * a.xstride, a.Cin, len, a.dil, t0, fT, fstride, a.cmax, a.lin, a.lscale);
+    // narrow FiLM tiles run their FiLM phase FIRST (scale and shift pairs: 4 accumulator sets, folded to 2 before the conv's pair comes
+    // alive: 4 sets at the peak instead of 5, which did not fit the 168 registers of a 12-wave workgroup)
+    constexpr bool FILM_FIRST = FILM && TL::WN == 1;
+    auto load_first = [&](int mt0_, int b_, int t0_) __attribute__((always_inline)) {
+        if constexpr (FILM_FIRST) film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0_, a.MT, a.cond + (long)b_ * a.Ccond * len, len, t0_);
+        else first_load<TL, TAPS, LERP, CLAMP>(regs, a.A6, a.MT, mt0_, fT ? a.x : a.x + (long)b_ * a.xstride, a.Cin, len, a.dil, t0_, fT, fstride, a.cmax, a.lin, a.lscale);
+    };
+    load_first(mt0, b, t0);
     for (int tile_no = 0; tile < vtiles; ++tile_no) {
         const int nxt = tile + 1;
         if constexpr (!Epi::kIgemm) {
@@ -840,8 +848,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             if (nxt < vtiles) {
                 int mt0n, bn, t0n;
                 coords(nxt, mt0n, bn, t0n);
-                first_load<TL, TAPS, LERP, CLAMP>(regs, a.A6, a.MT, mt0n, fT ? a.x : a.x + (long)bn * a.xstride, a.Cin, len, a.dil, t0n, fT, fstride, a.cmax, a.lin,
-                                           a.lscale);
+                load_first(mt0n, bn, t0n);
             }
         };
         const float* xb = fT ? a.x : a.x + (long)b * a.xstride;
@@ -945,18 +952,18 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             const float* cb = a.cond + (long)b * a.Ccond * len;
             const int mtoff = a.MT;                                   // the stacked FiLM image has 2 * a.MT m-tiles: scale rows, then shift rows
             const Bfp sc = bfp_load(a.amax_c, b);
-            split_phase<TL, TAPS, A_U4, LRELU, S_FB_F, false, LERP, false>(
-                hi, lo, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
-                [&]() __attribute__((always_inline)) { film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, len, t0); }, sx.s, nullptr, 0, 0u, 0, a.lin, a.lscale);
-            fold(hi, lo, Bs + 3 * TL::BM, sx.inv);                    // the conv result: frees `lo` before the FiLM phase
-            f32x16 asc[2][WM][WN], ash[2][WM][WN];
-            clear(asc[0]);
-            clear(asc[1]);
-            clear(ash[0]);
-            clear(ash[1]);
-            film_phase<TL>(asc, ash, regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, a.Ccond, len, t0, As, Xs, load_next_tile, sc.s);
-            fold(asc[0], asc[1], Bs + 4 * TL::BM, sc.inv);
-            fold(ash[0], ash[1], Bs + 5 * TL::BM, sc.inv);
+            f32x16 asc[WM][WN], lsc[WM][WN], ash[WM][WN], lsh[WM][WN];
+            clear(asc);
+            clear(lsc);
+            clear(ash);
+            clear(lsh);
+            film_phase<TL>(asc, lsc, ash, lsh, regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, a.Ccond, len, t0, As, Xs,
+                           [&]() __attribute__((always_inline)) { first_load<TL, TAPS, LERP, false>(regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, 0, 0u, 0, a.lin, a.lscale); }, sc.s);
+            fold(asc, lsc, Bs + 4 * TL::BM, sc.inv);            // scale and shift without their biases: frees two sets before the conv phase
+            fold(ash, lsh, Bs + 5 * TL::BM, sc.inv);
+            split_phase<TL, TAPS, A_U4, LRELU, S_FB_F, false, LERP, false>(hi, lo, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile, sx.s, nullptr, 0, 0u, 0,
+                                                                            a.lin, a.lscale);
+            fold(hi, lo, Bs + 3 * TL::BM, sx.inv);
             // out = ((h + b)(sc + b_sc)) + (sh + b_sh), + residual in the store pass
             {
 #pragma unroll
@@ -967,7 +974,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                         const float bm = Bs[row], bs = Bs[TL::BM + row], bh = Bs[2 * TL::BM + row];
 #pragma unroll
                         for (int j = 0; j < WN; ++j)
-                            hi[i][j][r] = __fadd_rn(__fmul_rn(hi[i][j][r] + bm, asc[0][i][j][r] + bs), ash[0][i][j][r] + bh);
+                            hi[i][j][r] = __fadd_rn(__fmul_rn(hi[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
                     }
                 tile_store<TL, true>(reinterpret_cast<float*>(smem_s), hi, ep.y, ep.res, b, ep.M, len, mt0, t0, mx_run, nullptr, 0, ep.res_lin, ep.res_scale);
             }
@@ -1142,15 +1149,15 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
         return conv3s_launch_t<SplitTile<2, 1, 6, 1>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC, nullptr, false, 0,
                                                                                        lin, lscale, bfp);
     if constexpr (FILM) {
-        // Two tiles for the FiLM-fused launches.  96 x 128: scale and shift in one phase.  96 x 256 (the plain convs' tile): the conv
-        // phase stages a slab for twice the columns, scale and shift run one after the other on one extra accumulator pair
-        // (split_phase<TWO>) and the cond tile is staged twice - per column cheaper, unless the wide tiles leave the last round of the
-        // 256 persistent workgroups underfilled.  Rounds x per-tile cost decides; a launch that cannot fill the chip keeps the narrow tile.
+        // Two tiles for the FiLM-fused launches.  96 x 256 (the plain convs' tile): the conv phase stages a slab for twice the columns,
+        // scale and shift run one after the other on one extra accumulator pair (split_phase<TWO>) and the cond tile is staged twice.
+        // 96 x 128: FiLM's scale and shift in one phase (four accumulator sets, then the conv's pair); its register budget is tight
+        // (measured slower per column with the accumulator pairs of the fp16 split), so it only serves launches that cannot fill
+        // the chip with wide tiles (a streaming block).
         const long mb = w.MT6 / 3;
-        const long tiles_n = mb * ((len + 127) / 128) * B, tiles_w = mb * ((len + 255) / 256) * B;
+        const long tiles_w = mb * ((len + 255) / 256) * B;
         const long slots = 256 * S_BPC;
-        const long rounds_n = (tiles_n + slots - 1) / slots, rounds_w = (tiles_w + slots - 1) / slots;
-        const bool wide = tiles_w >= slots && rounds_w * 186 < rounds_n * 100;
+        const bool wide = tiles_w >= slots;
         if (wide)
             return conv3s_launch_t<SplitTile<3, 1, 4, 2>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC, nullptr, false,
                                                                                            0, lin, lscale, bfp);

@@ -429,7 +429,7 @@ static int launch_up24s(tvc_ctx* ctx, hipStream_t s, Up24SArgs a, int B) {
     return launch_check(ctx, "up24s");
 }
 
-constexpr int U24S_WA = 250, U24S_WB = 250;     // output samples per tile of the two halves
+constexpr int U24S_WA = 250, U24S_WB = 250;     // output samples per tile of the two halves (196 / 218 for the second half - one round of first-conv tiles instead of two - measured 8 % slower: the halo dominates)
 
 // Upsample block with cin == 24 followed by FilterNet.output_layer:
 // x [B][24][len/f], cond [B][24][len] -> wave [B][len]; x1 is scratch [B][24][len].
