@@ -68,7 +68,7 @@ def load_target(gen, args, device):
     return torch.load(args.index, map_location="cpu").to(device)     # fp32 [1,768,N], or half: fp16 index storage
 
 
-SOLA_LATENCY = 1920 + 3840 + 960     # cross-fade + last delay + half the search range: nominal lag of StreamInfer's output
+SOLA_MAX_LATENCY = 1920 + 1920 + 3840     # cross-fade + search range + last delay: a block's output lags its input by this minus the SOLA lag (stream.py:76-83)
 
 
 @torch.no_grad()
@@ -76,7 +76,9 @@ def convert_chunked(gen, batch, tgt, pitch_shift, chunk_size, buffer_blocks, use
     """Block-wise conversion of `batch` [B, L] with bounded memory: every utterance is a stream of `chunk_size`-sample
     blocks through BatchedStreamInfer (rolling buffer with `buffer_blocks` blocks of extra context, full convert per
     block, SOLA alignment + cross-fade: reference module/infer/stream.py:68-96).  The streaming output lags its input by
-    ~SOLA_LATENCY samples; the lag is flushed with silence and trimmed so the result has the input's length.
+    SOLA_MAX_LATENCY minus the SOLA lag of the block (the lag locks onto one value per stream once the signal is periodic);
+    the tail is flushed with silence and every utterance is trimmed by its own median latency, so the result has the input's
+    length and lines up with the whole-file conversion.
     `noise_angles(i)` -> [B, 961, T] injects the decoder's noise phases of block i (parity runs against the oracle's
     `stream_callback`; default: drawn on the device per block, as the reference's `torch.rand` is).
     `return_blocks`: also return the untrimmed block outputs [B, nblk, chunk_size] and the SOLA lags [nblk, B]."""
@@ -85,17 +87,20 @@ def convert_chunked(gen, batch, tgt, pitch_shift, chunk_size, buffer_blocks, use
     st = BatchedStreamInfer(gen, n_streams=B, target=tgt, pitch_shift=pitch_shift, device=batch.device, block_size=chunk_size,
                             extra_size=buffer_blocks * chunk_size, use_phase_vocoder=use_phase_vocoder, use_graph=True)
     st.init_buffer()
-    nblk = -(-(L + SOLA_LATENCY) // chunk_size)
+    nblk = -(-(L + SOLA_MAX_LATENCY) // chunk_size)
     padded = torch.zeros(B, nblk * chunk_size, device=batch.device)
     padded[:, :L] = batch
     outs, lags = [], []
     for i in range(nblk):
         outs.append(st.audio_callback(padded[:, i * chunk_size:(i + 1) * chunk_size], noise_angle=noise_angles(i) if noise_angles else None))
-        if return_blocks:
-            lags.append(st.last_shift.clone())
-    out = torch.cat(outs, dim=1)[:, SOLA_LATENCY:SOLA_LATENCY + L]
+        lags.append(st.last_shift.clone())
+    lags = torch.stack(lags, dim=0)                                  # [nblk, B]
+    stream = torch.cat(outs, dim=1)
+    nsig = max(1, -(-L // chunk_size))                               # blocks that carry signal (the flush blocks' lags are noise)
+    latency = (SOLA_MAX_LATENCY - lags[:nsig].float().median(dim=0).values.round().long()).clamp(0, SOLA_MAX_LATENCY).tolist()
+    out = torch.stack([stream[b, latency[b]:latency[b] + L] for b in range(B)], dim=0)
     if return_blocks:
-        return out, torch.stack(outs, dim=1), torch.stack(lags, dim=0)
+        return out, torch.stack(outs, dim=1), lags
     return out
 
 

@@ -142,21 +142,23 @@ def test_chunked_mode_matches_the_oracle_stream_loop(gen, use_pv):
     tgt = synth.synth_index(300, seed=2)
     T = R.StreamState(block_size=chunk, extra_size=buf * chunk).input_size // 480
     angles = lambda i: synth.synth_angle(1, T, 4000 + i)
-    nblk = -(-(L + infer.SOLA_LATENCY) // chunk)
-    nthr = torch.get_num_threads()
+    nblk = -(-(L + infer.SOLA_MAX_LATENCY) // chunk)
+    nthr = min(8, torch.get_num_threads())      # the second CPU setting: 8 threads (the fixtures' build host), whatever the box has
 
     def oracle_run(padded):
         ost = R.StreamState(block_size=chunk, extra_size=buf * chunk)
         return [R.stream_callback(ost, enc_sd, dec_sd, tgt, 1.0, padded[i * chunk:(i + 1) * chunk], angles(i), use_phase_vocoder=use_pv) for i in range(nblk)]
 
-    for seed in range(77, 87):
+    all_threads = torch.get_num_threads()
+    for seed in range(82, 92):
         wf = synth.synth_wave(1, L, seed=seed)
         padded = torch.zeros(nblk * chunk)
         padded[:L] = wf[0]
+        torch.set_num_threads(nthr)
         ref = oracle_run(padded)
         torch.set_num_threads(1)
         ref1 = oracle_run(padded)
-        torch.set_num_threads(nthr)
+        torch.set_num_threads(all_threads)
         if all(a[1] == b[1] for a, b in zip(ref, ref1)):
             break
         print(f"[f4] seed {seed}: the oracle's own lags differ between 1 and {nthr} threads (near-tied arg-max): next seed")
@@ -186,4 +188,4 @@ def test_chunked_mode_matches_the_oracle_stream_loop(gen, use_pv):
             best, best_lag = c, lag
     print(f"[f4] trimmed chunked output vs whole-file conversion: correlation peak {best:.3f} at lag {best_lag} samples")
     assert out.shape == (1, L)
-    assert abs(best_lag) <= 960 and best > 0.5
+    assert abs(best_lag) <= 240 and best > 0.5      # (the trim uses the stream's median SOLA lag; single blocks deviate by a pitch period or so)

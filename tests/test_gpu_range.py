@@ -1,0 +1,106 @@
+"""The fp16 range guard of the split-precision kernels (conv3s.h: block floating point).
+
+Every fp32 operand is multiplied as two fp16 parts; fp16 tops out at 65 504 and loses relative precision below 6e-5, the fp32
+reference does neither.  The guard: weights normalised per 32-row m-tile at pack time, activations scaled by a per-utterance power
+of two taken from the tensor's |max| slot (written by the producing kernel) whenever that |max| is outside [2^-10, 2^15).  These
+tests drive activations far outside fp16's range on both sides and require the same accuracy against the oracle as at O(1), and
+that an out-of-range utterance leaves its batch mates untouched (the slots are per utterance)."""
+import pytest
+import torch
+
+from helpers import load_golden, oracle_one_thread, rel_rms, state_dicts
+from oracle import ref_cpu as R
+from tinyvc_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gen():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from tinyvc_amd.module.infer import Generator
+    from tinyvc_amd.module.tinyvc import Decoder, Encoder
+    enc_sd, dec_sd = state_dicts(0)
+    enc, dec = Encoder(), Decoder()
+    enc.load_state_dict(enc_sd)
+    dec.load_state_dict(dec_sd)
+    return Generator(enc, dec).to(DEV)
+
+
+@pytest.mark.parametrize("scale", [3e4, 1.0, 1e-7])
+def test_encoder_on_out_of_range_spectrograms(gen, scale):
+    """|STFT| of a waveform scaled by 3e4 peaks near 1e6 (> 65 504); scaled by 1e-7 it stays below 1e-5 (< 6e-5, fp16's smallest
+    normal).  SSL features and pitch logits vs the oracle on the SAME spectrogram: the gates of the O(1) case."""
+    from tinyvc_amd.module import utils
+    enc_sd, _dec_sd = state_dicts(0)
+    wf = synth.synth_wave(2, 9600 * 2, seed=31) * scale
+    spec = utils.spectrogram(wf.to(DEV))
+    with oracle_one_thread():
+        ssl_ref = R.ssl_features(enc_sd, spec.cpu())
+        log_ref = R.pitch_logits(enc_sd, spec.cpu())
+    eng = gen.encoder.engine(DEV)
+    ssl, _f0, logits = eng.encoder(spec, want_logits=True)
+    print(f"[range] encoder, wave x {scale:g}: |spec| max {float(spec.abs().max()):.3g}; ssl rel {rel_rms(ssl.cpu(), ssl_ref):.2e}, "
+          f"logits rel {rel_rms(logits.cpu(), log_ref):.2e}")
+    assert torch.isfinite(ssl).all() and torch.isfinite(logits).all()
+    assert rel_rms(ssl.cpu(), ssl_ref) <= 1e-5
+    assert rel_rms(logits.cpu(), log_ref) <= 6e-6
+
+
+@pytest.mark.parametrize("scale", [1e5, 1e-6])
+def test_filter_net_blocks_out_of_range(gen, scale):
+    """FilterNet with `source` / `energy` scaled by 1e5 (every activation of the down path is far beyond 65 504) or 1e-6 (below
+    fp16's normal range) and `content` by 1e3 / 1e-3: every Downsample / Upsample block output against the oracle on the same
+    inputs, at the O(1) gate (3e-6; a block whose operands overflowed or flushed would be off by orders of magnitude)."""
+    _enc_sd, dec_sd = state_dicts(0)
+    g = load_golden("convert_T28")
+    content = torch.from_numpy(g["matched"]) * (1e3 if scale > 1 else 1e-3)
+    f0s = torch.from_numpy(g["f0s"])
+    B, _c, T = content.shape
+    L = T * 480
+    gsrc = torch.Generator().manual_seed(5)
+    source = torch.randn(B, 16, L, generator=gsrc) * 0.3 * scale
+    energy = torch.rand(B, 1, L, generator=gsrc) * scale
+    with oracle_one_thread():
+        _out, skips_ref, ups_ref = R.filter_net(dec_sd, content, f0s, energy, source, return_blocks=True)
+    eng = gen.decoder.engine(DEV)
+    wave, skips, ups = eng.filter_net(content.to(DEV), f0s.to(DEV), energy.to(DEV), source.to(DEV), blocks=True)
+    assert torch.isfinite(wave).all()
+    worst = 0.0
+    for i, (s, r) in enumerate(zip(skips, skips_ref)):
+        e = rel_rms(s.cpu(), r)
+        worst = max(worst, e)
+        print(f"[range] x{scale:g} downs[{i}] |max| {float(r.abs().max()):.3g} rel {e:.2e}")
+        assert e <= 3e-6
+    for i, (u, r) in enumerate(zip(ups, ups_ref[:4])):
+        e = rel_rms(u.cpu(), r)
+        worst = max(worst, e)
+        print(f"[range] x{scale:g} ups[{i}] |max| {float(r.abs().max()):.3g} rel {e:.2e}")
+        assert e <= 3e-6
+    if scale > 1:
+        assert max(float(r.abs().max()) for r in skips_ref) > 65504 and float(source.abs().max()) > 65504
+    else:
+        assert float(source.abs().max()) < 6e-5 and float(energy.abs().max()) < 6e-5      # (the biases bring the activations back to O(0.1))
+
+
+def test_out_of_range_utterance_leaves_its_batch_mates_untouched(gen):
+    """The |max| slots are per utterance: a batch whose first utterance is 1e5 times too loud (and whose second contains an Inf sample)
+    converts the ordinary third utterance to exactly the samples it gets alone."""
+    tgt = synth.synth_index(500, seed=3).to(DEV)
+    wf = synth.synth_wave(3, 9600, seed=41)
+    angle = synth.synth_angle(3, 20, 42).to(DEV)
+    alone = gen.convert(wf[2:3].to(DEV), tgt, 0.0, noise_angle=angle[2:3])
+    loud = wf.clone()
+    loud[0] *= 1e5
+    loud[1, 4000] = float("inf")
+    out = gen.convert(loud.to(DEV), tgt, 0.0, noise_angle=angle)
+    assert torch.equal(out[2:3], alone)
+    assert torch.isfinite(out[0]).all(), "the loud utterance itself must convert (the reference does)"
+    # and the loud utterance equals the reference on the same input to the usual relative accuracy of its waveform
+    enc_sd, dec_sd = state_dicts(0)
+    with oracle_one_thread():
+        ref = R.convert(enc_sd, dec_sd, loud[:1], tgt.cpu(), 0.0, angle[:1].cpu())
+    e = rel_rms(out[0].cpu(), ref[0])
+    print(f"[range] utterance scaled by 1e5: waveform rel rms vs the oracle {e:.2e} (|wave| max {float(ref.abs().max()):.3g})")
+    assert e <= 2e-3
