@@ -35,9 +35,9 @@ SR = 24000
 FILTER_BYTES_PER_SAMPLE = 87.86e6 / SR      # layer-boundary activation bytes of FilterNet per 24 kHz sample
 FILTER_FLOPS_PER_SAMPLE = 2.483e9 / SR       # FilterNet FLOPs per 24 kHz output sample
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
-BF16_MFMA_PEAK_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 MFMA peak
+F16_MFMA_PEAK_TFLOPS = 2500.0              # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 FP32_MFMA_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_* peak = fp32 vector peak
-SPLIT_PRODUCTS = 6                         # bf16x3 split precision: six bf16 part-products per fp32 product
+SPLIT_PRODUCTS = 3                         # two-term fp16 split: three fp16 part-products per fp32 product
 
 
 STAGE_STEPS = 5      # untimed steps with every stage bracketed, after the timed region
@@ -297,11 +297,11 @@ def main():
                "algorithmic_bytes_per_launch": alg_bytes,
                "moved_gbs": traffic / t_filter / 1e9 if traffic else None,
                "moved_frac": traffic / t_filter / 1e9 / HBM_PEAK_GBS if traffic else None} if t_filter > 0 else None
-        mfma = {"achieved": SPLIT_PRODUCTS * flops / t_filter / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": SPLIT_PRODUCTS * flops / t_filter / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-                "flops_per_launch": flops, "bf16_part_products_per_fp32_product": SPLIT_PRODUCTS,
+        mfma = {"achieved": SPLIT_PRODUCTS * flops / t_filter / 1e12, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": SPLIT_PRODUCTS * flops / t_filter / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                "flops_per_launch": flops, "f16_part_products_per_fp32_product": SPLIT_PRODUCTS,
                 "fp32_equiv_tflops": flops / t_filter / 1e12, "fp32_equiv_frac_of_fp32_mfma_peak": flops / t_filter / 1e12 / FP32_MFMA_PEAK_TFLOPS} if t_filter > 0 else None
-        # which roof binds, from the data: the pipe the kernels issue on (bf16 MFMA, 6 part-products per product) against the
+        # which roof binds, from the data: the pipe the kernels issue on (fp16 MFMA, 3 part-products per product) against the
         # bytes that really crossed HBM (PMC); the layer-boundary byte model (north_star's 40 % target) stays in
         # `hbm.frac` / `hbm_layer_boundary_frac` but is never what selects `bound` once blocks are fused.
         roof = None
@@ -311,9 +311,9 @@ def main():
             pick = mfma if bound == "mfma" else {"achieved": hbm["moved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved}
             roof = {"bound": bound, "achieved": pick["achieved"], "peak": pick["peak"], "unit": pick["unit"], "frac": pick["frac"],
                     "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "FilterNet Conv1d stack = the filter_net launches of one step (split-precision bf16x3 MFMA: fused ups.4+output kernels, conv3s / conv48s for the 48..384-channel levels, conv24s / down0s for the 24-channel ones), hipEvent pair on the launch stream",
+                    "kernel": "FilterNet Conv1d stack = the filter_net launches of one step (two-term fp16 split on v_mfma_f32_32x32x16_f16, three part-products per fp32 product: fused ups.4+output kernels, conv3s / conv48s for the 48..384-channel levels, conv24s / down0s for the 24-channel ones), hipEvent pair on the launch stream",
                     "launch_ms": t_filter * 1e3,
-                    "hbm_layer_boundary_frac": hbm["frac"], "hbm_moved_frac": moved, "mfma_bf16_frac": mfma["frac"],
+                    "hbm_layer_boundary_frac": hbm["frac"], "hbm_moved_frac": moved, "mfma_f16_frac": mfma["frac"],
                     "hbm": hbm, "mfma": mfma,
                     "note": "neither roof is above 0.5: the stack is issue/latency-bound between them (DESIGN.md §4)"
                             if max(mfma["frac"], moved or 0.0) < 0.5 else None}

@@ -189,3 +189,25 @@ def test_chunked_mode_matches_the_oracle_stream_loop(gen, use_pv):
     print(f"[f4] trimmed chunked output vs whole-file conversion: correlation peak {best:.3f} at lag {best_lag} samples")
     assert out.shape == (1, L)
     assert abs(best_lag) <= 240 and best > 0.5      # (the trim uses the stream's median SOLA lag; single blocks deviate by a pitch period or so)
+
+
+def test_prepared_blob_is_checked_against_the_callers_n_and_nan_rows_rank_first_in_both_searches(gen):
+    """(1) a blob prepared for N vectors must not be walked with another N (the kernels derive the blob's geometry from the
+    caller's N): the call is refused; (2) a NaN index row orders as the maximum (torch.topk) in the two-stage search (N >= 4096) exactly
+    as in the exact kernel (N < 4096)."""
+    from tinyvc_amd._lib import TinyVCError
+    from tinyvc_amd.engine import default_engine
+    from tinyvc_amd.module.tinyvc import match_features
+    eng = default_engine(torch.device(DEV))
+    g = torch.Generator().manual_seed(3)
+    idx_small = torch.randn(1, 768, 1000, generator=g)
+    blob, n = eng.knn_prepare(idx_small.to(DEV))
+    src = torch.randn(1, 768, 5, generator=g).to(DEV)
+    eng.knn_match(src, blob, n)
+    with pytest.raises(TinyVCError):
+        eng.knn_match(src, blob, n + 256)
+    for N in (1000, 5000):
+        index = torch.randn(1, 768, N, generator=g)
+        index[0, 5, 700] = float("nan")                      # one poisoned vector
+        _m, idx = match_features(src, index.to(DEV), return_indices=True)
+        assert (idx[0, :, 0] == 700).all(), f"N = {N}: the NaN row must rank first for every query"

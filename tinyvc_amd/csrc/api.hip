@@ -1,5 +1,6 @@
 // libtinyvc_hip.so — context, checkpoint packing, workspace sizing and the extern "C" surface.
 #include <cmath>
+#include <mutex>
 
 #include "tvc_common.h"
 
@@ -426,6 +427,23 @@ void build_fft_tables(Packer& pk, tvc_ctx* ctx) {
 
 }  // namespace
 
+// Prepared kNN blobs of this process: device pointer -> N it was prepared for.  The kernels take the blob's geometry (offsets of the
+// inverse norms and the fp16 image) from the caller's N, so a call whose N differs from the one the blob was prepared with would read
+// out of bounds: such a call is refused.  (A blob this process did not prepare - e.g. a copy - is unknown here and trusted.)
+static std::mutex g_blob_mu;
+static std::map<const void*, int64_t> g_blobs;
+static void blob_record(const void* p, int64_t N) {
+    std::lock_guard<std::mutex> lk(g_blob_mu);
+    g_blobs[p] = N;
+}
+static int blob_check(tvc_ctx* ctx, const void* p, int64_t N, const char* what) {
+    std::lock_guard<std::mutex> lk(g_blob_mu);
+    auto it = g_blobs.find(p);
+    if (it != g_blobs.end() && it->second != N)
+        return fail(ctx, TVC_ERR_ARG, "%s: this blob was prepared for N = %lld index vectors, the call says N = %lld", what, (long long)it->second, (long long)N);
+    return 0;
+}
+
 extern "C" {
 
 int tvc_version(void) { return TVC_ABI_VERSION; }
@@ -752,6 +770,7 @@ int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, fl
     if (!ctx) return TVC_ERR_ARG;
     if (!index || !prepared || N <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_prepare_index_f32: bad argument");
     TVC_HIP(ctx, hipSetDevice(ctx->device));
+    blob_record(prepared, N);
     return run_prepare_index(ctx, (hipStream_t)stream, index, prepared, N);
 }
 
@@ -759,6 +778,7 @@ int tvc_knn_prepare_index_f16(tvc_ctx* ctx, void* stream, const void* rows_f16, 
     if (!ctx) return TVC_ERR_ARG;
     if (!rows_f16 || !prepared || N <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_prepare_index_f16: bad argument");
     TVC_HIP(ctx, hipSetDevice(ctx->device));
+    blob_record(prepared, N);
     return run_prepare_index_f16(ctx, (hipStream_t)stream, rows_f16, prepared, N);
 }
 
@@ -767,6 +787,7 @@ int tvc_knn_match_f32(tvc_ctx* ctx, void* stream, const float* src, const float*
     if (!ctx) return TVC_ERR_ARG;
     if (!src || !prepared || !out || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_match_f32: bad argument");
     if (N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_knn_match_f32: index needs at least k=4 vectors (torch.topk raises too)");
+    TVC_CHECK(blob_check(ctx, prepared, N, "tvc_knn_match_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(run_knn(ctx, s, ws, true, src, prepared, N, out, idx_out, B, T),
@@ -778,6 +799,7 @@ int tvc_knn_topk_f32(tvc_ctx* ctx, void* stream, const float* src, const float* 
     if (!ctx) return TVC_ERR_ARG;
     if (!src || !prepared || !sims_out || !idx_out || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_topk_f32: bad argument");
     if (N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_knn_topk_f32: an index shard needs at least k=4 vectors");
+    TVC_CHECK(blob_check(ctx, prepared, N, "tvc_knn_topk_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(run_knn_topk(ctx, s, ws, true, src, prepared, N, sims_out, idx_out, B, T),
@@ -788,6 +810,7 @@ int tvc_knn_gather_slots_f32(tvc_ctx* ctx, void* stream, const float* prepared, 
                              int64_t nslots) {
     if (!ctx) return TVC_ERR_ARG;
     if (!prepared || !idx || !slots || N <= 0 || nslots <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_gather_slots_f32: bad argument");
+    TVC_CHECK(blob_check(ctx, prepared, N, "tvc_knn_gather_slots_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     return run_knn_slots(ctx, (hipStream_t)stream, prepared, N, idx, slots, nslots);
 }
@@ -852,6 +875,7 @@ int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* p
     if (!wav || !prepared || !wave || B <= 0 || L <= 0 || L % kHop) return fail(ctx, TVC_ERR_ARG, "tvc_convert_f32: bad argument (L must be a positive multiple of 480)");
     if (L < kNfft / 2 + 1) return fail(ctx, TVC_ERR_ARG, "tvc_convert_f32: L must exceed 960 samples (STFT reflect padding, as torch.stft requires)");
     if (N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_convert_f32: index needs at least k=4 vectors");
+    TVC_CHECK(blob_check(ctx, prepared, N, "tvc_convert_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(convert_impl(ctx, s, ws, true, wav, prepared, N, pitch_shift, noise_angle, seed, wave, B, L),

@@ -8,6 +8,8 @@
 #include <utility>
 
 #include "small_kernels.h"
+#include <mutex>
+
 #include "tvc_common.h"
 
 namespace tvc {
@@ -64,9 +66,15 @@ static std::map<std::pair<tvc_ctx*, std::pair<int, int>>, ResampleTable>& tables
     static std::map<std::pair<tvc_ctx*, std::pair<int, int>>, ResampleTable> t;
     return t;
 }
+static std::mutex& tables_mu() {      // one host thread per ctx is the contract, but the map is shared by the ctxs of a process
+    static std::mutex m;
+    return m;
+}
 
 // Hann-windowed sinc filter bank, computed in fp64 and rounded once (the formula of tinyvc_amd/resample.py:_kernel)
+// (the first use of a rate pair allocates and uploads its table synchronously: not inside a stream capture)
 static int get_table(tvc_ctx* ctx, int orig_freq, int new_freq, ResampleTable* out) {
+    std::lock_guard<std::mutex> lk(tables_mu());
     auto key = std::make_pair(ctx, std::make_pair(orig_freq, new_freq));
     auto it = tables().find(key);
     if (it != tables().end()) {
@@ -102,6 +110,7 @@ static int get_table(tvc_ctx* ctx, int orig_freq, int new_freq, ResampleTable* o
 }
 
 void frontdoor_release(tvc_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(tables_mu());
     for (auto it = tables().begin(); it != tables().end();) {
         if (it->first.first == ctx) {
             if (it->second.kern) (void)hipFree(it->second.kern);

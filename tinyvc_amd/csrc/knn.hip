@@ -764,13 +764,11 @@ static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __r
                     bool anynan = false;
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[i][j][r]);
-                    if (MODE == 0) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) anynan |= acc[i][j][r] != acc[i][j][r];      // NaN enters the list as +inf (nan_max): never skipped
-                    }
+                    for (int r = 0; r < 16; ++r) anynan |= acc[i][j][r] != acc[i][j][r];      // NaN orders as the maximum (nan_max, torch.topk): never skipped, in either pass
                     bool maybe;
                     if (MODE == 0) maybe = anynan || !((F16 ? fmaxf(mx, 0.f) * imx : mx) <= top[j].v[3]);
-                    else maybe = (F16 ? fmaxf(mx, 0.f) * imx : mx) >= th[j];
+                    else maybe = anynan || (F16 ? fmaxf(mx, 0.f) * imx : mx) >= th[j];
                     if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -784,9 +782,9 @@ static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __r
                                         top[j].insert(nan_max(a * inv[row]));
                                     }
                                 } else {
-                                    bool hit;
-                                    if (!F16) hit = a >= th[j];
-                                    else hit = (fmaxf(a, 0.f) * imx >= th[j]) && (a * inv[row] >= th[j]);
+                                    bool hit;                                                  // a NaN similarity is a candidate (the exact kernel ranks it first)
+                                    if (!F16) hit = !(a < th[j]);
+                                    else hit = a != a || ((fmaxf(a, 0.f) * imx >= th[j]) && (a * inv[row] >= th[j]));
                                     if (hit) {
                                         const int n = n0 + wn * 64 + j * 32 + l31;
                                         const int pos = atomicAdd(&cnt[n], 1);

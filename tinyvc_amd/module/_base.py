@@ -13,6 +13,20 @@ from ..engine import Engine
 _VERSION = operator.attrgetter("_version")
 
 
+_EPOCH = [0]        # bumped whenever ANY module's structure may have changed: every cached parameter list (a child's or its owner's) is stale then
+
+
+def _bump(*_args):
+    _EPOCH[0] += 1
+
+
+# torch calls these for every Parameter / sub-module registration of every nn.Module in the process - also the ones behind
+# `module.weight = nn.Parameter(...)`, `gen.decoder = other` and load_state_dict(assign=True) on any descendant, stock nn.Conv1d
+# leaves included.  A registration anywhere only costs the next call one walk of its own parameter tree.
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump)
+torch.nn.modules.module.register_module_module_registration_hook(_bump)
+
+
 class HipModule(nn.Module):
     """nn.Module whose parameters are a checkpoint container; compute happens in the HIP library."""
 
@@ -21,15 +35,16 @@ class HipModule(nn.Module):
 
     def _param_list(self):
         """The parameter objects, cached: walking the module tree costs ~240 us for the 282 tensors of a Generator, which
-        would be paid on every convert call and every streaming block.  Dropped whenever the module is moved / cast
-        (`_apply`) or a checkpoint is loaded, and refreshed every 256 uses in case a Parameter object was re-assigned."""
+        would be paid on every convert call and every streaming block.  The cache is keyed on a process-wide epoch that every
+        structural change bumps - torch's global registration hooks fire for a Parameter or sub-module assigned anywhere in the tree
+        (`gen.decoder = other`, `conv.weight = nn.Parameter(...)`, load_state_dict(assign=True) on a child), `_apply` (.to(), .float())
+        and `load_state_dict` bump it themselves - so an owner never keeps
+        running (or keeps replaying a captured stream graph) on a child's replaced weights."""
         d = self.__dict__
-        age = d.get("_plist_age", 0) + 1
-        if d.get("_plist") is None or age > 256:
-            d["_plist"] = list(self.parameters())
-            age = 0
-        d["_plist_age"] = age
-        return d["_plist"]
+        c = d.get("_plist")
+        if c is None or c[0] != _EPOCH[0]:
+            c = d["_plist"] = (_EPOCH[0], list(self.parameters()))
+        return c[1]
 
     def _weights_key(self):
         # in-place edits bump `_version`; .to() / .float() swap the storage (data_ptr)
@@ -37,12 +52,14 @@ class HipModule(nn.Module):
         return tuple(map(_VERSION, ps)), tuple(p.data_ptr() for p in ps)
 
     def _apply(self, fn, *args, **kwargs):
-        self.__dict__.pop("_plist", None)
+        _bump()
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
-        self.__dict__.pop("_plist", None)
-        return super().load_state_dict(*args, **kwargs)
+        _bump()
+        r = super().load_state_dict(*args, **kwargs)
+        _bump()                      # (assign=True swaps the Parameter objects during the call)
+        return r
 
     def _module_device(self):
         p = next(self.parameters(), None)
