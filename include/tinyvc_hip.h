@@ -184,6 +184,18 @@ int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* p
                     int64_t N, float pitch_shift, const float* noise_angle, uint64_t seed,
                     float* wave, int B, int64_t L, void* ws, size_t ws_bytes);
 
+/* Generator.convert over a RAGGED batch (the reference converts the files of a directory one by one: infer.py:60-66; padding
+ * them to a common length would change results - GRN and the phase scan run over the whole time axis, convnext.py:31-34).
+ * wav / wave [B, Lmax] row-major, utterance b occupies its first lens[b] samples (lens[b] % 480 == 0, 960 < lens[b] <= Lmax; the
+ * tail of a wave row is zero-filled); noise_angle [B, 961, Lmax/480] (utterance b uses its first lens[b]/480 frames) or NULL.
+ * `lens` is a HOST array (lengths are launch geometry).  Utterances of equal length run as one batch each; the batches run
+ * concurrently on streams of the context, forked from and joined into `stream`.  Every utterance gets exactly the samples a
+ * B = 1 tvc_convert_f32 call gives it.  Workspace: tvc_workspace_bytes_ragged. */
+int tvc_workspace_bytes_ragged(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, int64_t N, size_t* out_bytes);
+int tvc_convert_ragged_f32(tvc_ctx* ctx, void* stream, const float* wav, int64_t Lmax, const int64_t* lens, const float* prepared_index,
+                           int64_t N, float pitch_shift, const float* noise_angle, uint64_t seed, float* wave, int B, void* ws,
+                           size_t ws_bytes);
+
 /* streaming tail -------------------------------------------------------------------------- */
 /* StreamInfer.audio_callback after convert (reference module/infer/stream.py:74-95), batched over
  * S streams: y [S, Ly] converted buffers; sola_buf [S,1920] in/out; fade_in [1920] = the sin^2

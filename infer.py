@@ -8,7 +8,7 @@ reference infer.py:17-29) driving the HIP path.
 Differences from the reference, all at the edges of the path: files are read/written with the
 package's own WAV I/O and resampler (torchaudio is not a dependency; ogg/mp3 need a codec and are
 skipped with a message); `-d` defaults to `cuda` and must be a GPU (there is no CPU path);
-all inputs of equal padded length are converted as one batch; resampling to 24 kHz runs on the GPU
+the whole directory is converted in one call (a ragged batch: every file over its own length); resampling to 24 kHz runs on the GPU
 (tvc_resample_f32); an index.pt stored in half precision is matched with the fp16 index storage.
 
 `--chunk-size / --buffer-size / --no-chunking`: the reference parses them and then converts every file
@@ -125,20 +125,31 @@ def main(argv=None):
         wf = gen.engine(device).resample(wf.to(device), sr, SAMPLE_RATE).mean(dim=0, keepdim=True)       # mono, 24 kHz (infer.py:63-64), on the GPU
         jobs.append((path, wf))
 
-    # group equal-length inputs so each group is one batched convert
-    by_len = {}
-    for path, wf in jobs:
-        by_len.setdefault(wf.shape[1], []).append((path, wf))
-    for length, group in by_len.items():
-        print(f"Converting {len(group)} file(s) of {length} samples ...")
-        batch = torch.cat([wf for _p, wf in group], dim=0).to(device)
-        if args.chunked and not args.no_chunking:
-            out = convert_chunked(gen, batch, tgt, args.pitch_shift, args.chunk_size, args.buffer_size, args.phase_vocoder).cpu()
-        else:
-            out = gen.convert(batch, tgt, args.pitch_shift).cpu()
-        for (path, _wf), y in zip(group, out):
-            name = os.path.splitext(os.path.basename(path))[0]
-            audio_io.save(os.path.join(args.outputs, f"{name}.wav"), y[None], SAMPLE_RATE)
+    if not jobs:
+        return 0
+    # one call for the whole directory: a ragged batch (every file converted over its own length, equal-length files batched,
+    # the batches concurrent on the GPU); the reference's loop converts them one by one (infer.py:60-66)
+    lengths = [wf.shape[1] for _p, wf in jobs]
+    Lmax = -(-max(lengths) // 480) * 480
+    batch = torch.zeros(len(jobs), Lmax, device=device)
+    for i, (_p, wf) in enumerate(jobs):
+        batch[i, :wf.shape[1]] = wf[0]
+    print(f"Converting {len(jobs)} file(s), {min(lengths)} .. {max(lengths)} samples ...")
+    if args.chunked and not args.no_chunking:
+        outs = []
+        for length in sorted(set(lengths)):      # streams of one group advance in lock step: chunked mode batches equal lengths
+            rows = [i for i, n in enumerate(lengths) if n == length]
+            o = convert_chunked(gen, batch[rows, :length], tgt, args.pitch_shift, args.chunk_size, args.buffer_size, args.phase_vocoder).cpu()
+            outs += list(zip(rows, o))
+        outs = [o for _i, o in sorted(outs, key=lambda t: t[0])]
+    elif len(set(lengths)) == 1:
+        outs = list(gen.convert(batch[:, :lengths[0]], tgt, args.pitch_shift).cpu())
+    else:
+        out = gen.convert(batch, tgt, args.pitch_shift, lengths=lengths).cpu()
+        outs = [out[i, :-(-lengths[i] // 480) * 480] for i in range(len(jobs))]
+    for (path, _wf), y in zip(jobs, outs):
+        name = os.path.splitext(os.path.basename(path))[0]
+        audio_io.save(os.path.join(args.outputs, f"{name}.wav"), y[None], SAMPLE_RATE)
     return 0
 
 

@@ -176,20 +176,27 @@ def test_chunked_mode_matches_the_oracle_stream_loop(gen, use_pv):
     print(f"[f4] chunked ({'phase vocoder' if use_pv else 'sin^2'}, seed {seed}) vs oracle stream loop: {nblk} blocks, lags identical, worst block rms diff {worst:.3e}; "
           f"the oracle on 1 thread vs {nthr} threads: worst block {spread:.3e}")
     assert worst <= max(1e-4, 1.5 * spread)
-    # alignment with the whole-file result: the streaming output is the same signal delayed by SOLA_LATENCY +- the per-block lag
+    # Alignment with the whole-file result.  Block k's output is samples [lag_k, lag_k + 1920) of the window's tail (stream.py:76-83),
+    # i.e. it lags its input by 7680 - lag_k samples, and the lag wanders through the whole search range over an utterance (here
+    # 0 .. 1900): there is no single latency, the trim uses the median.  Every block is its own conversion (the oscillator's phase
+    # restarts with the window and SOLA re-aligns it), so the chunked and the whole-file waveform share their envelope, not their
+    # phase: the check is that the short-time energy contours line up within the SOLA search range and correlate at the chosen trim.
     whole = gen.convert(wf.to(DEV), tgt.to(DEV), 1.0, noise_angle=synth.synth_angle(1, -(-L // 480), 9).to(DEV))[0, :L].cpu().double()
     ch = out[0].cpu().double()
-    a, b = whole[4800:L - 4800], None
-    best, best_lag = -1.0, None
-    for lag in range(-1920, 1921, 8):
-        b = ch[4800 + lag:L - 4800 + lag]
-        c = float((a * b).sum() / (a.norm() * b.norm()))
-        if c > best:
-            best, best_lag = c, lag
-    print(f"[f4] trimmed chunked output vs whole-file conversion: correlation peak {best:.3f} at lag {best_lag} samples")
+    hop = 120
+    env = lambda x: x[: len(x) // hop * hop].view(-1, hop).pow(2).mean(dim=1).sqrt()
+    ew, ec = env(whole), env(ch)
+    ew, ec = ew - ew.mean(), ec - ec.mean()
+    n = len(ew)
+    corr = {}
+    for lag in range(-16, 17):                     # +- 1920 samples
+        a_, b_ = ew[20:n - 20], ec[20 + lag:n - 20 + lag]
+        corr[lag * hop] = float((a_ * b_).sum() / (a_.norm() * b_.norm()))
+    best_lag = max(corr, key=corr.get)
+    print(f"[f4] trimmed chunked output vs whole-file conversion: energy-envelope correlation {corr[0]:.3f} at the trim, peak {corr[best_lag]:.3f} at lag {best_lag} samples; "
+          f"SOLA lags {int(lags.min())} .. {int(lags.max())}")
     assert out.shape == (1, L)
-    assert abs(best_lag) <= 240 and best > 0.5      # (the trim uses the stream's median SOLA lag; single blocks deviate by a pitch period or so)
-
+    assert corr[0] > 0.85 and abs(best_lag) < 1920
 
 def test_prepared_blob_is_checked_against_the_callers_n_and_nan_rows_rank_first_in_both_searches(gen):
     """(1) a blob prepared for N vectors must not be walked with another N (the kernels derive the blob's geometry from the

@@ -1,0 +1,102 @@
+"""Ragged batches through the C ABI (tvc_convert_ragged_f32): utterances of different lengths in one call.
+
+The reference converts the files of a directory one by one (infer.py:60-66), and padding a batch to a common length changes results
+(GRN normalises over the whole time axis, convnext.py:31-34; the oscillator's phase is a scan over it).  So the contract is: every
+utterance of a ragged batch gets exactly the samples its own B = 1 call gives it, and those are within 1e-4 of the oracle."""
+import os
+
+import pytest
+import torch
+
+from helpers import oracle_one_thread, rms, state_dicts
+from oracle import ref_cpu as R
+from tinyvc_amd import audio_io, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gen():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from tinyvc_amd.module.infer import Generator
+    from tinyvc_amd.module.tinyvc import Decoder, Encoder
+    enc_sd, dec_sd = state_dicts(0)
+    enc, dec = Encoder(), Decoder()
+    enc.load_state_dict(enc_sd)
+    dec.load_state_dict(dec_sd)
+    return Generator(enc, dec).to(DEV)
+
+
+def test_ragged_batch_equals_one_call_per_utterance_and_the_oracle(gen):
+    enc_sd, dec_sd = state_dicts(0)
+    frames = [33, 7, 50, 7, 3, 50, 21, 7, 12]                   # three groups of equal length among them, the shortest legal input too
+    lens = [480 * f - (17 if i % 2 else 0) for i, f in enumerate(frames)]      # some not yet padded to a frame
+    B, Lmax, Tmax = len(frames), 480 * max(frames), max(frames)
+    wf = torch.zeros(B, Lmax)
+    for b, n in enumerate(lens):
+        wf[b, :n] = synth.synth_wave(1, n, seed=500 + b)[0]
+    tgt = synth.synth_index(777, seed=8)
+    angle = synth.synth_angle(B, Tmax, 31)
+    out = gen.convert(wf.to(DEV), tgt.to(DEV), -1.5, noise_angle=angle.to(DEV), lengths=lens)
+    assert out.shape == (B, Lmax)
+    worst = 0.0
+    for b, f in enumerate(frames):
+        L = 480 * f
+        one = gen.convert(wf[b:b + 1, :lens[b]].to(DEV), tgt.to(DEV), -1.5, noise_angle=angle[b:b + 1, :, :f].contiguous().to(DEV))
+        assert one.shape == (1, L)
+        assert torch.equal(out[b, :L], one[0]), f"utterance {b} ({f} frames): ragged batch != its own B = 1 call"
+        assert not out[b, L:].any(), "the tail of a row is zero-filled"
+        with oracle_one_thread():
+            ref = R.convert(enc_sd, dec_sd, wf[b:b + 1, :lens[b]], tgt, -1.5, angle[b:b + 1, :, :f])
+        d = rms(out[b, :L].cpu() - ref[0])
+        worst = max(worst, d)
+        assert d <= 1e-4, f"utterance {b}: {d:.3e}"
+    print(f"[ragged] {B} utterances of {sorted(set(frames))} frames in one call: each equals its B = 1 call bit for bit; worst rms vs the oracle {worst:.3e}")
+    # a second, differently shaped ragged call on the same engine (workspace regrowth, lane reuse)
+    out2 = gen.convert(wf[:4].to(DEV), tgt.to(DEV), -1.5, noise_angle=angle[:4].to(DEV), lengths=lens[:4])
+    for b in range(4):
+        assert torch.equal(out2[b], out[b])
+
+
+def test_ragged_arguments_are_validated(gen):
+    from tinyvc_amd._lib import TinyVCError
+    tgt = synth.synth_index(64, seed=1).to(DEV)
+    wf = torch.zeros(2, 4800, device=DEV)
+    with pytest.raises((ValueError, TinyVCError)):
+        gen.convert(wf, tgt, 0.0, lengths=[4800, 900])            # torch.stft's reflect padding needs more than 960 samples
+    with pytest.raises((ValueError, TinyVCError)):
+        gen.convert(wf, tgt, 0.0, lengths=[4800, 9600])           # longer than its row
+
+
+def test_infer_py_converts_a_directory_of_different_lengths_in_one_call(tmp_path):
+    import infer
+    d = tmp_path
+    torch.save(synth.synth_state_dict("encoder"), d / "encoder.pt")
+    torch.save(synth.synth_state_dict("decoder"), d / "decoder.pt")
+    torch.save(synth.synth_index(300, seed=2), d / "index.pt")
+    (d / "inputs").mkdir()
+    lens = {"a": 12000, "b": 7777, "c": 12000, "d": 20011}
+    for i, (name, n) in enumerate(lens.items()):
+        audio_io.save(str(d / "inputs" / f"{name}.wav"), synth.synth_wave(1, n, seed=60 + i), 24000)
+    gen = infer.load_generator(str(d / "encoder.pt"), str(d / "decoder.pt"), torch.device(DEV))
+    calls = []
+    orig = type(gen).convert
+
+    def spy(self, *a, **k):
+        calls.append(k.get("lengths"))
+        return orig(self, *a, **k)
+
+    type(gen).convert = spy
+    try:
+        torch.manual_seed(0)
+        rc = infer.main(["-i", str(d / "inputs"), "-o", str(d / "out"), "-encp", str(d / "encoder.pt"), "-decp", str(d / "decoder.pt"),
+                         "-idx", str(d / "index.pt"), "-d", DEV])
+    finally:
+        type(gen).convert = orig
+    assert rc == 0
+    assert len(calls) == 1 and sorted(calls[0]) == sorted(lens.values()), "the directory must be converted in ONE ragged call"
+    for name, n in lens.items():
+        y, sr = audio_io.load(str(d / "out" / f"{name}.wav"))
+        assert sr == 24000 and y.shape == (1, -(-n // 480) * 480) and torch.isfinite(y).all() and float(y.abs().max()) > 1e-3
+    assert os.path.exists(d / "out" / "d.wav")

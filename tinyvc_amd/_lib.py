@@ -44,6 +44,8 @@ SIGNATURES = {
     "tvc_filter_net_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_void_p, c_size_t]),
     "tvc_dsp_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_convert_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_uint64, c_void_p, c_int, c_int64, c_void_p, c_size_t]),
+    "tvc_workspace_bytes_ragged": (c_int, [c_void_p, c_int, c_int64, POINTER(c_int64), c_int64, POINTER(c_size_t)]),
+    "tvc_convert_ragged_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int64), c_void_p, c_int64, c_float, c_void_p, c_uint64, c_void_p, c_int, c_void_p, c_size_t]),
     "tvc_sola_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int]),
     "tvc_profile_enable": (c_int, [c_void_p, c_int]),
     "tvc_profile_read": (c_int, [c_void_p, ctypes.c_char_p, c_size_t]),

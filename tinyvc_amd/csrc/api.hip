@@ -1,5 +1,6 @@
 // libtinyvc_hip.so — context, checkpoint packing, workspace sizing and the extern "C" surface.
 #include <cmath>
+#include <functional>
 #include <mutex>
 
 #include "tvc_common.h"
@@ -488,6 +489,14 @@ void tvc_ctx_destroy(tvc_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    for (auto& ln : ctx->lanes) {
+        if (ln.s) (void)hipStreamDestroy(ln.s);
+        if (ln.side) (void)hipStreamDestroy(ln.side);
+        if (ln.fork) (void)hipEventDestroy(ln.fork);
+        if (ln.join) (void)hipEventDestroy(ln.join);
+        if (ln.done) (void)hipEventDestroy(ln.done);
+    }
+    if (ctx->ev_ragged) (void)hipEventDestroy(ctx->ev_ragged);
     frontdoor_release(ctx);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->const_arena) (void)hipFree(ctx->const_arena);
@@ -880,6 +889,151 @@ int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* p
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(convert_impl(ctx, s, ws, true, wav, prepared, N, pitch_shift, noise_angle, seed, wave, B, L),
             convert_impl(ctx, s, ws, false, wav, prepared, N, pitch_shift, noise_angle, seed, wave, B, L));
+}
+
+// ---- ragged batches ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kLanes = 4;
+struct RaggedGroup {
+    int64_t L;
+    std::vector<int> rows;
+    int lane;
+};
+// equal-length groups, longest first, dealt to the lane with the least work so far
+int ragged_plan(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, std::vector<RaggedGroup>* groups) {
+    std::map<int64_t, std::vector<int>, std::greater<int64_t>> by_len;
+    for (int b = 0; b < B; ++b) {
+        if (lens[b] <= 0 || lens[b] % kHop || lens[b] > Lmax || lens[b] < kNfft / 2 + 1)
+            return fail(ctx, TVC_ERR_ARG, "ragged batch: lens[%d] = %lld must be a multiple of 480 in (960, Lmax]", b, (long long)lens[b]);
+        by_len[lens[b]].push_back(b);
+    }
+    double load[kLanes] = {0, 0, 0, 0};
+    for (auto& kv : by_len) {
+        int best = 0;
+        for (int l = 1; l < kLanes; ++l)
+            if (load[l] < load[best]) best = l;
+        load[best] += (double)kv.first * (double)kv.second.size() + 50000.0;      // (+ a launch-bound floor per group)
+        groups->push_back({kv.first, kv.second, best});
+    }
+    return 0;
+}
+// one group's scratch: [gathered wav][gathered angle][gathered out][convert workspace]; B_g == 1 rows are used in place
+int ragged_group(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const RaggedGroup& g, const float* wav, int64_t Lmax, const float* prepared, int64_t N,
+                 float pitch_shift, const float* angle, uint64_t seed, float* wave) {
+    const int Bg = (int)g.rows.size();
+    const int64_t L = g.L, T = L / kHop, Tmax = Lmax / kHop;
+    const bool gather = Bg > 1 && L != Lmax;
+    const bool gather_angle = angle && T != Tmax;
+    float* gw = gather || Bg > 1 ? ws.get<float>((size_t)Bg * L) : nullptr;
+    float* go = gather || Bg > 1 ? ws.get<float>((size_t)Bg * L) : nullptr;
+    float* ga = angle && (gather_angle || Bg > 1) ? ws.get<float>((size_t)Bg * kBins * T) : nullptr;
+    const float* in = gw;
+    float* out = go;
+    const float* ang = ga;
+    if (Bg == 1) {
+        in = wav + (size_t)g.rows[0] * Lmax;
+        out = wave + (size_t)g.rows[0] * Lmax;
+        if (angle && !gather_angle) ang = angle + (size_t)g.rows[0] * kBins * Tmax;
+    }
+    if (!dry) {
+        for (int i = 0; i < Bg; ++i) {
+            const int b = g.rows[i];
+            if (Bg > 1) TVC_HIP(ctx, hipMemcpyAsync(gw + (size_t)i * L, wav + (size_t)b * Lmax, (size_t)L * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (ga) TVC_HIP(ctx, hipMemcpy2DAsync(ga + (size_t)i * kBins * T, (size_t)T * sizeof(float), angle + (size_t)b * kBins * Tmax, (size_t)Tmax * sizeof(float),
+                                                   (size_t)T * sizeof(float), kBins, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    TVC_CHECK(convert_impl(ctx, s, ws, dry, in, prepared, N, pitch_shift, ang, seed + (uint64_t)g.rows[0] * 0x9E3779B97F4A7C15ull, out, Bg, L));
+    if (!dry) {
+        for (int i = 0; i < Bg; ++i) {
+            const int b = g.rows[i];
+            if (Bg > 1) TVC_HIP(ctx, hipMemcpyAsync(wave + (size_t)b * Lmax, go + (size_t)i * L, (size_t)L * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (L < Lmax) TVC_HIP(ctx, hipMemsetAsync(wave + (size_t)b * Lmax + L, 0, (size_t)(Lmax - L) * sizeof(float), s));
+        }
+    }
+    return 0;
+}
+// lanes' workspace regions: lane l starts at off[l]; every group of a lane reuses its region from the start
+int ragged_sizes(tvc_ctx* ctx, const std::vector<RaggedGroup>& groups, int64_t Lmax, int64_t N, bool with_angle, size_t* lane_bytes) {
+    for (int l = 0; l < kLanes; ++l) lane_bytes[l] = 0;
+    for (auto& g : groups) {
+        Ws ws(nullptr, 0, true);
+        TVC_CHECK(ragged_group(ctx, nullptr, ws, true, g, nullptr, Lmax, nullptr, N, 0.f, with_angle ? (const float*)256 : nullptr, 0, nullptr));
+        const size_t need = (ws.peak + 4095) & ~size_t(4095);
+        if (need > lane_bytes[g.lane]) lane_bytes[g.lane] = need;
+    }
+    return 0;
+}
+}  // namespace
+
+int tvc_workspace_bytes_ragged(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, int64_t N, size_t* out_bytes) {
+    TVC_CHECK(need_ready(ctx, NEED_NONE));
+    if (!out_bytes || !lens || B <= 0 || Lmax <= 0 || Lmax % kHop != 0 || N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_workspace_bytes_ragged: need B>0, Lmax%%480==0, N>=4");
+    std::vector<RaggedGroup> groups;
+    TVC_CHECK(ragged_plan(ctx, B, Lmax, lens, &groups));
+    size_t lb[kLanes];
+    TVC_CHECK(ragged_sizes(ctx, groups, Lmax, N, true, lb));
+    *out_bytes = lb[0] + lb[1] + lb[2] + lb[3] + 4096;
+    return TVC_OK;
+}
+
+int tvc_convert_ragged_f32(tvc_ctx* ctx, void* stream, const float* wav, int64_t Lmax, const int64_t* lens, const float* prepared, int64_t N,
+                           float pitch_shift, const float* noise_angle, uint64_t seed, float* wave, int B, void* wsp, size_t ws_bytes) {
+    TVC_CHECK(need_ready(ctx, NEED_ENC | NEED_DEC));
+    if (!wav || !lens || !prepared || !wave || B <= 0 || Lmax <= 0 || Lmax % kHop) return fail(ctx, TVC_ERR_ARG, "tvc_convert_ragged_f32: bad argument (Lmax must be a positive multiple of 480)");
+    if (N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_convert_ragged_f32: index needs at least k=4 vectors");
+    TVC_CHECK(blob_check(ctx, prepared, N, "tvc_convert_ragged_f32"));
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<RaggedGroup> groups;
+    TVC_CHECK(ragged_plan(ctx, B, Lmax, lens, &groups));
+    size_t lb[kLanes];
+    TVC_CHECK(ragged_sizes(ctx, groups, Lmax, N, noise_angle != nullptr, lb));
+    if (lb[0] + lb[1] + lb[2] + lb[3] > ws_bytes)
+        return fail(ctx, TVC_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", lb[0] + lb[1] + lb[2] + lb[3], ws_bytes);
+    if (ctx->lanes.empty()) {      // created on first use (not inside a stream capture)
+        ctx->lanes.resize(kLanes);
+        for (auto& ln : ctx->lanes) {
+            TVC_HIP(ctx, hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));
+            TVC_HIP(ctx, hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
+            TVC_HIP(ctx, hipEventCreateWithFlags(&ln.fork, hipEventDisableTiming));
+            TVC_HIP(ctx, hipEventCreateWithFlags(&ln.join, hipEventDisableTiming));
+            TVC_HIP(ctx, hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+        }
+        TVC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ragged, hipEventDisableTiming));
+    }
+    // fork: every lane that has work starts behind what is already queued on the caller's stream
+    TVC_HIP(ctx, hipEventRecord(ctx->ev_ragged, s));
+    bool used[kLanes] = {false, false, false, false};
+    size_t off[kLanes];
+    off[0] = 0;
+    for (int l = 1; l < kLanes; ++l) off[l] = off[l - 1] + lb[l - 1];
+    hipStream_t side0 = ctx->side;
+    hipEvent_t fork0 = ctx->ev_fork, join0 = ctx->ev_join;
+    int rc = 0;
+    for (auto& g : groups) {
+        tvc_ctx::Lane& ln = ctx->lanes[g.lane];
+        if (!used[g.lane]) {
+            if (hipStreamWaitEvent(ln.s, ctx->ev_ragged, 0) != hipSuccess) { rc = fail(ctx, TVC_ERR_HIP, "ragged: stream wait"); break; }
+            used[g.lane] = true;
+        }
+        ctx->side = ln.side;             // the pitch branch of this group forks onto the lane's own side stream
+        ctx->ev_fork = ln.fork;
+        ctx->ev_join = ln.join;
+        Ws ws((char*)wsp + off[g.lane], lb[g.lane], false);
+        rc = ragged_group(ctx, ln.s, ws, false, g, wav, Lmax, prepared, N, pitch_shift, noise_angle, seed, wave);
+        if (rc) break;
+    }
+    ctx->side = side0;
+    ctx->ev_fork = fork0;
+    ctx->ev_join = join0;
+    // join (also on an error path: the caller's stream must not run ahead of what was queued)
+    for (int l = 0; l < kLanes; ++l)
+        if (used[l]) {
+            (void)hipEventRecord(ctx->lanes[l].done, ctx->lanes[l].s);
+            (void)hipStreamWaitEvent(s, ctx->lanes[l].done, 0);
+        }
+    return rc;
 }
 
 int tvc_profile_enable(tvc_ctx* ctx, int on) {

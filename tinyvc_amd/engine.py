@@ -350,6 +350,25 @@ class Engine:
         self._ok(self.lib.tvc_convert_f32(self.ctx, self._stream(), _ptr(wav), _ptr(prepared), N, float(pitch_shift), _ptr(a), seed, _ptr(wave), B, L, p, n), "tvc_convert_f32")
         return wave
 
+    def convert_ragged(self, wav, lengths, prepared, N, pitch_shift, noise_angle=None):
+        """wav [B, Lmax] (row b holds an utterance of lengths[b] samples, a multiple of 480, zero-padded behind it) -> [B, Lmax]:
+        every utterance converted over its OWN length (tvc_convert_ragged_f32: equal-length groups run as concurrent batches)."""
+        wav = _prep(wav, "wave", self.device)
+        B, Lmax = wav.shape
+        if Lmax % spec.HOP:
+            raise ValueError("the padded length must be a multiple of 480")
+        lens = (ctypes.c_int64 * B)(*[int(x) for x in lengths])
+        a, seed = self._angle(noise_angle, B, Lmax // spec.HOP)
+        need = ctypes.c_size_t()
+        self._ok(self.lib.tvc_workspace_bytes_ragged(self.ctx, B, Lmax, lens, int(max(N, 4)), ctypes.byref(need)), "tvc_workspace_bytes_ragged")
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        wave = torch.empty(B, Lmax, dtype=_F32, device=self.device)
+        self._ok(self.lib.tvc_convert_ragged_f32(self.ctx, self._stream(), _ptr(wav), Lmax, lens, _ptr(prepared), N, float(pitch_shift), _ptr(a), seed,
+                                                 _ptr(wave), B, _ptr(self._ws), ctypes.c_size_t(self._ws.numel())), "tvc_convert_ragged_f32")
+        return wave
+
     def sola(self, y, sola_buf, fade_in, block, use_phase_vocoder=False, want_shift=False):
         """y [S, Ly]; sola_buf [S, 1920] updated in place; returns out [S, block] (and shifts)."""
         y = _prep(y, "y", self.device)

@@ -28,11 +28,15 @@ class Generator(HipModule):
         return ssl, f0
 
     @torch.no_grad()
-    def convert(self, wf, tgt, pitch_shift, f0_estimation="default", device=None, noise_angle=None):
+    def convert(self, wf, tgt, pitch_shift, f0_estimation="default", device=None, noise_angle=None, lengths=None):
         """generator.py:26-34: wf [B, L], tgt [1 or B, 768, N] -> converted waveform [B, L'] (L' = L
         padded to a multiple of 480).  `f0_estimation` / `device` are accepted and ignored exactly as
         in the reference.  `noise_angle` [B,961,T] (extension) injects the decoder's noise phases;
-        by default they are drawn with torch.rand on the device, as the reference does."""
+        by default they are drawn with torch.rand on the device, as the reference does.
+        `lengths` (extension): a RAGGED batch - row b of wf holds an utterance of lengths[b] samples, zero-padded behind it.
+        Every utterance is converted over its own length (padded to a multiple of 480), exactly as if it were converted
+        alone (the reference's loop, infer.py:60-66; GRN and the oscillator's phase run over the whole time axis, so padding
+        to a common length would change the results); row b of the result holds it, zeros behind."""
         wf = utils.autopad_waveform(self._input_device(wf))
         tgt = self._input_device(tgt)
         eng = self.engine(wf.device)
@@ -41,6 +45,14 @@ class Generator(HipModule):
             noise_angle = Decoder.draw_noise_angle(B, L // 480, wf.device)
         else:
             noise_angle = self._input_device(noise_angle)
+        if lengths is not None:
+            lens = [-(-int(n) // 480) * 480 for n in lengths]
+            if len(lens) != B or max(lens) > L or min(lens) <= 960:
+                raise ValueError("lengths: one entry per row, each in (960, L]")
+            if tgt.shape[0] != 1:
+                raise ValueError("a ragged batch takes one shared index")
+            blob, n = prepare_reference(tgt)
+            return eng.convert_ragged(wf, lens, blob, n, pitch_shift, noise_angle)
         if tgt.shape[0] == 1:
             blob, n = prepare_reference(tgt)
             return eng.convert(wf, blob, n, pitch_shift, noise_angle)
