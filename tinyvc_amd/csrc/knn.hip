@@ -785,6 +785,7 @@ static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __r
                                     bool hit;                                                  // a NaN similarity is a candidate (the exact kernel ranks it first)
                                     if (!F16) hit = !(a < th[j]);
                                     else hit = a != a || ((fmaxf(a, 0.f) * imx >= th[j]) && (a * inv[row] >= th[j]));
+                                    hit = hit && th[j] != INFINITY;                            // a padding column of the 256-query tile has no list (its threshold is +inf)
                                     if (hit) {
                                         const int n = n0 + wn * 64 + j * 32 + l31;
                                         const int pos = atomicAdd(&cnt[n], 1);
