@@ -403,6 +403,366 @@ int launch48(tvc_ctx* ctx, hipStream_t s, Conv48Args a, int B) {
     return launch_check(ctx, "conv48s");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two consecutive 48-channel convs in ONE kernel: out = conv_b(lrelu(conv_a(lrelu(x)) + b_a)) [FiLM(cond), + residual], the
+// first conv's output never leaves the CU (Upsample 3: c1 -> c2 + FiLM1 + x_up, decoder.py:173-182; Downsample 2: c1 -> c2,
+// decoder.py:150-155).  The second conv's halo is 2 * dil_b samples of a 128-column tile (5 % recompute at dil_b = 3; the
+// c3 -> c4 pair, dil 27, would recompute 42 %: not fused), so a tile is 128 columns of the intermediate h and 128 - 2 dil_b
+// output columns.  Both convs' weights (and FiLM's) are resident in LDS; h is split into the second conv's operand tile by
+// the first conv's epilogue with an exact per-tile power-of-two pre-scale (the tile's |max| meets in LDS behind the barrier
+// between the two convs); replicate padding of h at the utterance ends = a column clamp when the second conv reads it.
+struct Conv48PArgs {
+    const float* x;        // [B][48][len], or (LERP) the low-rate tensor [B][48][lin]
+    const float* cond;     // FILM: [B][48][len]
+    const float* res;      // RES 2: low-rate [B][48][rlin], interpolated here
+    float* out;            // [B][48][len]
+    const u32x4* Aa;       // first / second conv image, 36 pieces each
+    const u32x4* Ab;
+    const u32x4* F6;       // stacked FiLM image, 24 pieces
+    const float *bias_a, *bias_b, *bsc, *bsh;
+    const float *wsc_a, *wsc_b, *fsc;
+    const float* amax_x;
+    const float* amax_c;
+    float* amax_y;
+    int len, da, db, lin, rlin, tiles_per_utt, ntiles;
+    float lscale, rscale;
+};
+constexpr int kXPP = 136;      // input tile columns: 128 + 2 * dil_a (dil_a <= 4)
+
+template <bool FILM, bool LERP, int RES>
+__global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void conv48p_kernel(Conv48PArgs a) {
+    constexpr int C = kC48, NT = kNT48, XP = kXPP, HP = 128;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_p[];
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem_p);              // [2 parts][6 groups][XP]: lrelu(x), split
+    u32x4* Hs = Xs + 12 * XP;                                  // [2 parts][6 groups][HP]: lrelu(conv_a + b_a), split
+    u32x4* Wa = Hs + 12 * HP;                                  // 36 pieces
+    u32x4* Wb = Wa + 36 * 64;                                  // 36 pieces
+    u32x4* Ft = Wb + 36 * 64;                                  // 24 pieces (FILM)
+    float* Bi = reinterpret_cast<float*>(Ft + (FILM ? 24 * 64 : 0));    // bias_a, bias_b, bsc, bsh [64 each], [256] = the h tile's |max|, [260..267] = |max| exchange
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int mt = wave >> 2, nt = wave & 3;
+    const int len = a.len, da = a.da, db = a.db;
+    const int BNO = 128 - 2 * db;                              // output columns per tile
+    const int XW = 128 + 2 * da;
+    const int lin = LERP ? a.lin : len;
+
+    for (int i = tid; i < 36 * 64; i += NT) {
+        Wa[i] = a.Aa[i];
+        Wb[i] = a.Ab[i];
+    }
+    if (FILM)
+        for (int i = tid; i < 24 * 64; i += NT) Ft[i] = a.F6[i];
+    if (tid < 64) {
+        const int tc = tid < C ? tid : C - 1;
+        Bi[tid] = a.bias_a[tc];
+        Bi[64 + tid] = a.bias_b[tc];
+        if (FILM) {
+            Bi[128 + tid] = a.bsc[tc];
+            Bi[192 + tid] = a.bsh[tc];
+        }
+    }
+    if (tid == 0) Bi[256] = 0.f;
+    const float cwa = a.wsc_a[mt], cwb = a.wsc_b[mt], cwsc = FILM ? a.fsc[mt] : 1.f, cwsh = FILM ? a.fsc[2 + mt] : 1.f;
+
+    // staging items (8-channel group, column): 6 * XW <= 816 of them, two per thread
+    constexpr int XPER = 2;
+    float xr0[XPER][8], xr1[LERP ? XPER : 1][8], lam[LERP ? XPER : 1];
+    int ig[XPER], ic[XPER];
+#pragma unroll
+    for (int i = 0; i < XPER; ++i) {
+        const int idx = tid + i * NT;
+        const int g = idx / XW;
+        ic[i] = idx - g * XW;
+        ig[i] = g;                                             // g >= 6: idle item (loads a valid address, never stores)
+    }
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+        const int b = tile / a.tiles_per_utt;
+        const int px0 = (tile - b * a.tiles_per_utt) * BNO - db - da;
+        const float* xb = a.x + (long)b * C * lin;
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) {
+            const int g = ig[i] > 5 ? 5 : ig[i];
+            int p = px0 + ic[i];
+            p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+            if (LERP) {
+                const Lerp lc = lerp_coord(p, a.lscale, lin);
+                lam[i] = lc.w1;
+                const unsigned o0 = 4u * (unsigned)(8 * g * lin + lc.i0), o1 = 4u * (unsigned)(8 * g * lin + lc.i1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xr0[i][j] = ldg_so(xb + (long)j * lin, o0);
+                    xr1[i][j] = ldg_so(xb + (long)j * lin, o1);
+                }
+            } else {
+                const unsigned o = 4u * (unsigned)(8 * g * lin + p);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xb + (long)j * lin, o);
+            }
+        }
+    };
+    auto deposit = [&](float xs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) {
+            if (ig[i] > 5) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = LERP ? fmaf(1.f - lam[i], xr0[i][j], __fmul_rn(lam[i], xr1[i][j])) : xr0[i][j];   // = lerp_eval
+                v[j] = fmaxf(t, 0.1f * t) * xs;                                                             // = leaky_relu(x, 0.1), scaled
+            }
+            uint4 p1, p2;
+            split8(v, p1, p2);
+            Xs[(0 + ig[i]) * XP + ic[i]] = __builtin_bit_cast(u32x4, p1);
+            Xs[(6 + ig[i]) * XP + ic[i]] = __builtin_bit_cast(u32x4, p2);
+        }
+    };
+
+    int tile, tend;
+    tile_range(a.ntiles, tile, tend);
+    if (tile >= tend) return;
+    fetch(tile);
+    deposit(bfp_load(a.amax_x, tile / a.tiles_per_utt).s);
+    if (tile + 1 < tend) fetch(tile + 1);
+    slab_barrier();
+    float mx_run = 0.f;
+    int mx_b = tile / a.tiles_per_utt;
+
+    for (; tile < tend; ++tile) {
+        const int b = tile / a.tiles_per_utt;
+        if (a.amax_y && b != mx_b) {
+            amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 260);
+            mx_run = 0.f;
+            mx_b = b;
+        }
+        const Bfp sx = bfp_load(a.amax_x, b), sc = FILM ? bfp_load(a.amax_c, b) : Bfp{1.f, 1.f};
+        const int t0 = (tile - b * a.tiles_per_utt) * BNO;
+        const int next = tile + 1;
+        const int n = nt * 32 + l31;                       // this lane's column: of h in the first conv, of the output in the second
+        const int t = t0 + n;
+        const bool live = n < BNO && t < len;
+        const int tc = t < len ? t : len - 1;
+        const unsigned oo = 4u * (unsigned)((32 * mt + 4 * lh) * len + tc);
+
+        float cr[FILM ? 3 : 1][8];
+        if (FILM) {
+            const float* cb = a.cond + (long)b * C * len;
+            const unsigned oc = 4u * (unsigned)(8 * lh * len + tc);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cr[s][j] = ldg_so(cb + (long)(16 * s + j) * len, oc);
+        }
+        float rv[RES ? 4 : 1][4];
+        if (RES == 2) {
+            const float* rb = a.res + (long)b * C * a.rlin;
+            const Lerp lc = lerp_coord(tc, a.rscale, a.rlin);
+            const unsigned o0 = 4u * (unsigned)((32 * mt + 4 * lh) * a.rlin + lc.i0), o1 = 4u * (unsigned)((32 * mt + 4 * lh) * a.rlin + lc.i1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x0 = 0.f, x1 = 0.f;
+                    if (32 * mt + 8 * g < C) {
+                        x0 = ldg_so(rb + (long)(8 * g + q) * a.rlin, o0);
+                        x1 = ldg_so(rb + (long)(8 * g + q) * a.rlin, o1);
+                    }
+                    rv[g][q] = fmaf(lc.w0, x0, __fmul_rn(lc.w1, x1));      // = lerp_eval
+                }
+        }
+
+        // ---- first conv: h column n (position t0 - db + n) from Xs columns n + tap * da -------------------------------------
+        f32x16 acc, alo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = alo[r] = 0.f;
+        {
+            f16x8 af[2][2], bf[2][2];
+            auto frags = [&](int s, int fb) __attribute__((always_inline)) {
+                const int sl = s / 3, tap = s - sl * 3;
+                const int row = (2 * sl + lh) * XP + n + tap * da;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    bf[fb][p] = __builtin_bit_cast(f16x8, Xs[p * 6 * XP + row]);
+                    af[fb][p] = __builtin_bit_cast(f16x8, Wa[((s * 2 + mt) * 2 + p) * 64 + lane]);
+                }
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const int fb = s & 1;
+                if (s + 1 < 9) frags(s + 1, fb ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                alo = TVC_MFMA16(af[fb][1], bf[fb][0], alo);
+                acc = TVC_MFMA16(af[fb][0], bf[fb][0], acc);
+                alo = TVC_MFMA16(af[fb][0], bf[fb][1], alo);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // h = lrelu(conv_a + b_a); its tile |max| -> LDS; after the barrier: pre-scale, split, rows [part][group 4 mt + g][column]
+        float hv[4][4];
+        float hmx = 0.f;
+        {
+            const float c = cwa * sx.inv, cl = c * kLoInv;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4s_t bv = *reinterpret_cast<const f32x4s_t*>(Bi + 32 * mt + 8 * g + 4 * lh);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = comb(acc[4 * g + q], alo[4 * g + q], c, cl) + bv[q];
+                    hv[g][q] = fmaxf(v, 0.1f * v);
+                    if (32 * mt + 8 * g < C) hmx = fmaxf(hmx, fabsf(hv[g][q]));
+                }
+            }
+            hmx = wave_max(hmx);
+            if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(Bi + 256), __builtin_bit_cast(unsigned, hmx));
+        }
+        slab_barrier();                                   // the h tile's |max| is complete (Hs itself was last read before the previous tile's closing barriers)
+        const Bfp sh_ = bfp_from_amax(Bi[256]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (32 * mt + 8 * g >= C) continue;
+            u32x2_t p1, p2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[g][q] *= sh_.s;
+            split4_48(hv[g], p1, p2);
+            const auto sx_ = __builtin_amdgcn_permlane32_swap(p1[0], p2[0], false, false);
+            const auto sy_ = __builtin_amdgcn_permlane32_swap(p1[1], p2[1], false, false);
+            const u32x4 row = {sx_[0], sy_[0], sx_[1], sy_[1]};
+            *reinterpret_cast<u32x4*>(Hs + (6 * lh + 4 * mt + g) * HP + n) = row;
+        }
+        slab_barrier();                                   // Hs is complete; every wave has read the tile |max|
+        if (tid == 0) Bi[256] = 0.f;                      // (its next use is behind the next tile's barriers)
+
+        // ---- second conv: output column n from Hs columns n + tap * db, clamped to the utterance (replicate padding of h) ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = alo[r] = 0.f;
+        {
+            const int lo = db - t0 > 0 ? db - t0 : 0;                                  // h column of position 0
+            const int hi = len - 1 - t0 + db < HP - 1 ? len - 1 - t0 + db : HP - 1;    // ... of position len - 1
+            int col[3];
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                int c = n + tap * db;
+                c = c > HP - 1 ? HP - 1 : c;              // (lanes past the tile's output columns: any valid column)
+                col[tap] = c < lo ? lo : (c > hi ? hi : c);
+            }
+            f16x8 af[2][2], bf[2][2];
+            auto frags = [&](int s, int fb) __attribute__((always_inline)) {
+                const int sl = s / 3, tap = s - sl * 3;
+                const int row = (2 * sl + lh) * HP + col[tap];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    bf[fb][p] = __builtin_bit_cast(f16x8, Hs[p * 6 * HP + row]);
+                    af[fb][p] = __builtin_bit_cast(f16x8, Wb[((s * 2 + mt) * 2 + p) * 64 + lane]);
+                }
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const int fb = s & 1;
+                if (s + 1 < 9) frags(s + 1, fb ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                alo = TVC_MFMA16(af[fb][1], bf[fb][0], alo);
+                acc = TVC_MFMA16(af[fb][0], bf[fb][0], acc);
+                alo = TVC_MFMA16(af[fb][0], bf[fb][1], alo);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {
+            const float c = cwb * sh_.inv, cl = c * kLoInv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = comb(acc[r], alo[r], c, cl);
+        }
+        f32x16 asc, ash;
+        if (FILM) {
+            f32x16 lsc, lsh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asc[r] = ash[r] = lsc[r] = lsh[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cr[s][j] *= sc.s;
+                uint4 p1, p2;
+                split8(cr[s], p1, p2);
+                const f16x8 cf[2] = {__builtin_bit_cast(f16x8, p1), __builtin_bit_cast(f16x8, p2)};
+                f16x8 fa[2][2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    fa[0][p] = __builtin_bit_cast(f16x8, Ft[((s * 4 + mt) * 2 + p) * 64 + lane]);
+                    fa[1][p] = __builtin_bit_cast(f16x8, Ft[((s * 4 + 2 + mt) * 2 + p) * 64 + lane]);
+                }
+                lsc = TVC_MFMA16(fa[0][1], cf[0], lsc);
+                lsh = TVC_MFMA16(fa[1][1], cf[0], lsh);
+                asc = TVC_MFMA16(fa[0][0], cf[0], asc);
+                ash = TVC_MFMA16(fa[1][0], cf[0], ash);
+                lsc = TVC_MFMA16(fa[0][0], cf[1], lsc);
+                lsh = TVC_MFMA16(fa[1][0], cf[1], lsh);
+            }
+            const float c1 = cwsc * sc.inv, c2 = cwsh * sc.inv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                asc[r] = comb(asc[r], lsc[r], c1, c1 * kLoInv);
+                ash[r] = comb(ash[r], lsh[r], c2, c2 * kLoInv);
+            }
+        }
+        // ---- epilogue ---------------------------------------------------------------------------------------------------
+        {
+            float mx = 0.f;
+            float* ob = a.out + (long)b * C * len;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (32 * mt + 8 * g >= C) continue;                                // uniform per wave
+                const f32x4s_t bv = *reinterpret_cast<const f32x4s_t*>(Bi + 64 + 32 * mt + 8 * g + 4 * lh);
+                f32x4s_t bs, bh;
+                if (FILM) {
+                    bs = *reinterpret_cast<const f32x4s_t*>(Bi + 128 + 32 * mt + 8 * g + 4 * lh);
+                    bh = *reinterpret_cast<const f32x4s_t*>(Bi + 192 + 32 * mt + 8 * g + 4 * lh);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = acc[4 * g + q] + bv[q];
+                    if (FILM) v = __fadd_rn(__fmul_rn(v, asc[4 * g + q] + bs[q]), ash[4 * g + q] + bh[q]);
+                    if (RES) v = __fadd_rn(v, rv[g][q]);
+                    if (live) {
+                        stg_so(ob + (long)(8 * g + q) * len, oo, v);
+                        mx = fmaxf(mx, fabsf(v));
+                    }
+                }
+            }
+            mx_run = fmaxf(mx_run, mx);
+        }
+        // ---- next tile's input: registers -> LDS, then request the one after ------------------------------------------------
+        slab_barrier();                                   // every wave is done reading Xs and Hs
+        if (next < tend) {
+            deposit(bfp_load(a.amax_x, next / a.tiles_per_utt).s);
+            if (next + 1 < tend) fetch(next + 1);
+        }
+        slab_barrier();
+    }
+    if (a.amax_y) amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 260);
+}
+
+template <bool FILM, bool LERP, int RES>
+int launch48p(tvc_ctx* ctx, hipStream_t s, Conv48PArgs a, int B) {
+    static int ncu_dev[64] = {};
+    int& ncu = ncu_dev[ctx->device & 63];
+    constexpr size_t lds = (size_t)(12 * kXPP + 12 * 128 + 72 * 64 + (FILM ? 24 * 64 : 0)) * 16 + 272 * 4;
+    static_assert(lds <= 160 * 1024, "LDS");
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv48p_kernel<FILM, LERP, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv48p setup: %s", hipGetErrorString(e));
+        ncu = prop.multiProcessorCount;
+    }
+    const int bno = 128 - 2 * a.db;
+    a.tiles_per_utt = (a.len + bno - 1) / bno;
+    a.ntiles = a.tiles_per_utt * B;
+    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    hipLaunchKernelGGL((conv48p_kernel<FILM, LERP, RES>), dim3(grid), dim3(kNT48), lds, s, a);
+    return launch_check(ctx, "conv48p");
+}
+
 }  // namespace
 
 // mode bits: 1 = the input is the low-rate tensor [B][48][lin] (F.interpolate fused into the staging), 2 = FiLM over cond,
@@ -442,6 +802,31 @@ int run_conv48s(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, i
     }
     if (res) return fail(ctx, TVC_ERR_ARG, "conv48s: plain convs carry no residual");
     return launch48<false, false, 0>(ctx, s, a, B);
+}
+
+// The fused pair (conv48p_kernel): x (or, lin > 0, the low-rate tensor it is interpolated from) -> conv_a(dil da) -> lrelu -> conv_b(dil db)
+// [-> FiLM(cond) + F.interpolate(res_low)] -> out.  film == nullptr: plain pair (Downsample), no residual.
+int run_conv48_pair(tvc_ctx* ctx, hipStream_t s, const PackedW& wa, const PackedW& wb, const float* x, int lin, float lscale, const PackedW* film,
+                    const float* bsc, const float* bsh, const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int da,
+                    int db, const float* amax_x, const float* amax_c, float* amax_y) {
+    for (const PackedW* w : {&wa, &wb})
+        if (w->cin != kC48 || w->M != kC48 || w->taps != 3 || w->MT6 != 2 || !w->A6) return fail(ctx, TVC_ERR_ARG, "conv48 pair: 48 -> 48 channel k3 convs only");
+    if (da < 1 || da > 4 || db < 1 || db > 8) return fail(ctx, TVC_ERR_ARG, "conv48 pair: dilations (1..4, 1..8)");
+    if ((long)len * kC48 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "conv48 pair: utterance too long for 32-bit byte offsets");
+    if (film && (film->MT6 != 4 || !film->A6 || !cond || !bsc || !bsh || !res || rlin <= 0))
+        return fail(ctx, TVC_ERR_ARG, "conv48 pair: the FiLM variant needs the stacked image, both biases, cond and the low-rate residual");
+    Conv48PArgs a{};
+    a.x = x; a.cond = cond; a.res = res; a.out = out;
+    a.Aa = reinterpret_cast<const u32x4*>(wa.A6);
+    a.Ab = reinterpret_cast<const u32x4*>(wb.A6);
+    a.F6 = film ? reinterpret_cast<const u32x4*>(film->A6) : nullptr;
+    a.bias_a = wa.bias; a.bias_b = wb.bias; a.bsc = bsc; a.bsh = bsh;
+    a.wsc_a = wa.wscale; a.wsc_b = wb.wscale; a.fsc = film ? film->wscale : nullptr;
+    a.amax_x = amax_x; a.amax_c = amax_c; a.amax_y = amax_y;
+    a.len = len; a.da = da; a.db = db; a.lin = lin; a.rlin = rlin; a.lscale = lscale; a.rscale = rscale;
+    if (film) return lin > 0 ? launch48p<true, true, 2>(ctx, s, a, B) : fail(ctx, TVC_ERR_ARG, "conv48 pair: the FiLM pair starts from the low-rate tensor");
+    if (lin > 0 || res) return fail(ctx, TVC_ERR_ARG, "conv48 pair: the plain pair has neither an interpolated input nor a residual");
+    return launch48p<false, false, 0>(ctx, s, a, B);
 }
 
 }  // namespace tvc

@@ -295,9 +295,8 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
             if (d.cin == 24) {   // the whole 24-channel block in three conv24s launches; c3 folds down_res(xi) in and writes y2
                 TVC_CHECK(run_down24_split(ctx, s, d, xi, h1, h2, skip[i], y2, B, len, mxi, mh1, mh2, mout));
             } else {
-                if (d.cin == 48) {   // weights resident in LDS, one staging round trip per tile (conv48s.hip)
-                    TVC_CHECK(run_conv48s(ctx, s, d.c1, xi, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h1, B, len, 1, mxi, nullptr, mh1));
-                    TVC_CHECK(run_conv48s(ctx, s, d.c2, h1, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h2, B, len, 2, mh1, nullptr, mh2));
+                if (d.cin == 48) {   // c1 -> c2 in one launch, weights resident in LDS, c1's output never leaves the CU (conv48s.hip)
+                    TVC_CHECK(run_conv48_pair(ctx, s, d.c1, d.c2, xi, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h2, B, len, 1, 2, mxi, nullptr, mh2));
                 } else {
                     TVC_CHECK(conv3s_launch<true>(ctx, s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len}, BfpSlots{mxi, nullptr, mh1}));
                     TVC_CHECK(conv3s_launch<true>(ctx, s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len}, BfpSlots{mh1, nullptr, mh2}));
@@ -352,9 +351,8 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
                 float* mh = slot((half ? S_UHB : S_UHA) + i);                    // its output h
                 float* mout = slot((half ? S_UXU : S_UX1) + i);                  // the half's output
                 if (C == 48) {   // LDS-resident weights (conv48s.hip)
-                    if (half == 0) {
-                        TVC_CHECK(run_conv48s(ctx, s, ca, x, lin, lscale, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h, B, lo, da, ma_in, nullptr, mh));
-                        TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, bsc, bsh, cond, x, lin, lscale, xout, B, lo, db, mh, mcond, mout));
+                    if (half == 0) {   // c1 (interpolating) -> c2 + FiLM1 + interpolated residual in one launch
+                        TVC_CHECK(run_conv48_pair(ctx, s, ca, cb, x, lin, lscale, &fw, bsc, bsh, cond, x, lin, lscale, xout, B, lo, da, db, ma_in, mcond, mout));
                     } else {
                         TVC_CHECK(run_conv48s(ctx, s, ca, x1, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h, B, lo, da, ma_in, nullptr, mh));
                         // c4 + FiLM2 + residual + c5 (48 -> 24) in one launch: the level's output (and its |max|) is written directly

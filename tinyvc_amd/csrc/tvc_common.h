@@ -261,6 +261,10 @@ int run_conv48s(tvc_ctx*, hipStream_t, const PackedW& w, const float* x, int lin
                 const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil, const float* amax_x, const float* amax_c,
                 float* amax_y, const PackedW* c5 = nullptr, float* out5 = nullptr);
 
+int run_conv48_pair(tvc_ctx*, hipStream_t, const PackedW& wa, const PackedW& wb, const float* x, int lin, float lscale, const PackedW* film, const float* bsc,
+                    const float* bsh, const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int da, int db,
+                    const float* amax_x, const float* amax_c, float* amax_y);
+
 // ConvNeXt-v2 layer on x [B, C, T] in place (convnext.py:49-58); tmp buffers from ws.
 int run_convnext(tvc_ctx*, hipStream_t, Ws&, bool dry, const ConvNeXtW& w, float* x, int B, int T);
 
