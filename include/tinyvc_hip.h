@@ -17,6 +17,10 @@
  *     fork/join is capturable: a HIP graph captured on `stream` includes it);
  *   - `ws` is a caller-allocated device scratch buffer of at least tvc_workspace_bytes() bytes;
  *     the library never allocates device memory after tvc_finalize_weights();
+ *   - arithmetic: fp32 in, fp32 out.  Channel contractions run on the fp16 matrix pipe with every fp32 operand split into two
+ *     fp16 parts (22 significand bits, fp32-GEMM-level error); a per-utterance power-of-two scale taken from each tensor's largest
+ *     magnitude keeps the parts inside fp16's range, so results do not depend on the loudness of the input, and one utterance's
+ *     range never affects another utterance of the batch;
  *   - return value: 0 = ok, negative = tvc_status; tvc_last_error() has the message;
  *   - one ctx per device, one host thread per ctx at a time.
  */

@@ -1,6 +1,7 @@
 // Source-filter decoder (decoder.py:24-266): SourceNet, additive harmonic oscillator, filtered-noise
 // iSTFT, and the FilterNet U-Net.
 #include "conv3s.h"
+#include "conv_s2.h"
 #include "gemm_s2.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
@@ -236,6 +237,22 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
 // kernel's epilogue publishes it; tensors finished by an epilogue functor (the c5 GEMMs, content_in) get one pass of amax_rows.
 // The architecture is fixed (the module mirror only accepts the reference's default channels / factors).
 // =================================================================================================
+// y = conv(lrelu(x)) + b for the plain k3 convs of the 96..384-channel levels (lin > 0: x is the low-rate tensor, F.interpolate is
+// evaluated while staging): the pipelined kernel of conv_s2.h, or conv3s.h's two-barrier kernel outside its preconditions
+#ifndef X_CS2
+#define X_CS2 1
+#endif
+static int plain_conv(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, float* y, const BfpSlots& bfp, int lin = 0,
+                      float lscale = 0.f) {
+    int rc = 0;
+    if (X_CS2 && (lin > 0 ? conv_s2_try<true>(&rc, ctx, s, w, x, B, Cin, len, dil, y, bfp, lin, lscale) : conv_s2_try<false>(&rc, ctx, s, w, x, B, Cin, len, dil, y, bfp)))
+        return rc;
+    if (lin > 0)
+        return conv3s_launch<true, C3EpiBias<false>, false, true>(ctx, s, w, x, B, Cin, len, dil, C3EpiBias<false>{y, w.bias, nullptr, w.M, len}, bfp, nullptr, nullptr,
+                                                                   nullptr, 0, lin, lscale);
+    return conv3s_launch<true>(ctx, s, w, x, B, Cin, len, dil, C3EpiBias<false>{y, w.bias, nullptr, w.M, len}, bfp);
+}
+
 // cmax / smax (nullable): |max| slots of `content` / of cat[source, energy] if the caller already has them
 int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
                const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps, const float* cmax, const float* smax) {
@@ -298,8 +315,8 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
                 if (d.cin == 48) {   // c1 -> c2 in one launch, weights resident in LDS, c1's output never leaves the CU (conv48s.hip)
                     TVC_CHECK(run_conv48_pair(ctx, s, d.c1, d.c2, xi, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h2, B, len, 1, 2, mxi, nullptr, mh2));
                 } else {
-                    TVC_CHECK(conv3s_launch<true>(ctx, s, d.c1, xi, B, d.cin, len, 1, C3EpiBias<false>{h1, d.c1.bias, nullptr, d.cin, len}, BfpSlots{mxi, nullptr, mh1}));
-                    TVC_CHECK(conv3s_launch<true>(ctx, s, d.c2, h1, B, d.cin, len, 2, C3EpiBias<false>{h2, d.c2.bias, nullptr, d.cin, len}, BfpSlots{mh1, nullptr, mh2}));
+                    TVC_CHECK(plain_conv(ctx, s, d.c1, xi, B, d.cin, len, 1, h1, BfpSlots{mxi, nullptr, mh1}));
+                    TVC_CHECK(plain_conv(ctx, s, d.c2, h1, B, d.cin, len, 2, h2, BfpSlots{mh1, nullptr, mh2}));
                 }
                 // c3 + down_res(xi) as a second K phase on the same accumulators: no residual tensor, no 1x1 launch
                 TVC_CHECK((conv3s_launch<true, C3EpiBiasResConv>(ctx, s, d.c3, h2, B, d.cin, len, 4,
@@ -359,13 +376,12 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
                         TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, bsc, bsh, cond, x1, 0, 0.f, nullptr, B, lo, db, mh, mcond, slot(S_LEV + i), &u.c5, xlev[i]));
                     }
                 } else if (half == 0) {
-                    TVC_CHECK((conv3s_launch<true, C3EpiBias<false>, false, true>(ctx, s, ca, x, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo},
-                                                                                  BfpSlots{ma_in, nullptr, mh}, nullptr, nullptr, nullptr, 0, lin, lscale)));
+                    TVC_CHECK(plain_conv(ctx, s, ca, x, B, C, lo, da, h, BfpSlots{ma_in, nullptr, mh}, lin, lscale));
                     TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
                                                                           C3EpiFilmFused{xout, cb.bias, bsc, bsh, x, C, lo, lin, lscale},
                                                                           BfpSlots{mh, mcond, mout}, &fw, &fw, cond, C)));
                 } else {
-                    TVC_CHECK(conv3s_launch<true>(ctx, s, ca, x1, B, C, lo, da, C3EpiBias<false>{h, ca.bias, nullptr, C, lo}, BfpSlots{ma_in, nullptr, mh}));
+                    TVC_CHECK(plain_conv(ctx, s, ca, x1, B, C, lo, da, h, BfpSlots{ma_in, nullptr, mh}));
                     TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
                                                                           C3EpiFilmFused{xout, cb.bias, bsc, bsh, x1, C, lo},
                                                                           BfpSlots{mh, mcond, mout}, &fw, &fw, cond, C)));
