@@ -196,6 +196,68 @@ struct Packer {
         host_wscale[pw] = scale;
         return off;
     }
+    // conv (k3) + FiLM (two 1x1s) of one Upsample half for film_s2.h.  Image: [96-row block][16-channel slab][30 pieces][lane][8 fp16],
+    // piece q < 18: conv tap q / 6, m-tile (q % 6) / 2 of the block, part q % 2; q >= 18: to_scale (q < 24) / to_shift, m-tile, part.
+    // Lane order as in a6 (row = lane & 31, channel = 16 slab + 8 (lane >> 5) + j).  This kernel adds all three part products into ONE
+    // accumulator, so the second part is the UNSCALED fp16 residual and every m-tile is normalised to |max| in [2^13, 2^14): the
+    // residual's absolute fp16 resolution (2^-24, subnormals kept) is then 2^-37 of the tile's largest weight.
+    void film_u(FilmU* fu, const std::string& conv_name, const std::string& film, int C) {
+        const HostTensor* w = find(conv_name + ".weight");
+        const HostTensor* b = find(conv_name + ".bias");
+        const HostTensor* wsc = find(film + ".to_scale.weight");
+        const HostTensor* bsc = find(film + ".to_scale.bias");
+        const HostTensor* wsh = find(film + ".to_shift.weight");
+        const HostTensor* bsh = find(film + ".to_shift.bias");
+        if (!w || !b || !wsc || !bsc || !wsh || !bsh) return;
+        if (C % 96 != 0 || w->data.size() != (size_t)C * C * 3 || wsc->data.size() != (size_t)C * C || wsh->data.size() != (size_t)C * C ||
+            b->data.size() != (size_t)C || bsc->data.size() != (size_t)C || bsh->data.size() != (size_t)C) {
+            if (missing.empty()) missing = conv_name + " / " + film + " (unexpected shape)";
+            return;
+        }
+        const int MT = C / 32, nslab = C / 16, mblocks = C / 96;
+        auto tile_scale = [&](const std::vector<float>& wt, int per_row, int mt) {
+            float amax = 0.f;
+            for (int r = 0; r < 32; ++r)
+                for (int k = 0; k < per_row; ++k) amax = std::max(amax, std::fabs(wt[(size_t)(mt * 32 + r) * per_row + k]));
+            return pow2_scale(amax) * (1.f / 8192.f);
+        };
+        std::vector<float> tab((size_t)6 * C);
+        std::vector<float> s_conv(MT), s_sc(MT), s_sh(MT);
+        for (int mt = 0; mt < MT; ++mt) {
+            s_conv[mt] = tile_scale(w->data, 3 * C, mt);
+            s_sc[mt] = tile_scale(wsc->data, C, mt);
+            s_sh[mt] = tile_scale(wsh->data, C, mt);
+        }
+        for (int m = 0; m < C; ++m) {
+            tab[m] = b->data[m];
+            tab[(size_t)C + m] = s_conv[m / 32];
+            tab[(size_t)2 * C + m] = bsc->data[m];
+            tab[(size_t)3 * C + m] = bsh->data[m];
+            tab[(size_t)4 * C + m] = s_sc[m / 32];
+            tab[(size_t)5 * C + m] = s_sh[m / 32];
+        }
+        std::vector<float> img((size_t)mblocks * nslab * 30 * 64 * 4, 0.f);
+        uint16_t* o = reinterpret_cast<uint16_t*>(img.data());
+        for (int mb = 0; mb < mblocks; ++mb)
+            for (int s = 0; s < nslab; ++s)
+                for (int q = 0; q < 30; ++q) {
+                    const bool conv = q < 18;
+                    const int qq = conv ? q : q - 18, grp = qq / 6, mi = (qq % 6) / 2, part = qq % 2, mt = mb * 3 + mi;
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int m = mt * 32 + (lane & 31), ci = s * 16 + 8 * (lane >> 5) + j;
+                            float x;
+                            if (conv) x = w->data[((size_t)m * C + ci) * 3 + grp] / s_conv[mt];
+                            else if (grp == 0) x = wsc->data[(size_t)m * C + ci] / s_sc[mt];
+                            else x = wsh->data[(size_t)m * C + ci] / s_sh[mt];
+                            const uint16_t h1 = f16_bits(x);
+                            o[((((size_t)mb * nslab + s) * 30 + q) * 64 + lane) * 8 + j] = part == 0 ? h1 : f16_bits(x - f16_value(h1));
+                        }
+                }
+        fu->C = C;
+        fix.push_back({&fu->img, ab.put(img)});
+        fix.push_back({&fu->tab, ab.put(tab)});
+    }
     // Weight blob of one half of the fused ups.4 kernel (filter_up24s.hip): 28 pieces of 1 KiB in
     // v_mfma_f32_32x32x16_f16 A-lane order (row m = lane & 31, k = 8 * (lane >> 5) + j), two fp16 parts each:
     //   [conv a: 5 steps][2 parts] [conv b: 5 steps][2 parts] [FiLM: 2 steps][to_scale, to_shift][2 parts]
@@ -607,6 +669,10 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
         pk.conv({p + ".c5"}, &u.c5, u.cin, 1);
         pk.conv({p + ".film1.to_scale", p + ".film1.to_shift"}, &u.film1, u.cin, 1);
         pk.conv({p + ".film2.to_scale", p + ".film2.to_shift"}, &u.film2, u.cin, 1);
+        if (u.cin >= 96) {
+            pk.film_u(&u.fu1, p + ".c2", p + ".film1", u.cin);
+            pk.film_u(&u.fu2, p + ".c4", p + ".film2", u.cin);
+        }
         if (u.cin == 24) {
             pk.up24s_half(&u.s24a, p + ".c1", p + ".c2", p + ".film1", "", "");
             pk.up24s_half(&u.s24b, p + ".c3", p + ".c4", p + ".film2", p + ".c5", "filter_net.output_layer");

@@ -2,6 +2,10 @@
 // iSTFT, and the FilterNet U-Net.
 #include "conv3s.h"
 #include "conv_s2.h"
+#include "film_s2.h"
+#ifndef X_FS2
+#define X_FS2 1
+#endif
 #include "gemm_s2.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
@@ -253,6 +257,17 @@ static int plain_conv(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float
     return conv3s_launch<true>(ctx, s, w, x, B, Cin, len, dil, C3EpiBias<false>{y, w.bias, nullptr, w.M, len}, bfp);
 }
 
+// out = FiLM(conv(lrelu(h)), cond) + residual (res_lin > 0: the residual is F.interpolate of the low-rate tensor `res`)
+static int film_conv(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const PackedW& fw, const FilmU& fu, const float* h, const float* cond, int B, int C, int len, int dil,
+                     float* out, const float* bsc, const float* bsh, const float* res, int res_lin, float res_scale, const BfpSlots& bfp) {
+    int rc = 0;
+    // The two kernels round differently (film_s2.h: one accumulator per result), so the choice may depend on nothing but the utterance's
+    // own shape: an utterance converts to the same samples in every batch.  Below one 256-column tile the narrow conv3s tile wastes less.
+    if (X_FS2 && len >= FS2::BN && film_s2_try(&rc, ctx, s, fu, h, cond, B, C, len, dil, out, res, res_lin, res_scale, bfp)) return rc;
+    return conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, w, h, B, C, len, dil, C3EpiFilmFused{out, w.bias, bsc, bsh, res, C, len, res_lin, res_scale}, bfp, &fw, &fw,
+                                                     cond, C);
+}
+
 // cmax / smax (nullable): |max| slots of `content` / of cat[source, energy] if the caller already has them
 int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
                const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps, const float* cmax, const float* smax) {
@@ -377,14 +392,10 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
                     }
                 } else if (half == 0) {
                     TVC_CHECK(plain_conv(ctx, s, ca, x, B, C, lo, da, h, BfpSlots{ma_in, nullptr, mh}, lin, lscale));
-                    TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
-                                                                          C3EpiFilmFused{xout, cb.bias, bsc, bsh, x, C, lo, lin, lscale},
-                                                                          BfpSlots{mh, mcond, mout}, &fw, &fw, cond, C)));
+                    TVC_CHECK(film_conv(ctx, s, cb, fw, u.fu1, h, cond, B, C, lo, db, xout, bsc, bsh, x, lin, lscale, BfpSlots{mh, mcond, mout}));
                 } else {
                     TVC_CHECK(plain_conv(ctx, s, ca, x1, B, C, lo, da, h, BfpSlots{ma_in, nullptr, mh}));
-                    TVC_CHECK((conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, cb, h, B, C, lo, db,
-                                                                          C3EpiFilmFused{xout, cb.bias, bsc, bsh, x1, C, lo},
-                                                                          BfpSlots{mh, mcond, mout}, &fw, &fw, cond, C)));
+                    TVC_CHECK(film_conv(ctx, s, cb, fw, u.fu2, h, cond, B, C, lo, db, xout, bsc, bsh, x1, 0, 0.f, BfpSlots{mh, mcond, mout}));
                 }
             }
             if (C != 48) {   // c5 (1x1, C -> C/2) as a split-precision GEMM launch; its output's |max| in one pass (the functor finishes the elements)

@@ -59,8 +59,17 @@ struct DownW {
     const float* s24c3r = nullptr;   // c3's blob with c3.bias + down_res.bias and the joint scales (the launch folds the residual 1x1 in)
     int cin = 0, cout = 0, factor = 1;
 };
+// conv + FiLM packed for film_s2.h (cin >= 96): one weight image whose 30 KiB units hold everything a (96-row block, 16-channel slab)
+// step multiplies - the conv's three taps and the to_scale / to_shift columns of the same 16 channels - and one table of per-row
+// constants [6][C]: conv bias, conv row scale, b_scale, b_shift, to_scale row scale, to_shift row scale.
+struct FilmU {
+    const float* img = nullptr;
+    const float* tab = nullptr;
+    int C = 0;
+};
 struct UpW {
     PackedW c1, c2, c3, c4, c5, film1, film2;  // film = [to_scale ; to_shift] stacked on M (2C); film.bias = [b_scale (C) ; b_shift (C)]
+    FilmU fu1, fu2;                            // (c2, film1) and (c4, film2) for the single-accumulator pipelined kernel
     const float* s24a = nullptr;               // cin == 24: weight blobs of the two halves of the split-precision fused block (filter_up24s.hip)
     const float* s24b = nullptr;
     int cin = 0, cout = 0, factor = 1;
