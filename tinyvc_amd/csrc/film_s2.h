@@ -14,8 +14,8 @@
 // to make that negligible every operand is normalised first: weights per 32-row m-tile to |max| in [2^13, 2^14) at pack time (api.hip
 // film_u), activations per utterance to |max| in [2^14, 2^15) by the power of two taken from the tensor's |max| slot - always, not only
 // outside fp16's range.  A residual is then resolved to 2^-38 of its tensor's largest value; products stay below 2^29 and sums over
-// K = 3 * 384 below 2^40.  Error against fp64 on N(0,1) operands, K = 1152: 2.4e-7 rel rms (accumulator pairs: 1.9e-7, fp32 MFMA: 4.9e-7;
-// tools/micro/f16split.hip).  The slots this kernel reads are exact maxima written by the producing kernels' epilogues.
+// K = 3 * 384 below 2^40.  Error against fp64 on N(0,1) operands, K = 768: 3.1e-7 rel rms at every input scale from 1e-7 to 1e5 (accumulator
+// pairs: 1.9e-7, fp32 MFMA: 4.9e-7, bf16 x 3: 4.2e-7; tools/micro/f16split.hip, profiles/r03_f16split.txt).  The slots this kernel reads are exact maxima written by the producing kernels' epilogues.
 #pragma once
 #include "conv3s.h"
 

@@ -69,9 +69,10 @@ __global__ __launch_bounds__(256) void rate_k(float* out, int iters) {
 }
 
 // one wave per 32 x 32 output tile; W [M][K], X [K][N] fp32 row-major
-// MODE 0: fp32 mfma 32x32x2; 1: bf16x3 six products; 2: fp16x2 three products, two accumulators; 3: fp16x2, ONE accumulator (h2 unscaled)
+// MODE 0: fp32 mfma 32x32x2; 1: bf16x3 six products; 2: fp16x2 three products, two accumulators; 3: fp16x2, ONE accumulator (h2 unscaled);
+// 4: as 3 with both operands normalised first (W to |max| in [2^13, 2^14), X to [2^14, 2^15): film_s2.h), ws / xn = the powers of two
 template <int MODE>
-__global__ __launch_bounds__(64) void gemm_k(const float* __restrict__ W, const float* __restrict__ X, float* __restrict__ Y, int M, int K, int N, float xs) {
+__global__ __launch_bounds__(64) void gemm_k(const float* __restrict__ W, const float* __restrict__ X, float* __restrict__ Y, int M, int K, int N, float xs, float ws = 1.f, float xn = 1.f) {
     const int lane = threadIdx.x, l31 = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     f32x16 acc, acc2;
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(64) void gemm_k(const float* __restrict__ W, const 
     for (int k0 = 0; k0 < K; k0 += 16) {
         float wv[8], xv[8];
         for (int j = 0; j < 8; ++j) {
-            wv[j] = W[(long)(m0 + l31) * K + k0 + 8 * lh + j];
-            xv[j] = X[(long)(k0 + 8 * lh + j) * N + n0 + l31] * xs;
+            wv[j] = W[(long)(m0 + l31) * K + k0 + 8 * lh + j] * (MODE == 4 ? ws : 1.f);
+            xv[j] = X[(long)(k0 + 8 * lh + j) * N + n0 + l31] * xs * (MODE == 4 ? xn : 1.f);
         }
         if (MODE == 0) {
             for (int kk = 0; kk < 16; kk += 2) {
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(64) void gemm_k(const float* __restrict__ W, const 
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + 4 * lh + (r & 3) + 8 * (r >> 2);
         float v = MODE == 2 ? fmaf(acc2[r], 1.f / 2048.f, acc[r]) : acc[r];
-        Y[(long)row * N + n0 + l31] = v / xs;
+        Y[(long)row * N + n0 + l31] = MODE == 4 ? v / ws / xn / xs : v / xs;
     }
 }
 
@@ -176,14 +177,22 @@ int main() {
     const float scales[] = {1.f, 1e-3f, 1e-5f, 1e-7f, 1e3f, 1.5e4f, 1e5f};
     for (float xs : scales) {
         printf("activation scale %-8g:", xs);
-        for (int mode = 0; mode < 4; ++mode) {
+        float wmax = 0.f, xmax = 0.f;
+        for (auto w : W) wmax = std::max(wmax, std::fabs(w));
+        for (auto x : X) xmax = std::max(xmax, std::fabs(x * xs));
+        int ew, ex;
+        frexpf(wmax, &ew);
+        frexpf(xmax, &ex);
+        const float ws = ldexpf(1.f, 14 - ew), xn = ldexpf(1.f, 15 - ex);
+        for (int mode = 0; mode < 5; ++mode) {
             dim3 g(N / 32, M / 32);
+            if (mode == 4) gemm_k<4><<<g, 64>>>(dW, dX, dY, M, K, N, xs, ws, xn);
             if (mode == 0) gemm_k<0><<<g, 64>>>(dW, dX, dY, M, K, N, xs);
             if (mode == 1) gemm_k<1><<<g, 64>>>(dW, dX, dY, M, K, N, xs);
             if (mode == 2) gemm_k<2><<<g, 64>>>(dW, dX, dY, M, K, N, xs);
             if (mode == 3) gemm_k<3><<<g, 64>>>(dW, dX, dY, M, K, N, xs);
             hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost);
-            const char* nm[4] = {"fp32", "bf16x3", "f16x2(2acc)", "f16x2(1acc)"};
+            const char* nm[5] = {"fp32", "bf16x3", "f16x2(2acc)", "f16x2(1acc)", "f16x2(1acc,norm)"};
             printf("  %s %.3e", nm[mode], relrms(Y, ref));
         }
         printf("\n");
