@@ -14,6 +14,8 @@ from tinyvc_amd.module.tinyvc import Decoder, Encoder  # noqa: E402
 import infer as infer_cli  # noqa: E402
 
 dev = "cuda:0"
+from tinyvc_amd import _lib  # noqa: E402
+print("library:", _lib.load_library()._name)
 enc, dec = Encoder(), Decoder()
 enc.load_state_dict(synth.synth_state_dict("encoder"))
 dec.load_state_dict(synth.synth_state_dict("decoder"))
