@@ -3,8 +3,10 @@ torchaudio.functional.resample, infer.py:46,63; infer_streaming.py:70).
 
 Same published algorithm and defaults as torchaudio's `sinc_interp_hann` resampler — a Hann-windowed
 sinc polyphase filter bank, lowpass_filter_width = 6, rolloff = 0.99 — written from its documentation.
-torchaudio is absent from this image, so this step has no pinned parity; the tests
-check it against scipy.signal.resample_poly on band-limited signals."""
+torchaudio is absent from this image, so this step has no pinned parity.  This host
+restatement is the checker of the device kernel (`tvc_resample_f32`, frontdoor.hip): the GPU tests require the
+two to be bit-identical on every rate pair the entry scripts meet, and the CPU tests check this file against
+scipy.signal.resample_poly on band-limited signals."""
 import math
 
 import torch
