@@ -191,18 +191,27 @@ __device__ __forceinline__ u32x4 ldg_so4(const uint4* base, unsigned byte_off) {
 }
 
 
+// The two parts of a pair of fp32 values: h1 = fp16(v) (packed), h2 = fp16((v - h1) * S), S = kLoScale (or 1: film_s2.h).
+// The second part is ONE v_fma_mix per value - fp16(fma(h1, -S, v * S)), the fp16 operand read straight from h1's register half -
+// instead of convert-back, subtract, scale, convert: four vector instructions per pair instead of six, on the path every staged
+// activation takes.  The product h1 * S and the difference are exact in fp32, so the single rounding equals the four-step result bit for
+// bit (tools/micro/split_mix.hip: 2 M pairs over the whole exponent range, none different).
+template <bool SCALED = true>
+__device__ __forceinline__ void split2(float v0, float v1, unsigned& p1, unsigned& p2) {
+    const f32x2 a = {v0, v1};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, f16x2v));
+    const f32x2 b = SCALED ? a * kLoScale : a;
+    const float ns = SCALED ? -kLoScale : -1.f;
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p1), "s"(ns), "v"(b[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(p1), "s"(ns), "v"(b[1]));
+    p2 = r;
+}
 // two fp16 parts of 8 fp32 values (v = h1 + 2^-11 h2), packed for one 16-byte LDS row each
 __device__ __forceinline__ void split8(const float (&v)[8], uint4& p1, uint4& p2) {
     unsigned o1[4], o2[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x2 a = {v[2 * j], v[2 * j + 1]};
-        f16x2v h1 = __builtin_convertvector(a, f16x2v);
-        f32x2 r = (a - __builtin_convertvector(h1, f32x2)) * kLoScale;
-        f16x2v h2 = __builtin_convertvector(r, f16x2v);
-        o1[j] = __builtin_bit_cast(unsigned, h1);
-        o2[j] = __builtin_bit_cast(unsigned, h2);
-    }
+    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], o1[j], o2[j]);
     p1 = make_uint4(o1[0], o1[1], o1[2], o1[3]);
     p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
 }

@@ -67,14 +67,7 @@ __device__ __forceinline__ Bfp norm_from_amax(float amax) {
 __device__ __forceinline__ void split8u(const float (&v)[8], uint4& p1, uint4& p2) {
     unsigned o1[4], o2[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x2 a = {v[2 * j], v[2 * j + 1]};
-        f16x2v h1 = __builtin_convertvector(a, f16x2v);
-        f32x2 r = a - __builtin_convertvector(h1, f32x2);
-        f16x2v h2 = __builtin_convertvector(r, f16x2v);
-        o1[j] = __builtin_bit_cast(unsigned, h1);
-        o2[j] = __builtin_bit_cast(unsigned, h2);
-    }
+    for (int j = 0; j < 4; ++j) split2<false>(v[2 * j], v[2 * j + 1], o1[j], o2[j]);
     p1 = make_uint4(o1[0], o1[1], o1[2], o1[3]);
     p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
 }

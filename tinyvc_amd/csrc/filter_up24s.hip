@@ -65,12 +65,10 @@ struct Up24SArgs {
 __device__ __forceinline__ void split4(const float (&v)[4], u32x2& p1, u32x2& p2) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        f32x2 a = {v[2 * j], v[2 * j + 1]};
-        f16x2v h1 = __builtin_convertvector(a, f16x2v);
-        f32x2 r = (a - __builtin_convertvector(h1, f32x2)) * kLoScale;
-        f16x2v h2 = __builtin_convertvector(r, f16x2v);
-        p1[j] = __builtin_bit_cast(unsigned, h1);
-        p2[j] = __builtin_bit_cast(unsigned, h2);
+        unsigned q1, q2;
+        split2(v[2 * j], v[2 * j + 1], q1, q2);
+        p1[j] = q1;
+        p2[j] = q2;
     }
 }
 
