@@ -3,9 +3,6 @@
 #include "conv3s.h"
 #include "conv_s2.h"
 #include "film_s2.h"
-#ifndef X_FS2
-#define X_FS2 1
-#endif
 #include "gemm_s2.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
@@ -243,13 +240,10 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
 // =================================================================================================
 // y = conv(lrelu(x)) + b for the plain k3 convs of the 96..384-channel levels (lin > 0: x is the low-rate tensor, F.interpolate is
 // evaluated while staging): the pipelined kernel of conv_s2.h, or conv3s.h's two-barrier kernel outside its preconditions
-#ifndef X_CS2
-#define X_CS2 1
-#endif
 static int plain_conv(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, float* y, const BfpSlots& bfp, int lin = 0,
                       float lscale = 0.f) {
     int rc = 0;
-    if (X_CS2 && (lin > 0 ? conv_s2_try<true>(&rc, ctx, s, w, x, B, Cin, len, dil, y, bfp, lin, lscale) : conv_s2_try<false>(&rc, ctx, s, w, x, B, Cin, len, dil, y, bfp)))
+    if ((lin > 0 ? conv_s2_try<true>(&rc, ctx, s, w, x, B, Cin, len, dil, y, bfp, lin, lscale) : conv_s2_try<false>(&rc, ctx, s, w, x, B, Cin, len, dil, y, bfp)))
         return rc;
     if (lin > 0)
         return conv3s_launch<true, C3EpiBias<false>, false, true>(ctx, s, w, x, B, Cin, len, dil, C3EpiBias<false>{y, w.bias, nullptr, w.M, len}, bfp, nullptr, nullptr,
@@ -263,7 +257,7 @@ static int film_conv(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const Packed
     int rc = 0;
     // The two kernels round differently (film_s2.h: one accumulator per result), so the choice may depend on nothing but the utterance's
     // own shape: an utterance converts to the same samples in every batch.  Below one 256-column tile the narrow conv3s tile wastes less.
-    if (X_FS2 && len >= FS2::BN && film_s2_try(&rc, ctx, s, fu, h, cond, B, C, len, dil, out, res, res_lin, res_scale, bfp)) return rc;
+    if (len >= FS2::BN && film_s2_try(&rc, ctx, s, fu, h, cond, B, C, len, dil, out, res, res_lin, res_scale, bfp)) return rc;
     return conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, w, h, B, C, len, dil, C3EpiFilmFused{out, w.bias, bsc, bsh, res, C, len, res_lin, res_scale}, bfp, &fw, &fw,
                                                      cond, C);
 }

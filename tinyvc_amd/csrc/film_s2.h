@@ -38,12 +38,12 @@ struct FilmS2Args {
     float* amax_y;
 };
 
-#ifndef FS2_MW
-#define FS2_MW 1
-#endif
-// workgroup tile 96 x 256; MW x NWV waves, each WM x WN blocks of 32 x 32
+// Workgroup tile 96 x 256: 8 waves side by side, each all 96 rows (WM = 3 m-tiles) of 32 columns - 144 accumulator registers of the 256 a
+// wave has at two waves per SIMD.  The 12-wave layout of conv_s2.h (3 x 4 waves of 32 x 64: MW = 3, WN = 2) needs 96 accumulators + 28
+// staging registers + fragments > the 168 registers of three waves per SIMD: it compiles (the code below is written for both) but spills
+// its staging registers inside the step loop.
 struct FS2 {
-    static constexpr int MTB = 3, MW = FS2_MW, WM = MTB / MW, NWV = MW == 1 ? 8 : 4, WN = 8 / NWV, NW = MW * NWV, NTHR = NW * 64, BN = 256, MAXD = 27, XROW = BN + 2 * MAXD;
+    static constexpr int MTB = 3, MW = 1, WM = MTB / MW, NWV = MW == 1 ? 8 : 4, WN = 8 / NWV, NW = MW * NWV, NTHR = NW * 64, BN = 256, MAXD = 27, XROW = BN + 2 * MAXD;
     static constexpr int A_CONV = 3 * MTB * 2, A_PIECES = A_CONV + 2 * MTB * 2, A_PER = (A_PIECES + NW - 1) / NW;
     static constexpr int XS = (2 * XROW + NTHR - 1) / NTHR;       // conv staging items per thread
     static constexpr int A_U4 = A_PIECES * 64, X_U4 = 2 * 2 * XROW, C_U4 = 2 * 2 * BN, BUF_U4 = A_U4 + X_U4 + C_U4;
