@@ -25,31 +25,33 @@ __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
     return v;
 }
 
-// grid (T, B): csum[b][m][t] = sum over the frame's 480 samples of inc_m
+// One wavefront per frame (grid (ceil(T / 4), B), four frames per workgroup): lane l < 60 owns the frame's samples 8 l ... 8 l + 7.
+// csum[b][m][t] = sum over the frame's 480 samples of inc_m: a lane adds its eight increments, the wave reduces - no LDS, no barrier.
 static __global__ __launch_bounds__(256) void harm_frame_sum_kernel(const float* __restrict__ f0, double* __restrict__ csum,
                                                                     int T, float scale) {
-    __shared__ double red[4][kHarm];
-    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int t = 4 * blockIdx.x + (threadIdx.x >> 6);
+    if (t >= T) return;
     const float* f = f0 + (long)b * T;
     double acc[kHarm];
 #pragma unroll
     for (int m = 0; m < kHarm; ++m) acc[m] = 0.0;
-    for (int i = tid; i < kHop; i += 256) {
-        Lerp c = lerp_coord(t * kHop + i, scale, T);
-        float fs = lerp_eval(c, f[c.i0], f[c.i1]);
+    if (lane < kHop / 8) {
 #pragma unroll
-        for (int m = 0; m < kHarm; ++m) acc[m] += (double)__fdiv_rn(__fmul_rn(fs, (float)(m + 1)), 24000.f);
+        for (int k = 0; k < 8; ++k) {
+            Lerp c = lerp_coord(t * kHop + 8 * lane + k, scale, T);
+            float fs = lerp_eval(c, f[c.i0], f[c.i1]);
+#pragma unroll
+            for (int m = 0; m < kHarm; ++m) acc[m] += (double)__fdiv_rn(__fmul_rn(fs, (float)(m + 1)), 24000.f);
+        }
     }
 #pragma unroll
     for (int m = 0; m < kHarm; ++m) {
         double v = acc[m];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) red[wave][m] = v;
+        if (lane == m) csum[((long)b * kHarm + m) * T + t] = v;
     }
-    __syncthreads();
-    if (tid < kHarm) csum[((long)b * kHarm + tid) * T + t] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
 // grid (15, B), one wavefront: exclusive prefix over frames, in place
@@ -66,54 +68,54 @@ static __global__ __launch_bounds__(64) void harm_frame_scan_kernel(double* __re
     }
 }
 
-// grid (T, B): thread i < 240 owns samples 2i, 2i+1 of the frame
+// One wavefront per frame (grid (ceil(T / 4), B)): lane l < 60 owns samples 8 l ... 8 l + 7.  Per harmonic: the lane's eight increments,
+// one wave scan of their sums, the running prefix inside the lane - no LDS, no barrier (the 256-thread-per-frame version paid two
+// barriers and a four-wave carry per harmonic).
 static __global__ __launch_bounds__(256) void harm_synth_kernel(const float* __restrict__ f0, const float* __restrict__ amps,
                                                                 const double* __restrict__ coff, float* __restrict__ source,
                                                                 int T, float scale_size, float scale_amp) {
-    __shared__ double wtot[4];
-    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const bool act = tid < kHop / 2;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int t = 4 * blockIdx.x + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const bool act = lane < kHop / 8;
     const long L = (long)T * kHop;
     const float* f = f0 + (long)b * T;
-    const int p0 = t * kHop + 2 * tid;
-    float fs[2], uv[2];
-    Lerp ca[2];
+    const int p0 = t * kHop + 8 * (act ? lane : 0);
+    float fs[8], uv[8];
+    Lerp ca[8];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        int p = act ? p0 + e : t * kHop;
-        Lerp c = lerp_coord(p, scale_size, T);
-        float a0 = f[c.i0], a1 = f[c.i1];
+    for (int e = 0; e < 8; ++e) {
+        const Lerp c = lerp_coord(p0 + e, scale_size, T);
+        const float a0 = f[c.i0], a1 = f[c.i1];
         fs[e] = lerp_eval(c, a0, a1);
         uv[e] = lerp_eval(c, a0 > 20.f ? 1.f : 0.f, a1 > 20.f ? 1.f : 0.f);
-        ca[e] = lerp_coord(p, scale_amp, T);
+        ca[e] = lerp_coord(p0 + e, scale_amp, T);
     }
     for (int m = 0; m < kHarm; ++m) {
-        double d0 = act ? (double)__fdiv_rn(__fmul_rn(fs[0], (float)(m + 1)), 24000.f) : 0.0;
-        double d1 = act ? (double)__fdiv_rn(__fmul_rn(fs[1], (float)(m + 1)), 24000.f) : 0.0;
-        double pair = d0 + d1;
-        double inc = wave_incl_scan(pair, lane);
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        double base = coff[((long)b * kHarm + m) * T + t];
-        for (int w = 0; w < wave; ++w) base += wtot[w];
-        __syncthreads();
-        if (act) {
-            double e0 = base + (inc - pair) + d0;
-            double e1 = e0 + d1;
-            const float* am = amps + ((long)b * kHarm + m) * T;
-            float o[2];
-            double cyc[2] = {e0, e1};
+        double d[8], sum = 0.0;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float I = (float)cyc[e];                     // prefix rounded to fp32 (torch.cumsum output)
-                float frac = I - floorf(I);                  // I % 1
-                float theta = __fmul_rn(6.2831854820251465f, frac);
-                float hsin = __fmul_rn(sinf(theta), uv[e]);
-                float amp = lerp_eval(ca[e], am[ca[e].i0], am[ca[e].i1]);
+        for (int e = 0; e < 8; ++e) {
+            d[e] = act ? (double)__fdiv_rn(__fmul_rn(fs[e], (float)(m + 1)), 24000.f) : 0.0;
+            sum += d[e];
+        }
+        const double inc = wave_incl_scan(sum, lane);
+        double run = coff[((long)b * kHarm + m) * T + t] + (inc - sum);       // phase in front of this lane's first sample
+        if (act) {
+            const float* am = amps + ((long)b * kHarm + m) * T;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                run += d[e];
+                const float I = (float)run;                  // prefix rounded to fp32 (torch.cumsum output)
+                const float frac = I - floorf(I);            // I % 1
+                const float theta = __fmul_rn(6.2831854820251465f, frac);
+                const float hsin = __fmul_rn(sinf(theta), uv[e]);
+                const float amp = lerp_eval(ca[e], am[ca[e].i0], am[ca[e].i1]);
                 o[e] = __fmul_rn(hsin, amp);
             }
-            *reinterpret_cast<float2*>(source + ((long)b * 16 + m) * L + p0) = make_float2(o[0], o[1]);
+            float4* dst = reinterpret_cast<float4*>(source + ((long)b * 16 + m) * L + p0);
+            dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_float4(o[4], o[5], o[6], o[7]);
         }
     }
 }
@@ -206,9 +208,9 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
     // harmonics -> source[:, 0:15]
     const float scale_size = (float)T / (float)L;         // F.interpolate(f0, Lw): size given
     const float scale_amp = (float)(1.0 / (double)kHop);  // F.interpolate(amps, scale_factor=480)
-    hipLaunchKernelGGL(harm_frame_sum_kernel, dim3(T, B), dim3(256), 0, s, f0, csum, T, scale_size);
+    hipLaunchKernelGGL(harm_frame_sum_kernel, dim3((T + 3) / 4, B), dim3(256), 0, s, f0, csum, T, scale_size);
     hipLaunchKernelGGL(harm_frame_scan_kernel, dim3(kHarm, B), dim3(64), 0, s, csum, T);
-    hipLaunchKernelGGL(harm_synth_kernel, dim3(T, B), dim3(256), 0, s, f0, amps, csum, source, T, scale_size, scale_amp);
+    hipLaunchKernelGGL(harm_synth_kernel, dim3((T + 3) / 4, B), dim3(256), 0, s, f0, amps, csum, source, T, scale_size, scale_amp);
     // the 15 harmonic rows are sin(.) * voiced gate * interpolated amps: bounded by the amplitudes' own |max| (3 000 values per utterance)
     TVC_CHECK(run_amax_rows(ctx, s, amps, B, (long)kHarm * T, smax));
     // noise -> source[:, 15]: kernel * exp(i angle) -> inverse 1920-point FFT per frame (fft.hip) -> overlap-add
