@@ -16,6 +16,17 @@ namespace tvc {
 // of those per (utterance, harmonic), then an in-frame scan fused with sin / voiced gate / amplitude.
 // =================================================================================================
 
+// fl32(x / 24000), the oscillator's per-sample phase increment: IEEE division costs a dozen vector instructions (v_div_scale x 2, v_rcp,
+// four fmas, v_div_fmas, v_div_fixup) and there are 2 x 15 of them per output sample.  Multiply by the rounded reciprocal, take the exact
+// remainder with one fma, correct with another: by Markstein's theorem the result is the correctly rounded quotient whenever the
+// divisor's significand is not all ones; tools/micro/div24k.hip compares it with __fdiv_rn on every positive float from 2^-100 to 2^24
+// (1 048 576 000 values): identical.
+__device__ __forceinline__ float div24k(float x) {
+    const float r = 1.0f / 24000.0f;
+    const float q0 = __fmul_rn(x, r);
+    return fmaf(fmaf(-q0, 24000.0f, x), r, q0);
+}
+
 __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -42,7 +53,7 @@ static __global__ __launch_bounds__(256) void harm_frame_sum_kernel(const float*
             Lerp c = lerp_coord(t * kHop + 8 * lane + k, scale, T);
             float fs = lerp_eval(c, f[c.i0], f[c.i1]);
 #pragma unroll
-            for (int m = 0; m < kHarm; ++m) acc[m] += (double)__fdiv_rn(__fmul_rn(fs, (float)(m + 1)), 24000.f);
+            for (int m = 0; m < kHarm; ++m) acc[m] += (double)div24k(__fmul_rn(fs, (float)(m + 1)));
         }
     }
 #pragma unroll
@@ -95,7 +106,7 @@ static __global__ __launch_bounds__(256) void harm_synth_kernel(const float* __r
         double d[8], sum = 0.0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            d[e] = act ? (double)__fdiv_rn(__fmul_rn(fs[e], (float)(m + 1)), 24000.f) : 0.0;
+            d[e] = act ? (double)div24k(__fmul_rn(fs[e], (float)(m + 1))) : 0.0;
             sum += d[e];
         }
         const double inc = wave_incl_scan(sum, lane);
