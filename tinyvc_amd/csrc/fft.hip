@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kFW * 64) void stft_fft_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) float2 smem_f[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2* Zb = smem_f + wave * kM;                                   // this wave's 960 bins
-    float* Os = reinterpret_cast<float*>(smem_f + kFW * kM);           // [961][kFW] magnitudes
+    float* Os = reinterpret_cast<float*>(smem_f);                      // [961][kFW] magnitudes, over the bins once every wave has read its own (61 KB: two workgroups per CU)
     const int groups = (T + kFW - 1) / kFW;
     const int b = blockIdx.x / groups, t0 = (blockIdx.x - b * groups) * kFW;
     const int t = t0 + wave;
@@ -128,16 +128,31 @@ __global__ __launch_bounds__(kFW * 64) void stft_fft_kernel(const float* __restr
         for (int k2 = 0; k2 < 15; ++k2) Zb[15 * k1 + k2] = v[slot15(k2)];
     }
     __syncthreads();
+    constexpr int NK = (kM + 64) / 64;                                 // bins per lane: k = lane + 64 i <= 960
+    float mag[NK];
     if (t < T) {
         // X[k] = (Z[k] + conj Z[M-k]) / 2 - i W_1920^k (Z[k] - conj Z[M-k]) / 2
-        for (int k = lane; k <= kM; k += 64) {
-            const float2 a = Zb[k == kM ? 0 : k], c = Zb[k == 0 ? 0 : kM - k];
-            const float2 e = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
-            const float2 o = make_float2(0.5f * (a.x - c.x), 0.5f * (a.y + c.y));
-            const float2 w = tw1920[k];                                // (cos, sin): W = cos - i sin
-            const float re = e.x + fmaf(w.x, o.y, -w.y * o.x);         // -i W o = (c o.y - s o.x, -(c o.x + s o.y))
-            const float im = e.y - fmaf(w.x, o.x, w.y * o.y);
-            Os[k * kFW + wave] = sqrtf(fmaf(re, re, im * im));
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int k = lane + 64 * i;
+            mag[i] = 0.f;
+            if (k <= kM) {
+                const float2 a = Zb[k == kM ? 0 : k], c = Zb[k == 0 ? 0 : kM - k];
+                const float2 e = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
+                const float2 o = make_float2(0.5f * (a.x - c.x), 0.5f * (a.y + c.y));
+                const float2 w = tw1920[k];                                // (cos, sin): W = cos - i sin
+                const float re = e.x + fmaf(w.x, o.y, -w.y * o.x);         // -i W o = (c o.y - s o.x, -(c o.x + s o.y))
+                const float im = e.y - fmaf(w.x, o.x, w.y * o.y);
+                mag[i] = sqrtf(fmaf(re, re, im * im));
+            }
+        }
+    }
+    __syncthreads();                                                   // every wave has read its bins: the tile may be overwritten
+    if (t < T) {
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int k = lane + 64 * i;
+            if (k <= kM) Os[k * kFW + wave] = mag[i];
         }
     }
     __syncthreads();
@@ -223,7 +238,8 @@ int run_stft_fft(tvc_ctx* ctx, hipStream_t s, const float* wav, float* spec, int
     const int T = (int)(L / kHop);
     static bool ready_dev[64] = {};
     bool& ready = ready_dev[ctx->device & 63];
-    constexpr int lds = kFW * kM * 8 + kBins * kFW * 4;
+    constexpr int lds = kFW * kM * 8;
+    static_assert(kBins * kFW * 4 <= lds, "the magnitude tile overlays the bins");
     if (!ready) {
         hipError_t e = hipFuncSetAttribute((const void*)stft_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "stft_fft setup: %s", hipGetErrorString(e));
