@@ -28,11 +28,12 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 constexpr int U24S_WPE = 2;     // 8 waves per CU: 256 registers each
 
-template <int W_, int D1_, int D2_, bool SECOND_, int E_>
+template <int W_, int D1_, int D2_, bool SECOND_, int E_, int NWAVES_ = 8>
 struct U24S {
     static constexpr int C = 24, W = W_, D1 = D1_, D2 = D2_, E = E_, H = D1_ + D2_;
     static constexpr bool SECOND = SECOND_;
-    static constexpr int NWAVES = 8, NT = 512;
+    static constexpr int NWAVES = NWAVES_, NT = 64 * NWAVES_;
+    static constexpr int WGS_PER_CU = 8 / NWAVES_;             // two waves per SIMD (256 registers each)
     static constexpr int W2 = W + 2 * E;                       // columns the second conv must produce (position t0 - E + n)
     static constexpr int NT2 = (W2 + 31) / 32, W2r = NT2 * 32;
     static constexpr int NT1 = (W2 + 2 * D2 + 31) / 32;        // first-conv column tiles (position t0 - E - D2 + h)
@@ -422,7 +423,9 @@ static int launch_up24s(tvc_ctx* ctx, hipStream_t s, Up24SArgs a, int B) {
     }
     a.tiles_per_utt = (a.len + CF::W - 1) / CF::W;
     a.ntiles = a.tiles_per_utt * B;
-    int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    static_assert(CF::WGS_PER_CU * CF::LDS_BYTES <= 160 * 1024, "LDS for the workgroups that share a CU");
+    const int slots = ncu * CF::WGS_PER_CU;
+    int grid = a.ntiles < slots ? a.ntiles : slots;
     hipLaunchKernelGGL((up24s_kernel<CF>), dim3(grid), dim3(CF::NT), lds, s, a);
     return launch_check(ctx, "up24s");
 }
@@ -436,7 +439,7 @@ int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, co
                    const float* amax_x, const float* amax_c, float* amax_x1) {
     if (!u.s24a || !u.s24b) return fail(ctx, TVC_ERR_STATE, "up24s: the split weight blobs of the 24-channel block are missing");
     if ((long)len * 24 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "up24s: utterance too long for 32-bit element offsets");
-    using CA = U24S<U24S_WA, 1, 3, false, 0>;
+    using CA = U24S<U24S_WA, 1, 3, false, 0>;       // (U24S<122, 1, 3, false, 0, 4>: two independent 4-wave workgroups of 122-sample tiles per CU, was measured at 602 vs 590 us)
     using CB = U24S<U24S_WB, 9, 27, true, 3>;
     Up24SArgs a{};
     a.len = len;
