@@ -149,6 +149,11 @@ int tvc_knn_finish_f32(tvc_ctx* ctx, void* stream, const float* slots, float* ou
 int tvc_shift_frequency_f32(tvc_ctx* ctx, void* stream, const float* f0, float* out, int64_t n,
                             float semitones);
 
+/* The affine map of the noise phases (reference module/tinyvc/decoder.py:78: `torch.rand(N, fft_bin, Lf) * 2 * math.pi - math.pi`,
+ * three tensor ops): u [n] uniform draws in [0, 1) -> u * 2 * pi - pi with the same three fp32 roundings, in place, one launch.
+ * The draw itself stays the caller's (torch's generator on the device, as in the reference). */
+int tvc_noise_angle_from_uniform_f32(tvc_ctx* ctx, void* stream, float* u, int64_t n);
+
 /* decoder --------------------------------------------------------------------------------- */
 /* Decoder.infer (reference module/tinyvc/decoder.py:253-257): content [B,768,T], f0 [B,1,T],
  * energy [B,1,L], noise_angle [B,961,T] = the uniform phases of decoder.py:78 in [-pi,pi)

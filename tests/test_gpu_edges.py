@@ -219,3 +219,24 @@ def test_cfg5_five_minutes_against_a_million_vector_fp16_index(gen):
     # the staged kNN equals what convert used: same rows for the slice
     m16, _ = match_features(ssl[:, :, 7000:7200].contiguous(), d16, return_indices=True)
     assert torch.isfinite(m16).all()
+
+
+def test_noise_angle_map_equals_the_reference_expression():
+    """decoder.py:78 draws `torch.rand(...) * 2 * math.pi - math.pi` (three tensor ops); the module path applies them as ONE launch
+    (tvc_noise_angle_from_uniform_f32): bit-identical, odd sizes and the ends of the interval included, and the draw is torch's own."""
+    import math
+    from tinyvc_amd.engine import default_engine
+    from tinyvc_amd.module.tinyvc import Decoder
+    eng = default_engine(torch.device(DEV))
+    for n in (1, 3, 4, 5, 1023, 961 * 200 + 7):
+        u = torch.rand(n + 1, device=DEV)[1:].contiguous()          # (a 4-byte-aligned start: the vector path must not assume 16)
+        u[0] = 0.0
+        u[-1] = 1.0 - 2.0 ** -24
+        want = u * 2 * math.pi - math.pi
+        got = eng.noise_angle_from_uniform(u.clone())
+        assert torch.equal(got, want), n
+    torch.manual_seed(1234)
+    a = Decoder.draw_noise_angle(3, 17, torch.device(DEV))
+    torch.manual_seed(1234)
+    b = torch.rand(3, 961, 17, device=DEV) * 2 * math.pi - math.pi
+    assert torch.equal(a, b)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "tvc_knn_gather_slots_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64]),
     "tvc_knn_finish_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "tvc_shift_frequency_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float]),
+    "tvc_noise_angle_from_uniform_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "tvc_decoder_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_decoder_stages_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_filter_net_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_void_p, c_size_t]),

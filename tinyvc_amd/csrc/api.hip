@@ -904,6 +904,13 @@ int tvc_shift_frequency_f32(tvc_ctx* ctx, void* stream, const float* f0, float* 
     return run_shift(ctx, (hipStream_t)stream, f0, out, n, semitones);
 }
 
+int tvc_noise_angle_from_uniform_f32(tvc_ctx* ctx, void* stream, float* u, int64_t n) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!u || n <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_noise_angle_from_uniform_f32: bad argument");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_uniform_to_angle(ctx, (hipStream_t)stream, u, n);
+}
+
 int tvc_decoder_stages_f32(tvc_ctx* ctx, void* stream, const float* content, const float* f0, const float* energy,
                            const float* noise_angle, uint64_t seed, float* wave, float* amps, float* kernel,
                            float* source, int B, int T, void* wsp, size_t ws_bytes) {

@@ -67,6 +67,28 @@ static __global__ void shift_kernel(const float* __restrict__ f0, float* __restr
     }
 }
 
+// u in [0, 1) -> u * 2 * pi - pi with the reference expression's three fp32 roundings (decoder.py:78: `torch.rand(...) * 2 * math.pi - math.pi`
+// is three tensor ops; u * 2 is exact), in place, four values per thread
+static __global__ __launch_bounds__(256) void uniform_to_angle_kernel(float* __restrict__ u, int64_t n) {
+    const int64_t i = 4 * (blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
+    const float pi = 3.1415927410125732f;          // float(math.pi)
+    if (i + 3 < n && (reinterpret_cast<uintptr_t>(u) & 15) == 0) {
+        float4 v = *reinterpret_cast<float4*>(u + i);
+        v.x = __fsub_rn(__fmul_rn(__fmul_rn(v.x, 2.f), pi), pi);
+        v.y = __fsub_rn(__fmul_rn(__fmul_rn(v.y, 2.f), pi), pi);
+        v.z = __fsub_rn(__fmul_rn(__fmul_rn(v.z, 2.f), pi), pi);
+        v.w = __fsub_rn(__fmul_rn(__fmul_rn(v.w, 2.f), pi), pi);
+        *reinterpret_cast<float4*>(u + i) = v;
+    } else {
+        for (int64_t k = i; k < n && k < i + 4; ++k) u[k] = __fsub_rn(__fmul_rn(__fmul_rn(u[k], 2.f), pi), pi);
+    }
+}
+int run_uniform_to_angle(tvc_ctx* ctx, hipStream_t s, float* u, int64_t n) {
+    const int64_t groups = (n + 3) / 4;
+    hipLaunchKernelGGL(uniform_to_angle_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, u, n);
+    return launch_check(ctx, "uniform_to_angle");
+}
+
 int run_shift(tvc_ctx* ctx, hipStream_t s, const float* f0, float* out, int64_t n, float semitones) {
     hipLaunchKernelGGL(shift_kernel, dim3(grid_for(n)), dim3(256), 0, s, f0, out, (long)n, semitones);
     return launch_check(ctx, "shift_frequency");

@@ -235,6 +235,7 @@ int run_knn_topk(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* src, const f
 int run_knn_slots(tvc_ctx*, hipStream_t, const float* prepared, int64_t N, const int64_t* idx, float* slots, int64_t nslots);
 int run_knn_finish(tvc_ctx*, hipStream_t, const float* slots, float* out, int B, int T);
 int run_shift(tvc_ctx*, hipStream_t, const float* f0, float* out, int64_t n, float semitones);
+int run_uniform_to_angle(tvc_ctx*, hipStream_t, float* u, int64_t n);
 int run_decoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* content, const float* f0,
                 const float* energy, const float* angle, uint64_t seed, float* wave, float* amps_out,
                 float* kernel_out, float* source_out, int B, int T);

@@ -271,6 +271,16 @@ class Engine:
             self._ok(self.lib.tvc_shift_frequency_f32(self.ctx, self._stream(), _ptr(f0), _ptr(out), f0.numel(), float(semitones)), "tvc_shift_frequency_f32")
         return out
 
+    def noise_angle_from_uniform(self, u):
+        """u (fp32, contiguous, on the device) uniform in [0, 1) -> u * 2 * pi - pi in place: the reference's three tensor ops
+        (decoder.py:78) as one launch with the same roundings."""
+        _check_dev(u, "u", self.device)
+        if u.dtype != _F32 or not u.is_contiguous():
+            raise ValueError("u must be contiguous fp32")
+        if u.numel():
+            self._ok(self.lib.tvc_noise_angle_from_uniform_f32(self.ctx, self._stream(), _ptr(u), u.numel()), "tvc_noise_angle_from_uniform_f32")
+        return u
+
     def _angle(self, noise_angle, B, T):
         if noise_angle is None:
             return None, self.next_seed()

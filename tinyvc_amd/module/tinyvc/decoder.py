@@ -102,7 +102,11 @@ class Decoder(HipModule):
     def draw_noise_angle(batch, frames, device):
         """The uniform phases the reference draws inside oscillate_noise on every call
         (decoder.py:78), from torch's generator for `device` (honours torch.manual_seed)."""
-        return torch.rand(batch, S.FFT_BIN, frames, device=device) * 2 * math.pi - math.pi
+        u = torch.rand(batch, S.FFT_BIN, frames, device=device)
+        if u.is_cuda:       # the three tensor ops of the reference's expression as one in-place launch with the same roundings
+            from ...engine import default_engine
+            return default_engine(u.device).noise_angle_from_uniform(u)
+        return u * 2 * math.pi - math.pi
 
     @torch.no_grad()
     def infer(self, content, f0, energy, noise_angle=None):
