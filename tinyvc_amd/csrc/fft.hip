@@ -185,14 +185,26 @@ __global__ __launch_bounds__(kFW * 64) void noise_ifft_kernel(const float* __res
     {   // Y[f][k] = kernel * (cos, sin)(angle): the [961][T] tensors are read in runs of kFW frames
         const float* kb = kern + (long)b * kBins * T + t0;
         const float* ab = angle + (long)b * kBins * T + t0;
-        for (int i = tid; i < kBins * kFW; i += kFW * 64) {
+        // a thread's 16 elements are requested together (clamped addresses, no branch in front of the loads), then converted
+        constexpr int PER = (kBins * kFW + kFW * 64 - 1) / (kFW * 64);
+        float av[PER], kv[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            int i = tid + j * kFW * 64;
+            i = i < kBins * kFW ? i : kBins * kFW - 1;
+            const int k = i / kFW;
+            int f = i - k * kFW;
+            f = f < nf ? f : nf - 1;
+            av[j] = ab[(long)k * T + f];
+            kv[j] = kb[(long)k * T + f];
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + j * kFW * 64;
             const int k = i / kFW, f = i - k * kFW;
-            if (f < nf) {
-                const float a = ab[(long)k * T + f], kv = kb[(long)k * T + f];
-                float sn, cs;
-                sincosf(a, &sn, &cs);
-                smem_f[f * YS + k] = make_float2(__fmul_rn(cs, kv), __fmul_rn(sn, kv));
-            }
+            float sn, cs;
+            sincosf(av[j], &sn, &cs);
+            if (i < kBins * kFW && f < nf) smem_f[f * YS + k] = make_float2(__fmul_rn(cs, kv[j]), __fmul_rn(sn, kv[j]));
         }
     }
     __syncthreads();
