@@ -27,24 +27,6 @@ __device__ __forceinline__ float div24k(float x) {
     return fmaf(fmaf(-q0, 24000.0f, x), r, q0);
 }
 
-// sin(x) for x in [0, 2 pi] (the oscillator's phase is reduced to one turn before the sine): two-term Cody-Waite reduction by pi / 2 with
-// fma and the degree-7 / degree-8 kernels of Cephes' sinf / cosf.  libm's sinf carries its large-argument path and twice the selects;
-// on all 189 M floats of [2^-20, 2 pi] both are within 1 ulp of the correctly rounded sine (tools/micro/sin2pi.hip: 3.1 % / 3.8 % of the
-// inputs not correctly rounded, largest absolute error 2^-24 for both).
-__device__ __forceinline__ float sin_0_2pi(float x) {
-    const float qf = rintf(x * 0.63661977236758134f);
-    float r = fmaf(-qf, 1.57079637050628662109375f, x);
-    r = fmaf(-qf, -4.37113900018624283e-8f, r);
-    const int q = (int)qf;
-    const float z = r * r;
-    float s = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
-    s = fmaf(s * z, r, r);
-    float c = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
-    c = fmaf(c * z, z, fmaf(-0.5f, z, 1.0f));
-    const float v = (q & 1) ? c : s;
-    return (q & 2) ? -v : v;
-}
-
 __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -138,7 +120,7 @@ static __global__ __launch_bounds__(256) void harm_synth_kernel(const float* __r
                 const float I = (float)run;                  // prefix rounded to fp32 (torch.cumsum output)
                 const float frac = I - floorf(I);            // I % 1
                 const float theta = __fmul_rn(6.2831854820251465f, frac);
-                const float hsin = __fmul_rn(sin_0_2pi(theta), uv[e]);
+                const float hsin = __fmul_rn(sincos_small(theta).x, uv[e]);
                 const float amp = lerp_eval(ca[e], am[ca[e].i0], am[ca[e].i1]);
                 o[e] = __fmul_rn(hsin, amp);
             }

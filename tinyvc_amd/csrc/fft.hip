@@ -202,9 +202,9 @@ __global__ __launch_bounds__(kFW * 64) void noise_ifft_kernel(const float* __res
         for (int j = 0; j < PER; ++j) {
             const int i = tid + j * kFW * 64;
             const int k = i / kFW, f = i - k * kFW;
-            float sn, cs;
-            sincosf(av[j], &sn, &cs);
-            if (i < kBins * kFW && f < nf) smem_f[f * YS + k] = make_float2(__fmul_rn(cs, kv[j]), __fmul_rn(sn, kv[j]));
+            float2 sc = sincos_small(av[j]);             // (sin, cos); the phases are drawn in [-pi, pi)
+            if (!(fabsf(av[j]) <= 6.2831855f)) sincosf(av[j], &sc.x, &sc.y);      // a caller's own phases may be anything (NaN included): libm's full range
+            if (i < kBins * kFW && f < nf) smem_f[f * YS + k] = make_float2(__fmul_rn(sc.y, kv[j]), __fmul_rn(sc.x, kv[j]));
         }
     }
     __syncthreads();

@@ -29,6 +29,25 @@ __device__ __forceinline__ float lerp_eval(const Lerp& c, float x0, float x1) {
     return fmaf(c.w0, x0, __fmul_rn(c.w1, x1));
 }
 
+// (sin, cos)(a) for |a| <= 2 pi - the oscillator's phase is reduced to one turn before the sine, the noise phases are drawn in
+// [-pi, pi) -: two-term Cody-Waite reduction by pi / 2 with fma and the degree-7 / degree-8 kernels of Cephes' sinf / cosf (the cosine
+// finished with one rounding).  libm's sinf / sincosf carry their large-argument path and twice the selects.  Checked against the
+// correctly rounded values on every float of [2^-20, 2 pi] (sine) and of +-[2^-20, pi] (both): within 1 ulp like libm's, 2.2 % of the
+// sines not correctly rounded against libm's 3.1 %, largest absolute error 2^-24 for both (tools/micro/sin2pi.hip, profiles/r03_sin2pi.txt).
+__device__ __forceinline__ float2 sincos_small(float a) {
+    const float qf = rintf(a * 0.63661977236758134f);
+    float r = fmaf(-qf, 1.57079637050628662109375f, a);
+    r = fmaf(-qf, -4.37113900018624283e-8f, r);
+    const int q = (int)qf;
+    const float z = r * r;
+    float s = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    s = fmaf(s * z, r, r);
+    float c = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    c = fmaf(z, fmaf(z, c, -0.5f), 1.0f);
+    const float vs = (q & 1) ? c : s, vc = (q & 1) ? s : c;
+    return make_float2((q & 2) ? -vs : vs, ((q + 1) & 2) ? -vc : vc);
+}
+
 // y[row][d] = lerp(x[row][:]) — F.interpolate(mode='linear') on `rows` independent rows.
 // A thread owns 4 consecutive outputs: their source coordinates depend on d only, so they are computed once and
 // reused for every row the thread walks (blockIdx.y strides the rows); outputs leave as one 16-byte store.
