@@ -201,7 +201,7 @@ struct Packer {
     // Lane order as in a6 (row = lane & 31, channel = 16 slab + 8 (lane >> 5) + j).  This kernel adds all three part products into ONE
     // accumulator, so the second part is the UNSCALED fp16 residual and every m-tile is normalised to |max| in [2^13, 2^14): the
     // residual's absolute fp16 resolution (2^-24, subnormals kept) is then 2^-37 of the tile's largest weight.
-    void film_u(FilmU* fu, const std::string& conv_name, const std::string& film, int C) {
+    void film_u(FilmU* fu, const std::string& conv_name, const std::string& film, int C, const std::string& first_conv) {
         const HostTensor* w = find(conv_name + ".weight");
         const HostTensor* b = find(conv_name + ".bias");
         const HostTensor* wsc = find(film + ".to_scale.weight");
@@ -254,6 +254,22 @@ struct Packer {
                             o[((((size_t)mb * nslab + s) * 30 + q) * 64 + lane) * 8 + j] = part == 0 ? h1 : f16_bits(x - f16_value(h1));
                         }
                 }
+        // the bound the half's first conv normalises its pre-split output by (conv_s2.h PRE): max_m sum_{k, tap} |w[m][k][tap]| and max |b|, a
+        // hair above in float so that rounding cannot undercut them
+        if (const HostTensor* w1 = find(first_conv + ".weight")) {
+            const HostTensor* b1 = find(first_conv + ".bias");
+            if (b1 && w1->data.size() == (size_t)C * C * 3 && b1->data.size() == (size_t)C) {
+                double wl1 = 0.0, bm = 0.0;
+                for (int m = 0; m < C; ++m) {
+                    double sum = 0.0;
+                    for (int k = 0; k < 3 * C; ++k) sum += std::fabs((double)w1->data[(size_t)m * 3 * C + k]);
+                    wl1 = std::max(wl1, sum);
+                    bm = std::max(bm, std::fabs((double)b1->data[m]));
+                }
+                fu->hb_w = (float)(wl1 * 1.0001);
+                fu->hb_b = (float)(bm * 1.0001);
+            }
+        }
         fu->C = C;
         fix.push_back({&fu->img, ab.put(img)});
         fix.push_back({&fu->tab, ab.put(tab)});
@@ -670,8 +686,8 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
         pk.conv({p + ".film1.to_scale", p + ".film1.to_shift"}, &u.film1, u.cin, 1);
         pk.conv({p + ".film2.to_scale", p + ".film2.to_shift"}, &u.film2, u.cin, 1);
         if (u.cin >= 96) {
-            pk.film_u(&u.fu1, p + ".c2", p + ".film1", u.cin);
-            pk.film_u(&u.fu2, p + ".c4", p + ".film2", u.cin);
+            pk.film_u(&u.fu1, p + ".c2", p + ".film1", u.cin, p + ".c1");
+            pk.film_u(&u.fu2, p + ".c4", p + ".film2", u.cin, p + ".c3");
         }
         if (u.cin == 24) {
             pk.up24s_half(&u.s24a, p + ".c1", p + ".c2", p + ".film1", "", "");

@@ -28,7 +28,26 @@ struct ConvS2Args {
     int M, tiles_per_utt, ntiles, mblocks;
     const float* amax_x;   // per-utterance |max| slots (conv3s.h): input (read, nullable), output (written, nullable)
     float* amax_y;
+    // PRE: the output is written as the NEXT conv's ready operand (film_s2.h: split(lrelu(y) * 2^k) as two fp16 planes
+    // [B][part][M / 8][len][8 fp16], k from the analytic bound pre_w * |x|max + pre_b >= |y|, which both kernels evaluate alike)
+    uint4* ypre;
+    float pre_w, pre_b;
 };
+// |conv + bias| <= (max_m sum_k |w|) |x|max + max |b|: the bound the producer normalises its pre-split output by and the consumer undoes
+// (amax = the per-utterance |max| slot of the producer's INPUT; non-null for these launches)
+__device__ __forceinline__ float presplit_bound(float pre_w, float pre_b, const float* amax, int b) { return fmaf(pre_w, amax[b], pre_b); }
+// power of two that brings |max| into [2^14, 2^15) (1 for zero, Inf, NaN: they carry no information)
+__device__ __forceinline__ Bfp norm_from_amax(float amax) {
+    const unsigned u = __builtin_bit_cast(unsigned, amax);
+    Bfp r{1.f, 1.f};
+    if (u != 0u && u < 0x7f800000u) {
+        int k = 14 - ((int)(u >> 23) - 127);
+        k = k > 120 ? 120 : (k < -120 ? -120 : k);
+        r.s = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+        r.inv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+    }
+    return r;
+}
 
 struct CS2 {
     static constexpr int MTB = 3, NWV = 4, WN = 2, NW = MTB * NWV, NTHR = NW * 64, BN = NWV * WN * 32, MAXD = 27, XROW = BN + 2 * MAXD;
@@ -38,7 +57,7 @@ struct CS2 {
     static constexpr int lds_bytes = 2 * BUF_U4 * 16 + TAB * 4 + 64;
 };
 
-template <bool LERP>
+template <bool LERP, bool PRE = false>
 __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) void conv_s2_kernel(ConvS2Args a) {
     using TL = CS2;
     constexpr int MTB = TL::MTB, NWV = TL::NWV, WN = TL::WN, NW = TL::NW, BN = TL::BN, XROW = TL::XROW, A_PER = TL::A_PER;
@@ -195,6 +214,7 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
             const Bfp sx = bfp_load(a.amax_x, cb);
             const int row0 = (cmt0 + wm) * 32;
             float* yb = a.y + ((long)cb * a.M + row0) * len;
+            const float ps = PRE ? norm_from_amax(presplit_bound(a.pre_w, a.pre_b, a.amax_x, cb)).s : 1.f;
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int t = ct0 + (wn * WN + j) * 32 + l31;
@@ -207,7 +227,19 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
                         const float c = Tb[384 + row0] * sx.inv, cl = c * kLoInv;
                         const float e[4] = {comb(hi[j][4 * g], lo[j][4 * g], c, cl) + bv.x, comb(hi[j][4 * g + 1], lo[j][4 * g + 1], c, cl) + bv.y,
                                             comb(hi[j][4 * g + 2], lo[j][4 * g + 2], c, cl) + bv.z, comb(hi[j][4 * g + 3], lo[j][4 * g + 3], c, cl) + bv.w};
-                        if (live) {
+                        if (PRE) {
+                            // lrelu, normalise, split; a position's 16-byte operand row = [lanes 0-31's four channels | lanes 32-63's four]:
+                            // v_permlane32_swap hands the lower half of the wave both halves of the part-1 row, the upper half those of part 2
+                            float v[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = fmaxf(e[q], 0.1f * e[q]) * ps;
+                            unsigned p1[2], p2[2];
+                            split2<false>(v[0], v[1], p1[0], p2[0]);
+                            split2<false>(v[2], v[3], p1[1], p2[1]);
+                            const auto qx = __builtin_amdgcn_permlane32_swap(p1[0], p2[0], false, false);
+                            const auto qy = __builtin_amdgcn_permlane32_swap(p1[1], p2[1], false, false);
+                            if (live) a.ypre[(((long)cb * 2 + lh) * (a.M >> 3) + ((row0 >> 3) + g)) * len + t] = make_uint4(qx[0], qy[0], qx[1], qy[1]);
+                        } else if (live) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 stg_so(yb + (long)(8 * g + q) * len, off, e[q]);
@@ -254,9 +286,10 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
 }
 
 // true = launched (or failed: *rc); false = outside this kernel's preconditions (use conv3s_launch)
-template <bool LERP>
+template <bool LERP, bool PRE = false>
 inline bool conv_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, int B, int Cin, int len, int dil, float* y, const BfpSlots& bfp,
-                        int lin = 0, float lscale = 0.f) {
+                        int lin = 0, float lscale = 0.f, float pre_w = 0.f, float pre_b = 0.f) {
+    if (PRE && (!bfp.x || w.M % 8 != 0)) return false;
     if (w.taps != 3 || w.MT6 % 3 != 0 || w.M > 384 || Cin % 16 != 0 || Cin / 16 > w.S6 || dil < 1 || dil > CS2::MAXD || bfp.c) return false;
     if ((long)B * w.M * len >= (1L << 31) / 4 * 4 && (long)w.M * len * 4 >= (1L << 32)) return false;
     if ((long)Cin * (LERP ? lin : len) * 4 >= (1L << 32) || (long)w.M * len * 4 >= (1L << 32)) return false;      // 32-bit byte offsets inside an utterance
@@ -268,7 +301,7 @@ inline bool conv_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const PackedW& w, 
     if (!ready) {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_s2_kernel<LERP>, hipFuncAttributeMaxDynamicSharedMemorySize, CS2::lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_s2_kernel<LERP, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, CS2::lds_bytes);
         if (e != hipSuccess) { *rc = fail(ctx, TVC_ERR_HIP, "conv_s2 setup: %s", hipGetErrorString(e)); return true; }
         ncu = prop.multiProcessorCount;
         ready = true;
@@ -290,9 +323,12 @@ inline bool conv_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const PackedW& w, 
     a.tiles_per_utt = (len + CS2::BN - 1) / CS2::BN;
     a.ntiles = a.tiles_per_utt * B * a.mblocks;
     a.amax_x = bfp.x;
-    a.amax_y = bfp.y;
+    a.amax_y = PRE ? nullptr : bfp.y;
+    a.ypre = reinterpret_cast<uint4*>(y);
+    a.pre_w = pre_w;
+    a.pre_b = pre_b;
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
-    hipLaunchKernelGGL((conv_s2_kernel<LERP>), dim3(grid), dim3(CS2::NTHR), CS2::lds_bytes, s, a);
+    hipLaunchKernelGGL((conv_s2_kernel<LERP, PRE>), dim3(grid), dim3(CS2::NTHR), CS2::lds_bytes, s, a);
     *rc = launch_check(ctx, "conv_s2");
     return true;
 }

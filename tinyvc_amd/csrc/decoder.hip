@@ -275,6 +275,32 @@ static int film_conv(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const Packed
                                                      cond, C);
 }
 
+// One half of an Upsample block on the 96 / 192 / 384-channel levels: h = ca(lrelu(x)) (lin > 0: x = F.interpolate of the low-rate tensor,
+// evaluated while staging), out = FiLM(cb(lrelu(h)), cond) + residual.  When both convs take their pipelined kernels - a property of the
+// utterance's shape only - h crosses HBM as the second conv's READY operand: conv_s2's epilogue writes split(lrelu(h) * 2^k) as two fp16
+// planes (the bytes of the fp32 tensor), k from the analytic bound hb_w |x|max + hb_b >= |h|, and film_s2 stages it by copy: the
+// lrelu / scale / split of every staged element - repeated by each of the C / 96 row blocks that read it - is done once, by the producer.
+static int conv_film_half(tvc_ctx* ctx, hipStream_t s, const PackedW& ca, const PackedW& cb, const PackedW& fw, const FilmU& fu, const float* x, int lin, float lscale,
+                          int da, int db, float* h, const float* cond, int B, int C, int len, float* out, const float* bsc, const float* bsh, const float* res,
+                          int res_lin, float res_scale, const float* ma_in, float* mh, const float* mcond, float* mout) {
+    const bool pre = len >= FS2::BN && fu.img && fu.C == C && fu.hb_w > 0.f && C % 96 == 0 && C <= 384 && ma_in && mcond && res && db >= 1 && db <= FS2::MAXD &&
+                     (long)C * len * 4 < (1L << 32) && (res_lin <= 0 || (long)C * res_lin * 4 < (1L << 32));
+    if (pre) {
+        int rc = 0;
+        const BfpSlots in{ma_in, nullptr, nullptr};
+        const bool ok = lin > 0 ? conv_s2_try<true, true>(&rc, ctx, s, ca, x, B, C, len, da, h, in, lin, lscale, fu.hb_w, fu.hb_b)
+                                : conv_s2_try<false, true>(&rc, ctx, s, ca, x, B, C, len, da, h, in, 0, 0.f, fu.hb_w, fu.hb_b);
+        if (ok) {
+            TVC_CHECK(rc);
+            if (!film_s2_try(&rc, ctx, s, fu, h, cond, B, C, len, db, out, res, res_lin, res_scale, BfpSlots{ma_in, mcond, mout}, true, fu.hb_w, fu.hb_b))
+                return fail(ctx, TVC_ERR_STATE, "filter_net: the FiLM conv refused the pre-split operand its producer wrote");
+            return rc;
+        }
+    }
+    TVC_CHECK(plain_conv(ctx, s, ca, x, B, C, len, da, h, BfpSlots{ma_in, nullptr, mh}, lin, lscale));
+    return film_conv(ctx, s, cb, fw, fu, h, cond, B, C, len, db, out, bsc, bsh, res, res_lin, res_scale, BfpSlots{mh, mcond, mout});
+}
+
 // cmax / smax (nullable): |max| slots of `content` / of cat[source, energy] if the caller already has them
 int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
                const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps, const float* cmax, const float* smax) {
@@ -398,11 +424,9 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
                         TVC_CHECK(run_conv48s(ctx, s, cb, h, 0, 0.f, &fw, bsc, bsh, cond, x1, 0, 0.f, nullptr, B, lo, db, mh, mcond, slot(S_LEV + i), &u.c5, xlev[i]));
                     }
                 } else if (half == 0) {
-                    TVC_CHECK(plain_conv(ctx, s, ca, x, B, C, lo, da, h, BfpSlots{ma_in, nullptr, mh}, lin, lscale));
-                    TVC_CHECK(film_conv(ctx, s, cb, fw, u.fu1, h, cond, B, C, lo, db, xout, bsc, bsh, x, lin, lscale, BfpSlots{mh, mcond, mout}));
+                    TVC_CHECK(conv_film_half(ctx, s, ca, cb, fw, u.fu1, x, lin, lscale, da, db, h, cond, B, C, lo, xout, bsc, bsh, x, lin, lscale, ma_in, mh, mcond, mout));
                 } else {
-                    TVC_CHECK(plain_conv(ctx, s, ca, x1, B, C, lo, da, h, BfpSlots{ma_in, nullptr, mh}));
-                    TVC_CHECK(film_conv(ctx, s, cb, fw, u.fu2, h, cond, B, C, lo, db, xout, bsc, bsh, x1, 0, 0.f, BfpSlots{mh, mcond, mout}));
+                    TVC_CHECK(conv_film_half(ctx, s, ca, cb, fw, u.fu2, x1, 0, 0.f, da, db, h, cond, B, C, lo, xout, bsc, bsh, x1, 0, 0.f, ma_in, mh, mcond, mout));
                 }
             }
             if (C != 48) {   // c5 (1x1, C -> C/2) as a split-precision GEMM launch; its output's |max| in one pass (the functor finishes the elements)

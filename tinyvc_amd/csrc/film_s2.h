@@ -18,6 +18,7 @@
 // pairs: 1.9e-7, fp32 MFMA: 4.9e-7, bf16 x 3: 4.2e-7; tools/micro/f16split.hip, profiles/r03_f16split.txt).  The slots this kernel reads are exact maxima written by the producing kernels' epilogues.
 #pragma once
 #include "conv3s.h"
+#include "conv_s2.h"
 
 namespace tvc {
 
@@ -36,6 +37,10 @@ struct FilmS2Args {
     const float* amax_x;   // per-utterance |max| slots: h and cond (read), out (written, nullable)
     const float* amax_c;
     float* amax_y;
+    // XPRE: x is conv_s2's pre-split output (two fp16 planes [B][part][C / 8][len][8 fp16] of lrelu(h) * 2^k, k from the bound
+    // pre_w * |max of the producer's input| + pre_b): staged by copy, amax_x = that input's slot
+    const uint4* xpre;
+    float pre_w, pre_b;
 };
 
 // Workgroup tile 96 x 256: 8 waves side by side, each all 96 rows (WM = 3 m-tiles) of 32 columns - 144 accumulator registers of the 256 a
@@ -51,18 +56,6 @@ struct FS2 {
     static_assert(2 * BN <= NTHR, "one cond item per thread");
 };
 
-// power of two that brings |max| into [2^14, 2^15) (1 for zero, Inf, NaN: they carry no information)
-__device__ __forceinline__ Bfp norm_from_amax(float amax) {
-    const unsigned u = __builtin_bit_cast(unsigned, amax);
-    Bfp r{1.f, 1.f};
-    if (u != 0u && u < 0x7f800000u) {
-        int k = 14 - ((int)(u >> 23) - 127);
-        k = k > 120 ? 120 : (k < -120 ? -120 : k);
-        r.s = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
-        r.inv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
-    }
-    return r;
-}
 // fp16(v) and the fp16 of what it left behind
 __device__ __forceinline__ void split8u(const float (&v)[8], uint4& p1, uint4& p2) {
     unsigned o1[4], o2[4];
@@ -72,6 +65,7 @@ __device__ __forceinline__ void split8u(const float (&v)[8], uint4& p1, uint4& p
     p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
 }
 
+template <bool XPRE>
 __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::NW / 4))) void film_s2_kernel(FilmS2Args a) {
     using TL = FS2;
     constexpr int MTB = TL::MTB, WM = TL::WM, NWV = TL::NWV, WN = TL::WN, NW = TL::NW, BN = TL::BN, XROW = TL::XROW, A_PER = TL::A_PER, XS = TL::XS;
@@ -103,7 +97,8 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
     // this thread's two staging items: (8-channel half, column) of the conv's halo tile and of the cond tile; threads beyond the
     // items repeat an earlier one (same value to the same LDS row: no branch in the loop body)
     u32x4 ar[A_PER];
-    float xr[XS][8], cr[8];
+    float xr[XPRE ? 1 : XS][8], cr[8];
+    uint4 xq[XPRE ? XS : 1][2];          // XPRE: the two parts of an item, as stored
     int ig[XS], ic[XS], xdst[XS];
 #pragma unroll
     for (int k = 0; k < XS; ++k) {
@@ -130,7 +125,7 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
         int pc = lt0 + cc;
         pc = pc > len - 1 ? len - 1 : pc;
         co = (unsigned)(8 * cg * len + pc);
-        xs = norm_from_amax(a.amax_x[lb]).s;
+        xs = XPRE ? 1.f : norm_from_amax(a.amax_x[lb]).s;
         cs_ = norm_from_amax(a.amax_c[lb]).s;
     };
     tile_offsets();
@@ -144,10 +139,20 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
         }
         const float* xc = a.x + ((long)lb * C + (long)ls * 16) * len;
         const float* cc_ = a.cond + ((long)lb * C + (long)ls * 16) * len;
+        if (XPRE) {      // item (8-channel half ig, column): one 16-byte load per part; xo = 8 ig len + p -> plane row 2 ls + ig, column p
+            const uint4* xp = a.xpre + ((long)lb * 2 * (C >> 3) + 2 * ls) * len;
 #pragma unroll
-        for (int k = 0; k < XS; ++k)
+            for (int k = 0; k < XS; ++k) {
+                const unsigned e = xo[k] - (unsigned)(7 * ig[k] * len);            // = ig len + p
+                xq[k][0] = __builtin_bit_cast(uint4, ldg_so4(xp, 16u * e));
+                xq[k][1] = __builtin_bit_cast(uint4, ldg_so4(xp + (long)(C >> 3) * len, 16u * e));
+            }
+        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xr[k][j] = ldg_so(xc + (long)j * len, 4u * xo[k]);
+            for (int k = 0; k < XS; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xr[k][j] = ldg_so(xc + (long)j * len, 4u * xo[k]);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) cr[j] = ldg_so(cc_ + (long)j * len, 4u * co);
         rxs = xs;
@@ -179,9 +184,14 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
         uint4 p1, p2;
 #pragma unroll
         for (int k = 0; k < XS; ++k) {
+            if (XPRE) {
+                p1 = xq[k][0];
+                p2 = xq[k][1];
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(xr[k][j], 0.1f * xr[k][j]) * rxs;      // leaky_relu(h, 0.1), normalised (power of two: exact)
-            split8u(v, p1, p2);
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(xr[k][j], 0.1f * xr[k][j]) * rxs;      // leaky_relu(h, 0.1), normalised (power of two: exact)
+                split8u(v, p1, p2);
+            }
             Xb[xdst[k]] = p1;
             Xb[2 * XROW + xdst[k]] = p2;
         }
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
             int el = lane;
             asm volatile("" : "+v"(el));
             const int e31 = el & 31, eh = el >> 5;
-            const float ix = norm_from_amax(a.amax_x[cb]).inv, ic_ = norm_from_amax(a.amax_c[cb]).inv;
+            const float ix = norm_from_amax(XPRE ? presplit_bound(a.pre_w, a.pre_b, a.amax_x, cb) : a.amax_x[cb]).inv, ic_ = norm_from_amax(a.amax_c[cb]).inv;
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
             const int row0 = (cmb * MTB + wm * WM + i) * 32;
@@ -382,8 +392,9 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
 }
 
 // true = launched (or failed: *rc); false = outside this kernel's preconditions (use conv3s_launch)
+// pre = true: h is conv_s2's pre-split output (conv_s2.h PRE) normalised by the bound pre_w * |max| + pre_b, bfp.x = the slot that bound is taken from
 inline bool film_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const FilmU& fu, const float* h, const float* cond, int B, int C, int len, int dil, float* out,
-                        const float* res, int res_lin, float res_scale, const BfpSlots& bfp) {
+                        const float* res, int res_lin, float res_scale, const BfpSlots& bfp, bool pre = false, float pre_w = 0.f, float pre_b = 0.f) {
     if (!fu.img || fu.C != C || C % 96 != 0 || C > 384 || dil < 1 || dil > FS2::MAXD || !bfp.x || !bfp.c || !res) return false;
     if ((long)C * len * 4 >= (1L << 32) || (res_lin > 0 && (long)C * res_lin * 4 >= (1L << 32))) return false;
     static bool ready_dev[64] = {};
@@ -393,7 +404,8 @@ inline bool film_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const FilmU& fu, c
     if (!ready) {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS2::lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FS2::lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS2::lds_bytes);
         if (e != hipSuccess) {
             *rc = fail(ctx, TVC_ERR_HIP, "film_s2 setup: %s", hipGetErrorString(e));
             return true;
@@ -417,10 +429,14 @@ inline bool film_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const FilmU& fu, c
     a.tiles_per_utt = (len + FS2::BN - 1) / FS2::BN;
     a.ntiles = a.tiles_per_utt * B * a.mblocks;
     a.amax_x = bfp.x;
+    a.xpre = reinterpret_cast<const uint4*>(h);
+    a.pre_w = pre_w;
+    a.pre_b = pre_b;
     a.amax_c = bfp.c;
     a.amax_y = bfp.y;
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
-    hipLaunchKernelGGL(film_s2_kernel, dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
+    if (pre) hipLaunchKernelGGL(film_s2_kernel<true>, dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
+    else hipLaunchKernelGGL(film_s2_kernel<false>, dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
     *rc = launch_check(ctx, "film_s2");
     return true;
 }

@@ -66,6 +66,7 @@ struct FilmU {
     const float* img = nullptr;
     const float* tab = nullptr;
     int C = 0;
+    float hb_w = 0.f, hb_b = 0.f;      // bound of the half's FIRST conv (the producer of this kernel's h): |c(x) + b| <= hb_w |x|max + hb_b
 };
 struct UpW {
     PackedW c1, c2, c3, c4, c5, film1, film2;  // film = [to_scale ; to_shift] stacked on M (2C); film.bias = [b_scale (C) ; b_shift (C)]
