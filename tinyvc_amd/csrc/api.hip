@@ -670,6 +670,23 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
             pk.conv24s(&d.s24c1, p + ".c1", 24);
             pk.conv24s(&d.s24c2, p + ".c2", 24);
             pk.conv24s(&d.s24c3r, p + ".c3", 48, p + ".down_res.bias", &d.c3);
+            // bounds of the fused block's on-chip intermediates (down24f_kernel): max_m sum_k |w| and max |b| of c1 and c2, a hair above
+            auto bound = [&](const std::string& name, float* bw, float* bb) {
+                const HostTensor* w = pk.find(name + ".weight");
+                const HostTensor* b = pk.find(name + ".bias");
+                if (!w || !b || w->data.size() != (size_t)24 * 24 * 3 || b->data.size() != 24) return;
+                double wl1 = 0.0, bm = 0.0;
+                for (int m = 0; m < 24; ++m) {
+                    double sum = 0.0;
+                    for (int k = 0; k < 72; ++k) sum += std::fabs((double)w->data[(size_t)m * 72 + k]);
+                    wl1 = std::max(wl1, sum);
+                    bm = std::max(bm, std::fabs((double)b->data[m]));
+                }
+                *bw = (float)(wl1 * 1.0001);
+                *bb = (float)(bm * 1.0001);
+            };
+            bound(p + ".c1", &d.b1_w, &d.b1_b);
+            bound(p + ".c2", &d.b2_w, &d.b2_b);
         }
     }
     for (int i = 0; i < 5; ++i) {

@@ -358,7 +358,7 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
             const float* mxi = slot(S_SKIP0 + i - 1);
             float *mh1 = slot(S_DH1 + i - 1), *mh2 = slot(S_DH2 + i - 1), *mout = slot(S_SKIP0 + i);
             if (d.cin == 24) {   // the whole 24-channel block in three conv24s launches; c3 folds down_res(xi) in and writes y2
-                TVC_CHECK(run_down24_split(ctx, s, d, xi, h1, h2, skip[i], y2, B, len, mxi, mh1, mh2, mout));
+                TVC_CHECK(run_down24_fused(ctx, s, d, xi, skip[i], y2, B, len, mxi, mout));
             } else {
                 if (d.cin == 48) {   // c1 -> c2 in one launch, weights resident in LDS, c1's output never leaves the CU (conv48s.hip)
                     TVC_CHECK(run_conv48_pair(ctx, s, d.c1, d.c2, xi, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, h2, B, len, 1, 2, mxi, nullptr, mh2));

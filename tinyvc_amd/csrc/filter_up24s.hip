@@ -822,6 +822,317 @@ static int launch_conv24s(tvc_ctx* ctx, hipStream_t s, Conv24SArgs a, int B) {
     return launch_check(ctx, "conv24s");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole 24-channel Downsample block in ONE kernel: xi -> c1 (dil 1) -> lrelu -> c2 (dil 2) -> lrelu -> c3 (dil 4, 24 -> 48) + down_res(xi)
+// (decoder.py:143-158).  The three launches above are almost pure staging - without their MFMAs they take 75 of 85, 66 of 74 and 121 of
+// 164 us (profiles/r03_whatif.txt) - and h1 / h2 cross HBM between them (4 x 118 MB per step).  Here they stay on chip as the next conv's
+// split operand tiles, like the intermediate of the fused ups.4 halves: a tile is 244 output samples; c1 computes h1 on the 256 columns
+// c2's and c3's halos need (7 samples of xi beyond the tile on either side), c2 h2 on 252, c3 the 244 - one 32-column n-tile per wave and
+// conv, two barriers per tile, the next tile's input split into the second input buffer and the one after it in flight in registers
+// meanwhile (conv24s's scheme).  Same K order, same part products, same epilogue arithmetic as the three launches: for inputs inside
+// fp16's window the result is bit-identical to theirs.  The intermediates have no |max| slot (they never leave the CU): h1 is scaled by the
+// analytic bound (max_m sum|w1|) |xi|max + max|b1|, h2 by the bound of that bound, c3 and down_res share one scale as they share accumulators.
+struct Down24FArgs {
+    const float* x;        // xi [B][24][len]
+    float* out;            // [B][48][len]
+    float* y2;             // optional [B][48][len / 4]: mean of samples 4 d + 1, 4 d + 2 (the next block's 1/4-rate input)
+    const u32x4* img1;     // conv24s blobs: c1 (10 pieces + 64 floats), c2, c3 (20 pieces, bias = c3 + down_res, joint scales)
+    const u32x4* img2;
+    const u32x4* img3;
+    const u32x4* rimg;     // down_res image (8 pieces)
+    int len, tiles_per_utt, ntiles;
+    float b1_w, b1_b, b2_w, b2_b;      // |h1| <= b1_w |xi|max + b1_b, |h2| <= b2_w |h1|bound + b2_b
+    const float* amax_x;   // per-utterance |max| of xi (read, nullable), of out (written, nullable)
+    float* amax_y;
+};
+struct D24F {
+    static constexpr int W = 244, XW = W + 14, XP = 264, HP = 256, NT = 512;
+    static constexpr int LDS_BYTES = (2 * 6 * XP + 2 * 6 * HP + 48 * 64) * 16 + (3 * 64 + 8) * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu(2))) void down24f_kernel(Down24FArgs a) {
+    constexpr int W = D24F::W, XW = D24F::XW, XP = D24F::XP, HP = D24F::HP, NT = D24F::NT;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_df[];
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem_df);             // [2 buffers][2 parts][3 groups][XP]: lrelu(xi), position t0 - 7 + c
+    u32x4* H1 = Xs + 2 * 6 * XP;                               // [2 parts][3 groups][HP]: lrelu(h1), position t0 - 6 + c
+    u32x4* H2 = H1 + 6 * HP;                                   // lrelu(h2), position t0 - 4 + c
+    u32x4* W1 = H2 + 6 * HP;                                   // 10 + 10 + 20 + 8 pieces
+    u32x4* W2 = W1 + 10 * 64;
+    u32x4* W3 = W2 + 10 * 64;
+    u32x4* Wr = W3 + 20 * 64;
+    float* Bi = reinterpret_cast<float*>(Wr + 8 * 64);         // the three blobs' 64 floats (bias, [62 + mt] = scales), then the |max| exchange
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int len = a.len;
+    for (int i = tid; i < 10 * 64; i += NT) {
+        W1[i] = a.img1[i];
+        W2[i] = a.img2[i];
+    }
+    for (int i = tid; i < 20 * 64; i += NT) W3[i] = a.img3[i];
+    for (int i = tid; i < 8 * 64; i += NT) Wr[i] = a.rimg[i];
+    if (tid < 64) {
+        Bi[tid] = reinterpret_cast<const float*>(a.img1 + 10 * 64)[tid];
+        Bi[64 + tid] = reinterpret_cast<const float*>(a.img2 + 10 * 64)[tid];
+        Bi[128 + tid] = reinterpret_cast<const float*>(a.img3 + 20 * 64)[tid];
+    }
+
+    // staging items (8-channel group, column): 3 * XW = 774, two per thread
+    float xa[2][8];
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+        const int b = tile / a.tiles_per_utt;
+        const int px0 = (tile - b * a.tiles_per_utt) * W - 7;
+        const float* xb = a.x + (long)b * 24 * len;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * NT;
+            int g = idx / XW;
+            const int c = idx - g * XW;
+            g = g > 2 ? 2 : g;                                 // idle items load a valid address
+            int p = px0 + c;
+            p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+            const unsigned o = 4u * (unsigned)(8 * g * len + p);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xa[i][j] = ldg_so(xb + (long)j * len, o);
+        }
+    };
+    auto deposit = [&](int buf, float xs) __attribute__((always_inline)) {
+        u32x4* X = Xs + buf * 6 * XP;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * NT;
+            if (idx >= 3 * XW) continue;
+            const int g = idx / XW, c = idx - g * XW;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(xa[i][j], 0.1f * xa[i][j]) * xs;
+            uint4 p1, p2;
+            split8(v, p1, p2);
+            X[(0 + g) * XP + c] = __builtin_bit_cast(u32x4, p1);
+            X[(3 + g) * XP + c] = __builtin_bit_cast(u32x4, p2);
+        }
+    };
+    // block-floating-point scales of an utterance: xi (its slot), h1 and h2 (analytic bounds), and the one c3 and down_res share
+    struct Sc {
+        Bfp x, h1, hj;
+    };
+    auto scales = [&](int b) __attribute__((always_inline)) -> Sc {
+        Sc r;
+        r.x = bfp_load(a.amax_x, b);
+        if (a.amax_x) {
+            const float bound1 = fmaf(a.b1_w, a.amax_x[b], a.b1_b);
+            r.h1 = bfp_from_amax(bound1);
+            r.hj = bfp_min(bfp_from_amax(fmaf(a.b2_w, bound1, a.b2_b)), r.x);
+        } else {
+            r.h1 = r.hj = Bfp{1.f, 1.f};
+        }
+        return r;
+    };
+    // a 24-channel conv's epilogue into the next conv's operand tile: lrelu(acc + bias) * s, split, one 16-byte row per lane (up24s)
+    auto to_tile = [&](const f32x16& acc, const f32x16& alo, float c, const float* bias, float s, u32x4* H, int col) __attribute__((always_inline)) {
+        const float cl = c * kLoInv;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const f32x4s bv = *reinterpret_cast<const f32x4s*>(bias + 8 * g + 4 * lh);
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float t = comb(acc[4 * g + q], alo[4 * g + q], c, cl) + bv[q];
+                v[q] = fmaxf(t, 0.1f * t) * s;
+            }
+            u32x2 p1, p2;
+            split4(v, p1, p2);
+            const auto qx = __builtin_amdgcn_permlane32_swap(p1[0], p2[0], false, false);
+            const auto qy = __builtin_amdgcn_permlane32_swap(p1[1], p2[1], false, false);
+            const u32x4 row = {qx[0], qy[0], qx[1], qy[1]};
+            *reinterpret_cast<u32x4*>(H + (3 * lh + g) * HP + col) = row;
+        }
+    };
+
+    int tile, tend, cur = 0;
+    tile_range(a.ntiles, tile, tend);
+    if (tile >= tend) return;
+    fetch(tile);
+    deposit(0, bfp_load(a.amax_x, tile / a.tiles_per_utt).s);
+    if (tile + 1 < tend) fetch(tile + 1);
+    slab_barrier();
+    const int len2 = len >> 2;
+    float mx_run = 0.f;
+    int mx_b = tile / a.tiles_per_utt;
+    for (; tile < tend; ++tile, cur ^= 1) {
+        const int b = tile / a.tiles_per_utt;
+        if (a.amax_y && b != mx_b) {
+            amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 192);
+            mx_run = 0.f;
+            mx_b = b;
+        }
+        const int t0 = (tile - b * a.tiles_per_utt) * W;
+        const int next = tile + 1, next2 = next + 1;
+        if (next < tend) deposit(cur ^ 1, bfp_load(a.amax_x, next / a.tiles_per_utt).s);   // tile i + 1 (requested one tile ago) -> the other buffer
+        if (next2 < tend) fetch(next2);                        // tile i + 2 flies across this tile
+        const Sc sc = scales(b);
+        const int n = wave * 32 + l31;                         // this lane's column of every conv's tile
+        const int t = t0 + n;                                  // ... = the output position of c3's
+        const bool live = n < W && t < len;
+        const int tc = t < len ? t : len - 1;
+        // down_res's B fragments (xi at the output position, raw), requested before the first multiply
+        float xq0[8], xq1[8];
+        {
+            const float* xb2 = a.x + (long)b * 24 * len;
+            const unsigned o0 = 4u * (unsigned)(8 * lh * len + tc), o1 = 4u * (unsigned)tc;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xq0[j] = ldg_so(xb2 + (long)j * len, o0);                // K16 step 0: channels 8 lh + j
+                xq1[j] = ldg_so(xb2 + (long)(16 + j) * len, o1);         // step 1: channels 16 + j on lh = 0, the zero unit on lh = 1
+            }
+        }
+        // ---- c1: Xs -> H1 (position t0 - 6 + n needs xi at t0 - 7 + n + tap) ---------------------------------------------------
+        {
+            f32x16 acc, alo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = alo[r] = 0.f;
+            conv24_phase<XP, 1>(acc, alo, Xs + cur * 6 * XP, W1, n, 0, XW - 1, lane);       // Xs holds the replicate-padded input
+            to_tile(acc, alo, Bi[62] * sc.x.inv, Bi, sc.h1.s, H1, n);
+        }
+        slab_barrier();
+        // ---- c2: H1 -> H2 (position t0 - 4 + n needs h1 at positions ... + 2 (tap - 1) = H1 columns n + 2 tap) -------------------
+        {
+            f32x16 acc, alo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = alo[r] = 0.f;
+            const int lo = 6 - t0 > 0 ? 6 - t0 : 0;                                  // the layer's own replicate padding: h1 exists on [0, len)
+            const int hi = len - 1 - t0 + 6 < HP - 1 ? len - 1 - t0 + 6 : HP - 1;
+            conv24_phase<HP, 2>(acc, alo, H1, W2, n, lo, hi, lane);
+            to_tile(acc, alo, Bi[64 + 62] * sc.h1.inv, Bi + 64, sc.hj.s, H2, n);
+        }
+        slab_barrier();
+        // ---- c3 + down_res: H2 (columns n + 4 tap) and xi -> out, two m-tiles sharing every B fragment ---------------------------
+        f32x16 acc[2], alo[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = alo[mt][r] = 0.f;
+        {
+            const int lo = 4 - t0 > 0 ? 4 - t0 : 0;
+            const int hi = len - 1 - t0 + 4 < HP - 1 ? len - 1 - t0 + 4 : HP - 1;
+            constexpr int TAP0[5] = {0, 0, 1, 2, 2}, GRP0[5] = {0, 2, 1, 0, 2};
+            constexpr int TAP1[5] = {0, 1, 1, 2, 2}, GRP1[5] = {1, 0, 2, 1, 2};
+            f16x8 af[2][2][2], bf[2][2];
+            auto frags = [&](int s, int fb) __attribute__((always_inline)) {
+                int c = n + (lh ? TAP1[s] : TAP0[s]) * 4;
+                c = c < lo ? lo : (c > hi ? hi : c);
+                const int row = (lh ? GRP1[s] : GRP0[s]) * HP + c;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    bf[fb][p] = __builtin_bit_cast(f16x8, H2[p * 3 * HP + row]);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) af[fb][mt][p] = __builtin_bit_cast(f16x8, W3[((s * 2 + mt) * 2 + p) * 64 + lane]);
+                }
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const int fb = s & 1;
+                if (s + 1 < 5) frags(s + 1, fb ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) alo[mt] = TVC_MFMA16(af[fb][mt][1], bf[fb][0], alo[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[mt] = TVC_MFMA16(af[fb][mt][0], bf[fb][0], acc[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) alo[mt] = TVC_MFMA16(af[fb][mt][0], bf[fb][1], alo[mt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {       // + down_res(xi): two more K16 steps on the same accumulators
+            float xq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xq[j] = (st ? xq1[j] : xq0[j]) * sc.hj.s;
+            uint4 p1, p2;
+            split8(xq, p1, p2);
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            const bool dead = st == 1 && lh;
+            const f16x8 xf[2] = {__builtin_bit_cast(f16x8, dead ? z : p1), __builtin_bit_cast(f16x8, dead ? z : p2)};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f16x8 wf[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) wf[p] = __builtin_bit_cast(f16x8, Wr[((st * 2 + mt) * 2 + p) * 64 + lane]);
+                alo[mt] = TVC_MFMA16(wf[1], xf[0], alo[mt]);
+                acc[mt] = TVC_MFMA16(wf[0], xf[0], acc[mt]);
+                alo[mt] = TVC_MFMA16(wf[0], xf[1], alo[mt]);
+            }
+        }
+        float mx = 0.f;
+        {
+            float* ob = a.out + (long)b * 48 * len;
+            const unsigned oo = 4u * (unsigned)(4 * lh * len + tc);
+            const bool pair = a.y2 != nullptr && (t & 3) == 1 && t + 1 < len;      // 1/4-rate copy: mean of samples 4 d + 1, 4 d + 2
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float c = Bi[128 + 62 + mt] * sc.hj.inv, cl = c * kLoInv;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (32 * mt + 8 * g >= 48) continue;
+                    const f32x4s bv = *reinterpret_cast<const f32x4s*>(Bi + 128 + 32 * mt + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = comb(acc[mt][4 * g + q], alo[mt][4 * g + q], c, cl) + bv[q];
+                        const float vn = __shfl_down(v, 1);                        // sample t + 1 (same tile: W % 4 == 0)
+                        const int m = 32 * mt + 8 * g + 4 * lh + q;
+                        if (live) {
+                            stg_so(ob + (long)(32 * mt + 8 * g + q) * len, oo, v);
+                            mx = fmaxf(mx, fabsf(v));
+                            if (pair) a.y2[((long)b * 48 + m) * len2 + (t >> 2)] = fmaf(0.5f, v, __fmul_rn(0.5f, vn));
+                        }
+                    }
+                }
+            }
+        }
+        mx_run = fmaxf(mx_run, mx);
+        // (no barrier here: the next tile's c1 writes H1, which nobody reads any more; its first barrier comes before anybody rewrites H2)
+    }
+    if (a.amax_y) amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 192);
+}
+
+int run_down24_fused(tvc_ctx* ctx, hipStream_t s, const DownW& d, const float* xi, float* out, float* y2, int B, int len, const float* amax_xi, float* amax_out) {
+    if (!d.s24c1 || !d.s24c2 || !d.s24c3r || !d.res.A6 || d.res.MT6 != 2 || d.res.wjoint != d.c3.A6 || !(d.b1_w > 0.f))
+        return fail(ctx, TVC_ERR_STATE, "down24f: the split weight blobs of the 24-channel Downsample block are missing");
+    if (d.cin != 24 || d.cout != 48) return fail(ctx, TVC_ERR_ARG, "down24f: 24 -> 48 channels only");
+    if ((long)len * 48 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "down24f: utterance too long for 32-bit byte offsets");
+    if (y2 && len % 4 != 0) return fail(ctx, TVC_ERR_ARG, "down24f: the 1/4-rate copy needs len % 4 == 0");
+    static int ncu_dev[64] = {};
+    int& ncu = ncu_dev[ctx->device & 63];
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)down24f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, D24F::LDS_BYTES);
+        if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "down24f setup: %s", hipGetErrorString(e));
+        ncu = prop.multiProcessorCount;
+    }
+    Down24FArgs a{};
+    a.x = xi;
+    a.out = out;
+    a.y2 = y2;
+    a.img1 = reinterpret_cast<const u32x4*>(d.s24c1);
+    a.img2 = reinterpret_cast<const u32x4*>(d.s24c2);
+    a.img3 = reinterpret_cast<const u32x4*>(d.s24c3r);
+    a.rimg = reinterpret_cast<const u32x4*>(d.res.A6);
+    a.len = len;
+    a.tiles_per_utt = (len + D24F::W - 1) / D24F::W;
+    a.ntiles = a.tiles_per_utt * B;
+    a.b1_w = d.b1_w;
+    a.b1_b = d.b1_b;
+    a.b2_w = d.b2_w;
+    a.b2_b = d.b2_b;
+    a.amax_x = amax_xi;
+    a.amax_y = amax_out;
+    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    hipLaunchKernelGGL(down24f_kernel, dim3(grid), dim3(D24F::NT), D24F::LDS_BYTES, s, a);
+    return launch_check(ctx, "down24f");
+}
+
 // Downsample block with 24 input channels (decoder.py:143-158) after its interpolate:
 // xi [B][24][len] -> h1 -> h2 -> out [B][48][len] = c3(h2) + down_res(xi), and optionally the next block's 1/4-rate input.
 // slots: per-utterance |max| of xi (read), of h1 / h2 (scratch [B] each, zeroed) and of out (written; nullable).

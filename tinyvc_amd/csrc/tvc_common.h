@@ -57,6 +57,7 @@ struct DownW {
     const float* s24c1 = nullptr;   // cin == 24: weight blobs of conv24s_kernel (filter_up24s.hip)
     const float* s24c2 = nullptr;
     const float* s24c3r = nullptr;   // c3's blob with c3.bias + down_res.bias and the joint scales (the launch folds the residual 1x1 in)
+    float b1_w = 0.f, b1_b = 0.f, b2_w = 0.f, b2_b = 0.f;   // cin == 24: |c1 out| <= b1_w |xi|max + b1_b, |c2 out| <= b2_w |c1 out| + b2_b (down24f_kernel's on-chip intermediates)
     int cin = 0, cout = 0, factor = 1;
 };
 // conv + FiLM packed for film_s2.h (cin >= 96): one weight image whose 30 KiB units hold everything a (96-row block, 16-channel slab)
@@ -266,6 +267,7 @@ int run_up24_split(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const fl
                    const float* amax_c, float* amax_x1);
 int run_down0_split(tvc_ctx*, hipStream_t, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len,
                     const float* amax_x, float* amax_y);
+int run_down24_fused(tvc_ctx*, hipStream_t, const DownW& d, const float* xi, float* out, float* y2, int B, int len, const float* amax_xi, float* amax_out);
 int run_down24_split(tvc_ctx*, hipStream_t, const DownW& d, const float* xi, float* h1, float* h2, float* out, float* y2, int B, int len,
                      const float* amax_xi, float* amax_h1, float* amax_h2, float* amax_out);
 int run_conv48s(tvc_ctx*, hipStream_t, const PackedW& w, const float* x, int lin, float lscale, const PackedW* film, const float* bsc, const float* bsh,
