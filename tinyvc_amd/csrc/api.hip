@@ -400,7 +400,7 @@ struct Packer {
         img[10 * 256 + 31] = sc;
         fix.push_back({slot, ab.put(img)});
     }
-    // Weight blob of one 24-input-channel k3 conv for conv24s_kernel (filter_up24s.hip): pieces [step][m-tile][part]
+    // Weight blob of one 24-input-channel k3 conv for down24f_kernel (filter_up24s.hip): pieces [step][m-tile][part]
     // (same (tap, group) K order as up24s_half), then 64 floats: bias [M <= 48], [62], [63] = the power-of-two scales of the (at
     // most two) m-tiles.  M = 24 (one m-tile) or 48 (two).  `joint`: take the scales of this already packed image instead of the
     // weight's own (c3 of the 24-channel Downsample block is accumulated with down_res into one tile: conv_joint).

@@ -238,7 +238,7 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
 // FilterNet (decoder.py:193-233).  Every Conv1d runs on the split-precision fp16 MFMA path (conv3s.h):
 //   level (channels @ rate)     kernels
 //   24 @ L        downs[0]      down0s_kernel (+ the 1/5-rate pick Downsample 1 starts from)
-//   24 -> 48 @ L/5  Downsample 1  conv24s_kernel x3 (c3 also accumulates down_res(xi) and writes Downsample 2's 1/4-rate input)
+//   24 -> 48 @ L/5  Downsample 1  down24f_kernel: the whole block in one launch (h1 / h2 on chip; c3 also accumulates down_res(xi) and writes Downsample 2's 1/4-rate input)
 //   48 -> 96 @ L/20 Downsample 2  conv48s_kernel (c1, c2: LDS-resident weights), conv3s (c3 + down_res as a second K phase)
 //   96 -> 192, 192 -> 384       conv3s x3 per block, same c3 fusion
 //   384, 192, 96  Upsample 0-2  conv3s: c1 (interpolating while it stages), c2 + FiLM1 + interpolated residual, c3, c4 + FiLM2 + residual;
@@ -357,7 +357,7 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
             const int f2 = i < 4 ? ctx->downs[i].factor : 0;
             const float* mxi = slot(S_SKIP0 + i - 1);
             float *mh1 = slot(S_DH1 + i - 1), *mh2 = slot(S_DH2 + i - 1), *mout = slot(S_SKIP0 + i);
-            if (d.cin == 24) {   // the whole 24-channel block in three conv24s launches; c3 folds down_res(xi) in and writes y2
+            if (d.cin == 24) {   // the whole 24-channel block in one launch; c3 folds down_res(xi) in and writes y2
                 TVC_CHECK(run_down24_fused(ctx, s, d, xi, skip[i], y2, B, len, mxi, mout));
             } else {
                 if (d.cin == 48) {   // c1 -> c2 in one launch, weights resident in LDS, c1's output never leaves the CU (conv48s.hip)

@@ -594,249 +594,20 @@ int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// One 24-input-channel k3 conv (Downsample 1's c1 / c2 / c3, decoder.py:143-158) on the same machinery: 24 -> 24 (one
-// m-tile) or 24 -> 48 (two), optional leaky_relu on the input, optional 1/4-rate copy for the next Downsample block (mean of
-// samples 4 d + 1 and 4 d + 2, see C3EpiBias).  Persistent, double-buffered input tiles.
-// RESCONV: the block's residual down_res(xi), a 1x1 conv of a second 24-channel tensor, is accumulated on the same tile from B
-// fragments loaded straight from HBM (the two weight images share their per-m-tile scales, the two inputs the smaller of their
-// block-floating-point scales: one accumulator pair, one unit).
-template <int MT_, int DIL_, bool LRELU_, bool RESCONV_>
-struct C24S {
-    static constexpr int MT = MT_, DIL = DIL_;
-    static constexpr bool LRELU = LRELU_, RESCONV = RESCONV_;
-    static constexpr int XW = 256, XP = XW, W = (XW - 2 * DIL) / 4 * 4, NT = 512;
-    static constexpr int PIECES = 10 * MT, RPIECES = RESCONV ? 4 * MT : 0, FL = 64;      // + 8 floats behind FL for the |max| exchange
-    static constexpr int LDS_BYTES = (2 * 6 * XP + (PIECES + RPIECES) * 64) * 16 + (FL + 8) * 4;
-    static_assert(W % 4 == 0, "the 1/4-rate copy pairs samples inside a tile");
-};
-struct Conv24SArgs {
-    const float* x;        // [B][24][len]
-    const float* res;      // RESCONV: the second input xi [B][24][len]
-    const u32x4* rimg;     // RESCONV: the 1x1's image (PackedW::A6 of a 24-input 1x1: [2 steps][MT][2 parts])
-    float* out;            // [B][M][len]
-    float* y2;             // optional [B][M][len / 4]
-    const u32x4* img;      // 10 * MT weight pieces [step][m-tile][part], then 64 floats: bias, [62 + mt] = the m-tiles' scales
-    int M, len, tiles_per_utt, ntiles;
-    // block-floating-point guard (conv3s.h): per-utterance |max| slots of x / xi (read, nullable) and of the output (written, nullable)
-    const float* amax_x;
-    const float* amax_r;
-    float* amax_y;
-};
-
-template <class CF>
-__global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(2))) void conv24s_kernel(Conv24SArgs a) {
-    constexpr int W = CF::W, XW = CF::XW, XP = CF::XP, NT = CF::NT, MT = CF::MT, DIL = CF::DIL;
-    extern __shared__ __attribute__((aligned(16))) uint4 smem_c[];
-    u32x4* Xs = reinterpret_cast<u32x4*>(smem_c);              // [2 buffers][2 parts][3 groups][XP]
-    u32x4* Wt = Xs + 2 * 6 * XP;
-    u32x4* Wr = Wt + CF::PIECES * 64;
-    float* Bi = reinterpret_cast<float*>(Wr + CF::RPIECES * 64);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int len = a.len, M = a.M;
-    for (int i = tid; i < CF::PIECES * 64; i += NT) Wt[i] = a.img[i];
-    for (int i = tid; i < CF::RPIECES * 64; i += NT) Wr[i] = a.rimg[i];
-    for (int i = tid; i < CF::FL; i += NT) Bi[i] = reinterpret_cast<const float*>(a.img + CF::PIECES * 64)[i];
-
-    auto scale_of = [&](int b) __attribute__((always_inline)) -> Bfp {
-        const Bfp sx = bfp_load(a.amax_x, b);
-        return CF::RESCONV ? bfp_min(sx, bfp_load(a.amax_r, b)) : sx;
-    };
-    // staging items (group, column): 768 of them, thread -> item tid and (tid < 256) item tid + 512
-    float xa[2][8];
-    auto fetch = [&](int tile) __attribute__((always_inline)) {
-        const int b = tile / a.tiles_per_utt;
-        const int px0 = (tile - b * a.tiles_per_utt) * W - DIL;
-        const float* xb = a.x + (long)b * 24 * len;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * NT;
-            const int g = (idx >> 8) > 2 ? 2 : (idx >> 8), c = idx & 255;     // idle items load a valid address
-            int p = px0 + c;
-            p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
-            const unsigned o = 4u * (unsigned)(8 * g * len + p);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xa[i][j] = ldg_so(xb + (long)j * len, o);
-        }
-    };
-    auto deposit = [&](int buf, float xs) __attribute__((always_inline)) {
-        u32x4* X = Xs + buf * 6 * XP;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * NT;
-            if (idx >= 768) continue;
-            const int g = idx >> 8, c = idx & 255;
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (CF::LRELU ? fmaxf(xa[i][j], 0.1f * xa[i][j]) : xa[i][j]) * xs;
-            uint4 p1, p2;
-            split8(v, p1, p2);
-            X[(0 + g) * XP + c] = __builtin_bit_cast(u32x4, p1);
-            X[(3 + g) * XP + c] = __builtin_bit_cast(u32x4, p2);
-        }
-    };
-
-    int tile, tend, cur = 0;                             // a contiguous range of tiles per workgroup (amax_flush_wg, conv3s.h)
-    tile_range(a.ntiles, tile, tend);
-    if (tile >= tend) return;
-    fetch(tile);
-    deposit(0, scale_of(tile / a.tiles_per_utt).s);
-    if (tile + 1 < tend) fetch(tile + 1);
-    slab_barrier();
-    const int len2 = len >> 2;
-    float mx_run = 0.f;
-    int mx_b = tile / a.tiles_per_utt;
-    for (; tile < tend; ++tile, cur ^= 1) {
-        const int b = tile / a.tiles_per_utt;
-        if (a.amax_y && b != mx_b) {
-            amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + CF::FL);
-            mx_run = 0.f;
-            mx_b = b;
-        }
-        const int t0 = (tile - b * a.tiles_per_utt) * W;
-        const int next = tile + 1, next2 = next + 1;
-        if (next < tend) deposit(cur ^ 1, scale_of(next / a.tiles_per_utt).s);            // tile i + 1 (requested one tile ago) -> the other buffer
-        if (next2 < tend) fetch(next2);               // tile i + 2 flies across this tile
-        const Bfp sx = scale_of(b);
-        const int n = wave * 32 + l31;
-        const int t = t0 + n;
-        const bool live = n < W && t < len;
-        const unsigned oo = 4u * (unsigned)(4 * lh * len + (t < len ? t : len - 1));
-        // the second input's B fragments (RESCONV), requested before the multiply
-        float xq0[8], xq1[8];
-        if (CF::RESCONV) {
-            const float* xb2 = a.res + (long)b * 24 * len;
-            const int tc = t < len ? t : len - 1;
-            const unsigned o0 = 4u * (unsigned)(8 * lh * len + tc), o1 = 4u * (unsigned)tc;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                xq0[j] = ldg_so(xb2 + (long)j * len, o0);                // K16 step 0: channels 8 lh + j
-                xq1[j] = ldg_so(xb2 + (long)(16 + j) * len, o1);         // step 1: channels 16 + j on lh = 0, the zero unit on lh = 1
-            }
-        }
-        f32x16 acc[MT], alo[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = alo[mt][r] = 0.f;
-        {   // 9 (tap, group) units in 5 K16 steps (conv24_phase), MT m-tiles sharing every B fragment
-            const u32x4* src = Xs + cur * 6 * XP;
-            constexpr int TAP0[5] = {0, 0, 1, 2, 2}, GRP0[5] = {0, 2, 1, 0, 2};
-            constexpr int TAP1[5] = {0, 1, 1, 2, 2}, GRP1[5] = {1, 0, 2, 1, 2};
-            f16x8 af[2][MT][2], bf[2][2];
-            auto frags = [&](int s, int fb) __attribute__((always_inline)) {
-                int c = n + (lh ? TAP1[s] : TAP0[s]) * DIL;
-                c = c > XW - 1 ? XW - 1 : c;
-                const int row = (lh ? GRP1[s] : GRP0[s]) * XP + c;
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    bf[fb][p] = __builtin_bit_cast(f16x8, src[p * 3 * XP + row]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) af[fb][mt][p] = __builtin_bit_cast(f16x8, Wt[((s * MT + mt) * 2 + p) * 64 + lane]);
-                }
-            };
-            frags(0, 0);
-#pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                const int fb = s & 1;
-                if (s + 1 < 5) frags(s + 1, fb ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) alo[mt] = TVC_MFMA16(af[fb][mt][1], bf[fb][0], alo[mt]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = TVC_MFMA16(af[fb][mt][0], bf[fb][0], acc[mt]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) alo[mt] = TVC_MFMA16(af[fb][mt][0], bf[fb][1], alo[mt]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (CF::RESCONV) {   // + down_res(xi): two more K16 steps on the same accumulators
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                float xq[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xq[j] = (st ? xq1[j] : xq0[j]) * sx.s;
-                uint4 p1, p2;
-                split8(xq, p1, p2);
-                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-                const bool dead = st == 1 && lh;
-                const f16x8 xf[2] = {__builtin_bit_cast(f16x8, dead ? z : p1), __builtin_bit_cast(f16x8, dead ? z : p2)};
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    f16x8 wf[2];
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) wf[p] = __builtin_bit_cast(f16x8, Wr[((st * MT + mt) * 2 + p) * 64 + lane]);
-                    alo[mt] = TVC_MFMA16(wf[1], xf[0], alo[mt]);
-                    acc[mt] = TVC_MFMA16(wf[0], xf[0], acc[mt]);
-                    alo[mt] = TVC_MFMA16(wf[0], xf[1], alo[mt]);
-                }
-            }
-        }
-        float mx = 0.f;
-        {
-            float* ob = a.out + (long)b * M * len;
-            const bool pair = a.y2 != nullptr && (t & 3) == 1 && t + 1 < len;      // 1/4-rate copy: mean of samples 4 d + 1, 4 d + 2
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float c = Bi[62 + mt] * sx.inv, cl = c * kLoInv;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (32 * mt + 8 * g >= M) continue;                            // uniform
-                    const f32x4s bv = *reinterpret_cast<const f32x4s*>(Bi + 32 * mt + 8 * g + 4 * lh);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float v = comb(acc[mt][4 * g + q], alo[mt][4 * g + q], c, cl) + bv[q];
-                        const float vn = __shfl_down(v, 1);                        // sample t + 1 (same tile: W % 4 == 0)
-                        const int m = 32 * mt + 8 * g + 4 * lh + q;
-                        if (live && m < M) {
-                            stg_so(ob + (long)(32 * mt + 8 * g + q) * len, oo, v);
-                            mx = fmaxf(mx, fabsf(v));
-                            if (pair) a.y2[((long)b * M + m) * len2 + (t >> 2)] = fmaf(0.5f, v, __fmul_rn(0.5f, vn));
-                        }
-                    }
-                }
-            }
-        }
-        mx_run = fmaxf(mx_run, mx);
-        slab_barrier();
-    }
-    if (a.amax_y) amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + CF::FL);
-}
-
-template <class CF>
-static int launch_conv24s(tvc_ctx* ctx, hipStream_t s, Conv24SArgs a, int B) {
-    static int ncu_dev[64] = {};
-    int& ncu = ncu_dev[ctx->device & 63];
-    const size_t lds = (size_t)CF::LDS_BYTES;
-    if (!ncu) {
-        hipDeviceProp_t prop;
-        hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv24s_kernel<CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv24s setup: %s", hipGetErrorString(e));
-        ncu = prop.multiProcessorCount;
-    }
-    a.tiles_per_utt = (a.len + CF::W - 1) / CF::W;
-    a.ntiles = a.tiles_per_utt * B;
-    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
-    hipLaunchKernelGGL((conv24s_kernel<CF>), dim3(grid), dim3(CF::NT), lds, s, a);
-    return launch_check(ctx, "conv24s");
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // The whole 24-channel Downsample block in ONE kernel: xi -> c1 (dil 1) -> lrelu -> c2 (dil 2) -> lrelu -> c3 (dil 4, 24 -> 48) + down_res(xi)
-// (decoder.py:143-158).  The three launches above are almost pure staging - without their MFMAs they take 75 of 85, 66 of 74 and 121 of
-// 164 us (profiles/r03_whatif.txt) - and h1 / h2 cross HBM between them (4 x 118 MB per step).  Here they stay on chip as the next conv's
+// (decoder.py:143-158).  As three launches (one conv each, until round 3) the block was almost pure staging - without their MFMAs they took
+// 75 of 85, 66 of 74 and 121 of 164 us (profiles/r03_whatif.txt) - and h1 / h2 crossed HBM between them (4 x 118 MB per step).  Here they stay on chip as the next conv's
 // split operand tiles, like the intermediate of the fused ups.4 halves: a tile is 244 output samples; c1 computes h1 on the 256 columns
 // c2's and c3's halos need (7 samples of xi beyond the tile on either side), c2 h2 on 252, c3 the 244 - one 32-column n-tile per wave and
 // conv, two barriers per tile, the next tile's input split into the second input buffer and the one after it in flight in registers
-// meanwhile (conv24s's scheme).  Same K order, same part products, same epilogue arithmetic as the three launches: for inputs inside
-// fp16's window the result is bit-identical to theirs.  The intermediates have no |max| slot (they never leave the CU): h1 is scaled by the
+// meanwhile.  Same K order, same part products, same epilogue arithmetic as the three launches had: for inputs inside fp16's window the
+// result is bit-identical to theirs (measured before they were removed).  The intermediates have no |max| slot (they never leave the CU): h1 is scaled by the
 // analytic bound (max_m sum|w1|) |xi|max + max|b1|, h2 by the bound of that bound, c3 and down_res share one scale as they share accumulators.
 struct Down24FArgs {
     const float* x;        // xi [B][24][len]
     float* out;            // [B][48][len]
     float* y2;             // optional [B][48][len / 4]: mean of samples 4 d + 1, 4 d + 2 (the next block's 1/4-rate input)
-    const u32x4* img1;     // conv24s blobs: c1 (10 pieces + 64 floats), c2, c3 (20 pieces, bias = c3 + down_res, joint scales)
+    const u32x4* img1;     // the three convs' blobs (api.hip Packer::conv24s): c1 (10 pieces + 64 floats), c2, c3 (20 pieces, bias = c3 + down_res, joint scales)
     const u32x4* img2;
     const u32x4* img3;
     const u32x4* rimg;     // down_res image (8 pieces)
@@ -1131,33 +902,6 @@ int run_down24_fused(tvc_ctx* ctx, hipStream_t s, const DownW& d, const float* x
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     hipLaunchKernelGGL(down24f_kernel, dim3(grid), dim3(D24F::NT), D24F::LDS_BYTES, s, a);
     return launch_check(ctx, "down24f");
-}
-
-// Downsample block with 24 input channels (decoder.py:143-158) after its interpolate:
-// xi [B][24][len] -> h1 -> h2 -> out [B][48][len] = c3(h2) + down_res(xi), and optionally the next block's 1/4-rate input.
-// slots: per-utterance |max| of xi (read), of h1 / h2 (scratch [B] each, zeroed) and of out (written; nullable).
-int run_down24_split(tvc_ctx* ctx, hipStream_t s, const DownW& d, const float* xi, float* h1, float* h2, float* out, float* y2, int B, int len,
-                     const float* amax_xi, float* amax_h1, float* amax_h2, float* amax_out) {
-    if (!d.s24c1 || !d.s24c2 || !d.s24c3r || !d.res.A6 || d.res.MT6 != 2 || d.res.wjoint != d.c3.A6)
-        return fail(ctx, TVC_ERR_STATE, "conv24s: the split weight blobs of the 24-channel Downsample block are missing");
-    if (d.cin != 24 || d.cout != 48) return fail(ctx, TVC_ERR_ARG, "conv24s: 24 -> 48 channels only");
-    if ((long)len * 48 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "conv24s: utterance too long for 32-bit byte offsets");
-    if (y2 && len % 4 != 0) return fail(ctx, TVC_ERR_ARG, "conv24s: the 1/4-rate copy needs len % 4 == 0");
-    Conv24SArgs a{};
-    a.len = len;
-    a.x = xi; a.out = h1; a.M = 24; a.img = reinterpret_cast<const u32x4*>(d.s24c1);
-    a.amax_x = amax_xi; a.amax_y = amax_h1;
-    TVC_CHECK((launch_conv24s<C24S<1, 1, true, false>>(ctx, s, a, B)));
-    a.x = h1; a.out = h2; a.img = reinterpret_cast<const u32x4*>(d.s24c2);
-    a.amax_x = amax_h1; a.amax_y = amax_h2;
-    TVC_CHECK((launch_conv24s<C24S<1, 2, true, false>>(ctx, s, a, B)));
-    // c3 + down_res(xi): the blob with the summed biases and the joint scales, the 1x1's image, xi as the second input
-    a.x = h2; a.out = out; a.y2 = y2; a.M = 48;
-    a.amax_x = amax_h2; a.amax_r = amax_xi; a.amax_y = amax_out;
-    a.img = reinterpret_cast<const u32x4*>(d.s24c3r);
-    a.rimg = reinterpret_cast<const u32x4*>(d.res.A6);
-    a.res = xi;
-    return launch_conv24s<C24S<2, 4, true, true>>(ctx, s, a, B);
 }
 
 }  // namespace tvc

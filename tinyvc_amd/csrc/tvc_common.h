@@ -54,7 +54,7 @@ struct ConvNeXtW {
 struct DownW {
     PackedW res, c1, c2, c3;             // c3 and res share their per-m-tile scales (accumulated into one tile)
     const float* c3res_bias = nullptr;   // c3.bias + down_res.bias [c3.Mpad]: c3 launches that fold the residual 1x1 in as a second K phase
-    const float* s24c1 = nullptr;   // cin == 24: weight blobs of conv24s_kernel (filter_up24s.hip)
+    const float* s24c1 = nullptr;   // cin == 24: weight blobs of down24f_kernel (filter_up24s.hip)
     const float* s24c2 = nullptr;
     const float* s24c3r = nullptr;   // c3's blob with c3.bias + down_res.bias and the joint scales (the launch folds the residual 1x1 in)
     float b1_w = 0.f, b1_b = 0.f, b2_w = 0.f, b2_b = 0.f;   // cin == 24: |c1 out| <= b1_w |xi|max + b1_b, |c2 out| <= b2_w |c1 out| + b2_b (down24f_kernel's on-chip intermediates)
@@ -268,8 +268,6 @@ int run_up24_split(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const fl
 int run_down0_split(tvc_ctx*, hipStream_t, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len,
                     const float* amax_x, float* amax_y);
 int run_down24_fused(tvc_ctx*, hipStream_t, const DownW& d, const float* xi, float* out, float* y2, int B, int len, const float* amax_xi, float* amax_out);
-int run_down24_split(tvc_ctx*, hipStream_t, const DownW& d, const float* xi, float* h1, float* h2, float* out, float* y2, int B, int len,
-                     const float* amax_xi, float* amax_h1, float* amax_h2, float* amax_out);
 int run_conv48s(tvc_ctx*, hipStream_t, const PackedW& w, const float* x, int lin, float lscale, const PackedW* film, const float* bsc, const float* bsh,
                 const float* cond, const float* res, int rlin, float rscale, float* out, int B, int len, int dil, const float* amax_x, const float* amax_c,
                 float* amax_y, const PackedW* c5 = nullptr, float* out5 = nullptr);
