@@ -348,8 +348,8 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
         const int len = (int)len_dn[i];
         size_t mk = ws.mark();
         float* xi = xi_pre[i];
-        float* h1 = ws.get<float>((size_t)B * d.cin * len);
-        float* h2 = ws.get<float>((size_t)B * d.cin * len);
+        float* h1 = d.cin == 24 ? nullptr : ws.get<float>((size_t)B * d.cin * len);      // (the 24-channel block keeps its intermediates on chip)
+        float* h2 = d.cin == 24 ? nullptr : ws.get<float>((size_t)B * d.cin * len);
         if (!dry) {
             static const char* names[4] = {"filter.down1", "filter.down2", "filter.down3", "filter.down4"};
             ProfScope ps(ctx, s, dry, names[i - 1]);
