@@ -311,7 +311,7 @@ def main():
             pick = mfma if bound == "mfma" else {"achieved": hbm["moved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved}
             roof = {"bound": bound, "achieved": pick["achieved"], "peak": pick["peak"], "unit": pick["unit"], "frac": pick["frac"],
                     "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "FilterNet Conv1d stack = the filter_net launches of one step (two-term fp16 split on v_mfma_f32_32x32x16_f16, three part-products per fp32 product: fused ups.4+output kernels, film_s2 / conv_s2 / conv3s for the 96..384-channel levels, conv48s / conv48p for the 48-channel one, conv24s / down0s for the 24-channel ones), hipEvent pair on the launch stream",
+                    "kernel": "FilterNet Conv1d stack = the filter_net launches of one step (two-term fp16 split on v_mfma_f32_32x32x16_f16, three part-products per fp32 product: fused ups.4+output kernels, film_s2 / conv_s2 / conv3s for the 96..384-channel levels, conv48s / conv48p for the 48-channel one, down24f / down0s for the 24-channel ones), hipEvent pair on the launch stream",
                     "launch_ms": t_filter * 1e3,
                     "hbm_layer_boundary_frac": hbm["frac"], "hbm_moved_frac": moved, "mfma_f16_frac": mfma["frac"],
                     "hbm": hbm, "mfma": mfma,
