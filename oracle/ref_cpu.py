@@ -30,6 +30,12 @@ FILTER_FACTORS = (2, 3, 4, 4, 5)
 SSL_DILATIONS = (1, 3, 9, 1, 1, 1)
 
 
+def _fp(x):
+    """fp32 like the reference - except that an fp64 tensor stays fp64: evaluating this file on `.double()` weights and inputs
+    gives the path's fp64 value, the fixed truth tests/test_gpu_truth.py measures both fp32 implementations against."""
+    return x if x.dtype == torch.float64 else x.float()
+
+
 # --------------------------------------------------------------------------- front end (a1-a3)
 def autopad_waveform(wf, frame=HOP):
     """reference module/utils/auto_padding.py:5-11 — zero-extend the tail to a multiple of 480."""
@@ -42,8 +48,9 @@ def autopad_waveform(wf, frame=HOP):
 def spectrogram(wf):
     """reference module/utils/spectrogram.py:8-15 — |STFT| (n_fft 1920, hop 480, periodic Hann,
     centre/reflect), first frame dropped -> [B, 961, L/480]."""
-    win = torch.hann_window(N_FFT)
-    s = torch.stft(wf.float(), N_FFT, HOP, window=win, return_complex=True).abs()
+    wf = _fp(wf)
+    win = torch.hann_window(N_FFT, dtype=wf.dtype)
+    s = torch.stft(wf, N_FFT, HOP, window=win, return_complex=True).abs()
     return s[:, :, 1:]
 
 
@@ -108,7 +115,7 @@ def pitch_decode(logits, k=4, fmin=20.0, cpo=48):
     the class frequencies 20*2^(id/48) (classes at or below 20 Hz count as 0); f0 <= 20 -> 0."""
     top, ids = torch.topk(logits, k, dim=1)
     p = F.softmax(top, dim=1)
-    fr = fmin * (2 ** (ids.to(torch.float) / cpo))
+    fr = fmin * (2 ** (ids.to(logits.dtype) / cpo))
     fr = torch.where(fr <= fmin, torch.zeros_like(fr), fr)
     f0 = (p * fr).sum(dim=1, keepdim=True)
     return torch.where(f0 <= fmin, torch.zeros_like(f0), f0)
@@ -170,7 +177,7 @@ def oscillate_harmonics(f0, num_harmonics=NUM_HARMONICS, fmin=20.0):
     L = T * HOP
     mul = (torch.arange(num_harmonics + 1) + 1).view(1, -1, 1)
     fs = F.interpolate(f0, L, mode="linear") * mul
-    uv = F.interpolate((f0 > fmin).to(torch.float), L, mode="linear")
+    uv = F.interpolate((f0 > fmin).to(f0.dtype), L, mode="linear")
     cyc = torch.cumsum(fs / SAMPLE_RATE, dim=2)
     return torch.sin(2 * math.pi * (cyc % 1)) * uv
 
@@ -178,7 +185,7 @@ def oscillate_harmonics(f0, num_harmonics=NUM_HARMONICS, fmin=20.0):
 def oscillate_noise(kernel, angle):
     """reference module/tinyvc/decoder.py:63-85 with the uniform phase draw made an argument:
     `angle` is what `torch.rand(N, 961, T) * 2*pi - pi` returns there (decoder.py:78)."""
-    y = torch.exp(1j * angle) * kernel.float()
+    y = torch.exp(1j * angle) * _fp(kernel)
     y = F.pad(y, [1, 0])
     return torch.istft(y, N_FFT, HOP).unsqueeze(1)
 

@@ -249,4 +249,6 @@ def test_ten_seconds_against_the_host_cpu_spread(models):
     _log(f"[headline] T=500: GPU vs CPU({n} threads) {d:.3e}; CPU 1 thread vs {n} threads {spread:.3e}; ratio {d / spread:.2f}; "
          f"decoder on the oracle's inputs {dec_only:.3e}")
     assert dec_only <= 1e-6
-    assert d <= max(2.5e-4, 3 * spread)
+    # end to end: logged only - the claim that does not depend on this host's thread count is test_gpu_truth.py (GPU and reference
+    # arithmetic both measured against the fp64 evaluation of the path); here only that nothing discrete went wrong
+    assert d <= 1e-3
