@@ -59,6 +59,65 @@ def test_ragged_batch_equals_one_call_per_utterance_and_the_oracle(gen):
         assert torch.equal(out2[b], out[b])
 
 
+def test_long_utterances_run_as_one_ragged_batch_inside_the_kernels(gen):
+    """Utterances of >= 128 frames (2.56 s) share every kernel launch (csrc/ragged.h): per-utterance lengths inside the kernels.  Seven
+    different lengths - odd and even frame counts, one not padded to a frame, a duplicate - mixed with two short ones that take the
+    grouped path in the same call.  Contract unchanged: every utterance equals its own B = 1 call bit for bit."""
+    enc_sd, dec_sd = state_dicts(0)
+    frames = [200, 131, 256, 17, 145, 128, 200, 9, 173]
+    lens = [480 * f - (23 if i % 3 == 1 else 0) for i, f in enumerate(frames)]
+    B, Lmax, Tmax = len(frames), 480 * max(frames), max(frames)
+    wf = torch.zeros(B, Lmax)
+    for b, n in enumerate(lens):
+        wf[b, :n] = synth.synth_wave(1, n, seed=700 + b)[0]
+    tgt = synth.synth_index(5003, seed=8)              # the two-stage search (N >= 4096)
+    angle = synth.synth_angle(B, Tmax, 33)
+    out = gen.convert(wf.to(DEV), tgt.to(DEV), 0.75, noise_angle=angle.to(DEV), lengths=lens)
+    assert out.shape == (B, Lmax) and torch.isfinite(out).all()
+    bad = []
+    for b, f in enumerate(frames):
+        L = 480 * f
+        one = gen.convert(wf[b:b + 1, :lens[b]].to(DEV), tgt.to(DEV), 0.75, noise_angle=angle[b:b + 1, :, :f].contiguous().to(DEV))
+        if not torch.equal(out[b, :L], one[0]):
+            bad.append((b, f, rms(out[b, :L].cpu() - one[0].cpu())))
+        assert not out[b, L:].any(), "the tail of a row is zero-filled"
+    assert not bad, f"ragged batch != B = 1 call for (utterance, frames, rms): {bad}"
+    with oracle_one_thread():
+        ref = R.convert(enc_sd, dec_sd, wf[2:3, :lens[2]], tgt, 0.75, angle[2:3, :, :frames[2]])
+    d = rms(out[2, :480 * frames[2]].cpu() - ref[0])
+    print(f"[ragged] in-kernel batch of {sorted(f for f in frames if f >= 128)} frames: bit-identical to the B = 1 calls; 256-frame utterance vs the oracle {d:.3e}")
+    assert d <= 1e-4
+    # the library's own phase draw (noise_angle = None) and a second call on the same engine
+    o2 = gen.convert(wf.to(DEV), tgt.to(DEV), 0.75, lengths=lens)
+    assert torch.isfinite(o2).all() and not o2[1, 480 * frames[1]:].any()
+
+
+def test_sixty_four_distinct_lengths_are_one_batch(gen):
+    """The bench's ragged64 workload: 64 utterances of 64 different lengths (150 ... 250 frames).  Rows 0, 31 and 63 against their
+    B = 1 calls; the whole call must not be slower than a few equal-length steps (it used to be 64 sequential B = 1 conversions)."""
+    import time
+    frames = [150 + (i * 100) // 63 for i in range(64)]
+    lens = [480 * f for f in frames]
+    wf = synth.synth_wave(64, max(lens), seed=100)
+    for b, n in enumerate(lens):
+        wf[b, n:] = 0
+    wf = wf.to(DEV)
+    tgt = synth.synth_index(10000, seed=8).to(DEV)
+    angle = synth.synth_angle(64, max(frames), 5).to(DEV)
+    out = gen.convert(wf, tgt, 0.0, noise_angle=angle, lengths=lens)
+    for b in (0, 31, 63):
+        one = gen.convert(wf[b:b + 1, :lens[b]], tgt, 0.0, noise_angle=angle[b:b + 1, :, :frames[b]].contiguous())
+        assert torch.equal(out[b, :lens[b]], one[0]), f"utterance {b}"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        gen.convert(wf, tgt, 0.0, noise_angle=angle, lengths=lens)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    print(f"[ragged] 64 distinct lengths: {ms:.2f} ms per call")
+    assert ms < 20.0
+
+
 def test_ragged_arguments_are_validated(gen):
     from tinyvc_amd._lib import TinyVCError
     tgt = synth.synth_index(64, seed=1).to(DEV)

@@ -1005,14 +1005,48 @@ struct RaggedGroup {
     std::vector<int> rows;
     int lane;
 };
-// equal-length groups, longest first, dealt to the lane with the least work so far
-int ragged_plan(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, std::vector<RaggedGroup>* groups) {
-    std::map<int64_t, std::vector<int>, std::greater<int64_t>> by_len;
+// Utterances of at least kRagMinFrames frames (2.56 s) are converted as ragged batches INSIDE the kernels (ragged.h): every level of
+// FilterNet is then at least one 256-column tile long, which is what selects the kernels a conversion runs (film_s2 / conv_s2 against
+// conv3s's narrow tiles, decoder.hip film_conv) - so every utterance of the batch takes exactly the path its own B = 1 call takes and
+// the result is bit-identical to it.  Shorter ones keep the host-side plan: equal-length groups as ordinary batches on the lanes.
+constexpr int kRagMinFrames = 128;
+constexpr int kRagMaxFrames = 80000;       // frames per in-kernel batch: 24 rows x 480 x 4 B x frames stays below the 32-bit byte offsets of the 24-channel kernels
+struct RagBatchPlan {
+    std::vector<int> rows, frames;
+    int Ttot = 0;
+};
+int ragged_split(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, std::vector<RagBatchPlan>* batches, std::vector<int>* short_rows) {
     for (int b = 0; b < B; ++b) {
         if (lens[b] <= 0 || lens[b] % kHop || lens[b] > Lmax || lens[b] < kNfft / 2 + 1)
             return fail(ctx, TVC_ERR_ARG, "ragged batch: lens[%d] = %lld must be a multiple of 480 in (960, Lmax]", b, (long long)lens[b]);
-        by_len[lens[b]].push_back(b);
+        const int T = (int)(lens[b] / kHop);
+        if (T < kRagMinFrames) {
+            short_rows->push_back(b);
+            continue;
+        }
+        if (T > kRagMaxFrames) return fail(ctx, TVC_ERR_ARG, "ragged batch: lens[%d] = %lld is longer than a batch may be; convert it with tvc_convert_f32", b, (long long)lens[b]);
+        if (batches->empty() || batches->back().Ttot + T > kRagMaxFrames) batches->emplace_back();
+        batches->back().rows.push_back(b);
+        batches->back().frames.push_back(T);
+        batches->back().Ttot += T;
     }
+    return 0;
+}
+// one in-kernel ragged batch: [tables][convert workspace]; the drivers run it as ONE utterance of Ttot frames (B = 1) with ctx->rag set
+int ragged_batch(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const RagBatchPlan& p, const float* wav, int64_t Lmax, const float* prepared, int64_t N,
+                 float pitch_shift, const float* angle, uint64_t seed, float* wave) {
+    int* scratch = ws.get<int>(rag_scratch_ints((int)p.rows.size(), p.Ttot));
+    RagHost h;
+    TVC_CHECK(rag_setup(ctx, s, dry, h, p.frames, p.rows, (int)(Lmax / kHop), scratch));
+    ctx->rag = &h;
+    const int rc = convert_impl(ctx, s, ws, dry, wav, prepared, N, pitch_shift, angle, seed + (uint64_t)p.rows[0] * 0x9E3779B97F4A7C15ull, wave, 1, (int64_t)p.Ttot * kHop);
+    ctx->rag = nullptr;
+    return rc;
+}
+// equal-length groups of the SHORT utterances, longest first, dealt to the lane with the least work so far
+int ragged_plan(tvc_ctx* ctx, const std::vector<int>& rows, const int64_t* lens, std::vector<RaggedGroup>* groups) {
+    std::map<int64_t, std::vector<int>, std::greater<int64_t>> by_len;
+    for (int b : rows) by_len[lens[b]].push_back(b);
     double load[kLanes] = {0, 0, 0, 0};
     for (auto& kv : by_len) {
         int best = 0;
@@ -1054,20 +1088,47 @@ int ragged_group(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const RaggedGrou
         for (int i = 0; i < Bg; ++i) {
             const int b = g.rows[i];
             if (Bg > 1) TVC_HIP(ctx, hipMemcpyAsync(wave + (size_t)b * Lmax, go + (size_t)i * L, (size_t)L * sizeof(float), hipMemcpyDeviceToDevice, s));
-            if (L < Lmax) TVC_HIP(ctx, hipMemsetAsync(wave + (size_t)b * Lmax + L, 0, (size_t)(Lmax - L) * sizeof(float), s));
         }
     }
     return 0;
 }
-// lanes' workspace regions: lane l starts at off[l]; every group of a lane reuses its region from the start
-int ragged_sizes(tvc_ctx* ctx, const std::vector<RaggedGroup>& groups, int64_t Lmax, int64_t N, bool with_angle, size_t* lane_bytes) {
+// lanes' workspace regions: lane l starts at off[l]; every group of a lane reuses its region from the start.  Sized for a call with AND
+// without caller-supplied noise phases (the library's own draw needs a buffer the injected phases do not).
+int ragged_sizes(tvc_ctx* ctx, const std::vector<RaggedGroup>& groups, int64_t Lmax, int64_t N, size_t* lane_bytes) {
     for (int l = 0; l < kLanes; ++l) lane_bytes[l] = 0;
-    for (auto& g : groups) {
-        Ws ws(nullptr, 0, true);
-        TVC_CHECK(ragged_group(ctx, nullptr, ws, true, g, nullptr, Lmax, nullptr, N, 0.f, with_angle ? (const float*)256 : nullptr, 0, nullptr));
-        const size_t need = (ws.peak + 4095) & ~size_t(4095);
-        if (need > lane_bytes[g.lane]) lane_bytes[g.lane] = need;
-    }
+    for (auto& g : groups)
+        for (int with_angle = 0; with_angle < 2; ++with_angle) {
+            Ws ws(nullptr, 0, true);
+            TVC_CHECK(ragged_group(ctx, nullptr, ws, true, g, nullptr, Lmax, nullptr, N, 0.f, with_angle ? (const float*)256 : nullptr, 0, nullptr));
+            const size_t need = (ws.peak + 4095) & ~size_t(4095);
+            if (need > lane_bytes[g.lane]) lane_bytes[g.lane] = need;
+        }
+    return 0;
+}
+// the in-kernel batches run one after the other on the caller's stream and share one region
+int ragged_batch_bytes(tvc_ctx* ctx, const std::vector<RagBatchPlan>& batches, int64_t Lmax, int64_t N, size_t* bytes) {
+    *bytes = 0;
+    for (auto& p : batches)
+        for (int with_angle = 0; with_angle < 2; ++with_angle) {
+            Ws ws(nullptr, 0, true);
+            TVC_CHECK(ragged_batch(ctx, nullptr, ws, true, p, nullptr, Lmax, nullptr, N, 0.f, with_angle ? (const float*)256 : nullptr, 0, nullptr));
+            const size_t need = (ws.peak + 4095) & ~size_t(4095);
+            if (need > *bytes) *bytes = need;
+        }
+    return 0;
+}
+struct RaggedCall {
+    std::vector<RagBatchPlan> batches;
+    std::vector<RaggedGroup> groups;
+    size_t batch_bytes = 0, lb[kLanes] = {0, 0, 0, 0};
+    size_t total() const { return batch_bytes + lb[0] + lb[1] + lb[2] + lb[3] + 4096; }
+};
+int ragged_call_plan(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, int64_t N, RaggedCall* c) {
+    std::vector<int> short_rows;
+    TVC_CHECK(ragged_split(ctx, B, Lmax, lens, &c->batches, &short_rows));
+    TVC_CHECK(ragged_plan(ctx, short_rows, lens, &c->groups));
+    TVC_CHECK(ragged_batch_bytes(ctx, c->batches, Lmax, N, &c->batch_bytes));
+    TVC_CHECK(ragged_sizes(ctx, c->groups, Lmax, N, c->lb));
     return 0;
 }
 }  // namespace
@@ -1075,11 +1136,9 @@ int ragged_sizes(tvc_ctx* ctx, const std::vector<RaggedGroup>& groups, int64_t L
 int tvc_workspace_bytes_ragged(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, int64_t N, size_t* out_bytes) {
     TVC_CHECK(need_ready(ctx, NEED_NONE));
     if (!out_bytes || !lens || B <= 0 || Lmax <= 0 || Lmax % kHop != 0 || N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_workspace_bytes_ragged: need B>0, Lmax%%480==0, N>=4");
-    std::vector<RaggedGroup> groups;
-    TVC_CHECK(ragged_plan(ctx, B, Lmax, lens, &groups));
-    size_t lb[kLanes];
-    TVC_CHECK(ragged_sizes(ctx, groups, Lmax, N, true, lb));
-    *out_bytes = lb[0] + lb[1] + lb[2] + lb[3] + 4096;
+    RaggedCall c;
+    TVC_CHECK(ragged_call_plan(ctx, B, Lmax, lens, N, &c));
+    *out_bytes = c.total();
     return TVC_OK;
 }
 
@@ -1091,48 +1150,66 @@ int tvc_convert_ragged_f32(tvc_ctx* ctx, void* stream, const float* wav, int64_t
     TVC_CHECK(blob_check(ctx, prepared, N, "tvc_convert_ragged_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    std::vector<RaggedGroup> groups;
-    TVC_CHECK(ragged_plan(ctx, B, Lmax, lens, &groups));
-    size_t lb[kLanes];
-    TVC_CHECK(ragged_sizes(ctx, groups, Lmax, N, noise_angle != nullptr, lb));
-    if (lb[0] + lb[1] + lb[2] + lb[3] > ws_bytes)
-        return fail(ctx, TVC_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", lb[0] + lb[1] + lb[2] + lb[3], ws_bytes);
-    if (ctx->lanes.empty()) {      // created on first use (not inside a stream capture)
-        ctx->lanes.resize(kLanes);
-        for (auto& ln : ctx->lanes) {
-            TVC_HIP(ctx, hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));
-            TVC_HIP(ctx, hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
-            TVC_HIP(ctx, hipEventCreateWithFlags(&ln.fork, hipEventDisableTiming));
-            TVC_HIP(ctx, hipEventCreateWithFlags(&ln.join, hipEventDisableTiming));
-            TVC_HIP(ctx, hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    RaggedCall c;
+    TVC_CHECK(ragged_call_plan(ctx, B, Lmax, lens, N, &c));
+    if (c.total() - 4096 > ws_bytes) return fail(ctx, TVC_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", c.total() - 4096, ws_bytes);
+    if (!c.groups.empty() && ctx->lanes.empty()) {      // created on first use (not inside a stream capture); published only when complete
+        std::vector<tvc_ctx::Lane> lanes(kLanes);
+        hipEvent_t ev = nullptr;
+        bool ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        for (auto& ln : lanes)
+            ok = ok && hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&ln.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ln.join, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            for (auto& ln : lanes) {
+                if (ln.s) (void)hipStreamDestroy(ln.s);
+                if (ln.side) (void)hipStreamDestroy(ln.side);
+                if (ln.fork) (void)hipEventDestroy(ln.fork);
+                if (ln.join) (void)hipEventDestroy(ln.join);
+                if (ln.done) (void)hipEventDestroy(ln.done);
+            }
+            if (ev) (void)hipEventDestroy(ev);
+            return fail(ctx, TVC_ERR_HIP, "ragged batch: could not create the lanes' streams / events");
         }
-        TVC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ragged, hipEventDisableTiming));
+        ctx->lanes.swap(lanes);
+        ctx->ev_ragged = ev;
     }
-    // fork: every lane that has work starts behind what is already queued on the caller's stream
-    TVC_HIP(ctx, hipEventRecord(ctx->ev_ragged, s));
-    bool used[kLanes] = {false, false, false, false};
-    size_t off[kLanes];
-    off[0] = 0;
-    for (int l = 1; l < kLanes; ++l) off[l] = off[l - 1] + lb[l - 1];
-    hipStream_t side0 = ctx->side;
-    hipEvent_t fork0 = ctx->ev_fork, join0 = ctx->ev_join;
+    // the whole padded output is cleared once: every kernel writes its utterance's own samples only
+    TVC_HIP(ctx, hipMemsetAsync(wave, 0, (size_t)B * Lmax * sizeof(float), s));
     int rc = 0;
-    for (auto& g : groups) {
-        tvc_ctx::Lane& ln = ctx->lanes[g.lane];
-        if (!used[g.lane]) {
-            if (hipStreamWaitEvent(ln.s, ctx->ev_ragged, 0) != hipSuccess) { rc = fail(ctx, TVC_ERR_HIP, "ragged: stream wait"); break; }
-            used[g.lane] = true;
+    bool used[kLanes] = {false, false, false, false};
+    if (!c.groups.empty()) {
+        // fork: every lane that has work starts behind what is already queued on the caller's stream
+        TVC_HIP(ctx, hipEventRecord(ctx->ev_ragged, s));
+        size_t off[kLanes];
+        off[0] = c.batch_bytes;
+        for (int l = 1; l < kLanes; ++l) off[l] = off[l - 1] + c.lb[l - 1];
+        hipStream_t side0 = ctx->side;
+        hipEvent_t fork0 = ctx->ev_fork, join0 = ctx->ev_join;
+        for (auto& g : c.groups) {
+            tvc_ctx::Lane& ln = ctx->lanes[g.lane];
+            if (!used[g.lane]) {
+                if (hipStreamWaitEvent(ln.s, ctx->ev_ragged, 0) != hipSuccess) { rc = fail(ctx, TVC_ERR_HIP, "ragged: stream wait"); break; }
+                used[g.lane] = true;
+            }
+            ctx->side = ln.side;             // the pitch branch of this group forks onto the lane's own side stream
+            ctx->ev_fork = ln.fork;
+            ctx->ev_join = ln.join;
+            Ws ws((char*)wsp + off[g.lane], c.lb[g.lane], false);
+            rc = ragged_group(ctx, ln.s, ws, false, g, wav, Lmax, prepared, N, pitch_shift, noise_angle, seed, wave);
+            if (rc) break;
         }
-        ctx->side = ln.side;             // the pitch branch of this group forks onto the lane's own side stream
-        ctx->ev_fork = ln.fork;
-        ctx->ev_join = ln.join;
-        Ws ws((char*)wsp + off[g.lane], lb[g.lane], false);
-        rc = ragged_group(ctx, ln.s, ws, false, g, wav, Lmax, prepared, N, pitch_shift, noise_angle, seed, wave);
-        if (rc) break;
+        ctx->side = side0;
+        ctx->ev_fork = fork0;
+        ctx->ev_join = join0;
     }
-    ctx->side = side0;
-    ctx->ev_fork = fork0;
-    ctx->ev_join = join0;
+    // the in-kernel batches, one after the other on the caller's stream (beside the lanes)
+    for (auto& p : c.batches) {
+        if (rc) break;
+        Ws ws(wsp, c.batch_bytes, false);
+        rc = ragged_batch(ctx, s, ws, false, p, wav, Lmax, prepared, N, pitch_shift, noise_angle, seed, wave);
+    }
     // join (also on an error path: the caller's stream must not run ahead of what was queued)
     for (int l = 0; l < kLanes; ++l)
         if (used[l]) {

@@ -119,6 +119,7 @@ struct ConvSArgs {
     const float* amax_x = nullptr;
     const float* amax_c = nullptr;
     float* amax_y = nullptr;
+    RagDev rag;          // ragged batch (ragged.h, RAG kernels): `len` is the row stride of every tensor, the tile walk and the valid extents come from here
 };
 
 // power-of-two input scale from a tensor's per-utterance |max|: identity while amax is inside [2^-10, 2^15), else 2^-floor(log2 amax)
@@ -273,7 +274,10 @@ struct SlabMap {
 // utterance b starts at element b * fstride, channels are fT apart; a tile may straddle utterances.
 template <class TL, bool LERP = false>
 __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t0, int fT = 0, unsigned fstride = 0, int kcin = 0, int lin = 0,
-                                         float lscale = 0.f, float xs = 1.f, const float* amax = nullptr) {
+                                         float lscale = 0.f, float xs = 1.f, const float* amax = nullptr, int rs_ = 0, const int* __restrict__ c2b = nullptr, int cmult = 1) {
+    // ragged batches (ragged.h): rs_ = row stride of the tensor when it is not `len` (len = the tile's utterance, xb points at its first column);
+    // c2b = frame -> utterance for GEMM tiles over the whole batch (the per-utterance scale is then the column's, as on flat tiles)
+    const int rs = rs_ ? rs_ : len;
     const int xw = TL::BN + 2 * dil;
 #pragma unroll
     for (int i = 0; i < TL::X_PER; ++i) {
@@ -302,17 +306,18 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
             m.w1[i] = lc.w1;
             m.xk[i] = 0;
         } else {
-            m.xo[i] = (unsigned)(m.xg8[i] * len + p);
+            m.xo[i] = (unsigned)(m.xg8[i] * rs + p);
             m.xk[i] = 0;
+            if (c2b) m.xs[i] = bfp_load(amax, c2b[p / cmult]).s;
         }
     }
 }
 // global -> registers only (no use of the values here: the loads stay in flight behind the MFMAs)
 template <class TL, int TAPS, bool LERP = false, bool CLAMP = false>
 __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ A6, int MT, int mt0,
-                                          const float* __restrict__ xb, int Cin, int len, int s, int fT = 0, int cmax = 0, int lin = 0) {
+                                          const float* __restrict__ xb, int Cin, int len, int s, int fT = 0, int cmax = 0, int lin = 0, int rs_ = 0) {
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER, STEPS = TAPS * TL::KG;
-    const int cs = LERP ? lin : (fT > 0 ? fT : len);     // channel stride
+    const int cs = LERP ? lin : (fT > 0 ? fT : (rs_ ? rs_ : len));     // channel stride
     constexpr int PIECES = STEPS * MTB * kParts, A_PER = (PIECES + NW - 1) / NW;
     static_assert(A_PER <= SlabRegs<TL>::A_MAX, "weight pieces must fit the staging registers");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -359,10 +364,10 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
 template <class TL, int TAPS, bool LERP = false, bool CLAMP = false>
 __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0, const float* __restrict__ xb,
                                            int Cin, int len, int dil, int t0, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0,
-                                           float lscale = 0.f) {
+                                           float lscale = 0.f, int rs_ = 0) {
     SlabMap<TL> m;
-    make_map<TL, LERP>(m, len, dil, t0, fT, fstride, 0, lin, lscale);
-    slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT, cmax, lin);
+    make_map<TL, LERP>(m, len, dil, t0, fT, fstride, 0, lin, lscale, 1.f, nullptr, rs_);
+    slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT, cmax, lin, rs_);
 }
 
 // (hi, lo) += W (.) x over all slabs of one input tensor (hi: the h1 w1 products, lo: h1 w2 + h2 w1 in units of 2^-11).
@@ -376,13 +381,13 @@ template <class TL, int TAPS, int A_U4, bool LRELU, int FB, bool SCALED = false,
 __device__ __forceinline__ void split_phase(f32x16 (&hi)[TL::WM][TL::WN], f32x16 (&lo)[TL::WM][TL::WN], SlabRegs<TL>& r, const uint4* __restrict__ A6, int MT, int mt0,
                                             const float* __restrict__ xb, int Cin, int len, int dil, int t0, uint4* As, uint4* Xs, Next next, float xs,
                                             const float* Ks = nullptr, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0, float lscale = 0.f,
-                                            int mt0b = 0, Mid mid = Mid(), const float* amax = nullptr) {
+                                            int mt0b = 0, Mid mid = Mid(), const float* amax = nullptr, int rs_ = 0, const int* __restrict__ c2b = nullptr, int cmult = 1) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NWV, wn = wave - wm * NWV;
     SlabMap<TL> m;
-    make_map<TL, LERP>(m, len, dil, t0, fT, fstride, Cin, lin, lscale, xs, amax);
+    make_map<TL, LERP>(m, len, dil, t0, fT, fstride, Cin, lin, lscale, xs, amax, rs_, c2b, cmult);
     constexpr int STEPS = TAPS * TL::KG;               // K16 steps per slab: (channel group, tap)
     constexpr int PIECES = STEPS * MTB * kParts, A_PER = (PIECES + NW - 1) / NW;
     auto lstore = [&](int sl) __attribute__((always_inline)) {
@@ -431,8 +436,8 @@ __device__ __forceinline__ void split_phase(f32x16 (&hi)[TL::WM][TL::WN], f32x16
         lstore(TWO && s >= nslab1 ? s - nslab1 : s);   // slab s: registers -> LDS
         TR_STAMP(r, 2);
         if (s + 1 < nslab) {                       // flies across this slab's MFMAs
-            if (TWO) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, s + 1 >= nslab1 ? mt0b : mt0, xb, Cin, len, s + 1 >= nslab1 ? s + 1 - nslab1 : s + 1, fT, cmax, lin);
-            else slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin);
+            if (TWO) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, s + 1 >= nslab1 ? mt0b : mt0, xb, Cin, len, s + 1 >= nslab1 ? s + 1 - nslab1 : s + 1, fT, cmax, lin, rs_);
+            else slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin, rs_);
         } else next();
         TR_STAMP(r, 3);
         slab_barrier();
@@ -589,7 +594,10 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
 // by the kernel when the workgroup leaves the utterance.
 template <class TL, bool RES>
 __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][TL::WN], float* __restrict__ y, const float* __restrict__ res,
-                                           int b, int M, int len, int mt0, int t0, float& mx, float* __restrict__ y2 = nullptr, int f2 = 0, int rlin = 0, float rscale = 0.f) {
+                                           int b, int M, int len, int mt0, int t0, float& mx, float* __restrict__ y2 = nullptr, int f2 = 0, int rlin = 0, float rscale = 0.f,
+                                           int rs_ = 0, int coloff = 0) {
+    // ragged batches (ragged.h): rs_ = the tensors' row stride, coloff = first column of the tile's utterance (b = 0 then), len = its length
+    const int rs = rs_ ? rs_ : len;
     constexpr int WM = TL::WM, WN = TL::WN, BM = TL::BM, BN = TL::BN, OS = TL::OS, NTHR = TL::NTHR;
     // The thread index is laundered through an empty asm: everything below depends on it only, so the compiler would hoist
     // all of the store pass's index math (64-bit offsets included) out of the persistent tile loop and keep ~25 registers
@@ -611,14 +619,14 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
         slab_barrier();
     };
     __builtin_amdgcn_sched_barrier(0);                         // nothing of the store pass moves up into the FiLM combine (three accumulator sets live there)
-    float* yb = y + ((long)b * M + mt0 * 32) * len + t0;      // offsets inside the tile's rows fit 32 bits
+    float* yb = y + ((long)b * M + mt0 * 32) * rs + coloff + t0;      // offsets inside the tile's rows fit 32 bits
     // rlin > 0: the residual is F.interpolate(res_low) of a [B][M][rlin] tensor, evaluated here instead of read back
-    const float* rb = RES ? (rlin > 0 ? res + ((long)b * M + mt0 * 32) * rlin : res + ((long)b * M + mt0 * 32) * len + t0) : nullptr;
+    const float* rb = RES ? (rlin > 0 ? res + ((long)b * M + mt0 * 32) * rlin : res + ((long)b * M + mt0 * 32) * rs + coloff + t0) : nullptr;
     const int rows = M - mt0 * 32 < BM ? M - mt0 * 32 : BM;
-    const bool vec = (len & 3) == 0;                        // rows start 16-byte aligned (t0 is a multiple of 32)
+    const bool vec = ((rs | coloff) & 3) == 0;              // rows start 16-byte aligned (t0 is a multiple of 32)
     // optional 1/f2-rate copy for the next Downsample block (see C3EpiBias): pick for f2 = 3 / 5, two-sample mean for f2 = 4
-    const int len2 = f2 > 0 ? len / f2 : 0;
-    float* y2b = y2 ? y2 + ((long)b * M + mt0 * 32) * len2 : nullptr;
+    const int len2 = f2 > 0 ? rs / f2 : 0;                  // (row stride of the decimated copy)
+    float* y2b = y2 ? y2 + ((long)b * M + mt0 * 32) * len2 + (f2 > 0 ? coloff / f2 : 0) : nullptr;
     if constexpr (RES) {
         if (rlin > 0) {
             // a thread's four columns are the same for every row it visits: the interpolation coordinates are computed once
@@ -673,7 +681,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
                     if (row >= rows) break;
                     const float4 o = *reinterpret_cast<const float4*>(Ot + row * OS + c);
                     const float e[4] = {o.x + w[k][0], o.y + w[k][1], o.z + w[k][2], o.w + w[k][3]};
-                    const int off = row * len + c;
+                    const int off = row * rs + c;
                     if (full) {
                         *reinterpret_cast<float4*>(yb + off) = make_float4(e[0], e[1], e[2], e[3]);
                         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(e[0]), fabsf(e[1]))), fmaxf(fabsf(e[2]), fabsf(e[3])));
@@ -700,7 +708,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
             for (int k = 0; k < NR; ++k) {
                 int row = tid / G + k * RS;
                 row = row < rows ? row : rows - 1;
-                q[k] = *reinterpret_cast<const float4*>(rb + row * len + c);
+                q[k] = *reinterpret_cast<const float4*>(rb + row * rs + c);
             }
             park();
 #pragma unroll
@@ -709,7 +717,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
                 if (row >= rows) break;
                 float4 w = *reinterpret_cast<const float4*>(Ot + row * OS + c);
                 w.x += q[k].x; w.y += q[k].y; w.z += q[k].z; w.w += q[k].w;
-                *reinterpret_cast<float4*>(yb + row * len + c) = w;
+                *reinterpret_cast<float4*>(yb + row * rs + c) = w;
                 mx = fmaxf(fmaxf(mx, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
                 if (y2b) {
                     const float e[4] = {w.x, w.y, w.z, w.w};
@@ -733,7 +741,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
         const int row = idx / (BN / 4), c = (idx - row * (BN / 4)) * 4;
         if (row >= rows || t0 + c >= len) continue;
         const float4 o = *reinterpret_cast<const float4*>(Ot + row * OS + c);
-        const int off = row * len + c;
+        const int off = row * rs + c;
         if (RES && rlin > 0) {
             const float e[4] = {o.x, o.y, o.z, o.w};
             float w[4];
@@ -791,8 +799,14 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     }
 }
 
-template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false, bool CLAMP = false>
+// RAG: a ragged batch (ragged.h).  Time-tiled launches (plain convs, Downsample's c3 + down_res) walk the batch's column-tile table, `a.len` is
+// the row stride and every tile takes its utterance's first column / length from the table; GEMM launches walk all columns of the batch and
+// look the column's utterance up for the block-floating-point scale only.
+template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false, bool CLAMP = false, bool RAG = false>
 __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ? S_WPE_F : (Epi::kIgemm ? (TL::NW <= 8 ? S_WPE_G : 5) : S_WPE)))) void conv3s_kernel(ConvSArgs a, Epi ep) {
+    static_assert(!RAG || (!FILM && !LERP && !SCALED), "ragged batches: plain / residual-conv / GEMM launches only");
+    constexpr bool RAGT = RAG && !Epi::kIgemm;      // time-tiled ragged walk
+    constexpr bool RAGG = RAG && Epi::kIgemm;       // GEMM over the whole ragged batch
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, A_U4 = TL::a_u4(TAPS);
     extern __shared__ __attribute__((aligned(16))) uint4 smem_s[];
     uint4* As = smem_s;
@@ -802,7 +816,9 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     const int lh = lane >> 5;
     const int wm = wave / TL::NWV;
     const int mblocks = a.MT / MTB;
-    const int len = a.len;
+    int len = a.len;                     // RAGT: the current tile's utterance (set by coords); otherwise the launch's
+    const int rs = RAGT ? a.len : 0;     // RAGT: row stride of x / cond / y (0 = `len`, the helpers' default)
+    int coloff = 0;                      // RAGT: first column of the current tile's utterance
     const int ntiles = a.ntiles;
 
     // persistent: a workgroup walks a CONTIGUOUS range of tiles; the first slab of every phase - including the
@@ -814,9 +830,17 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     auto coords = [&](int v, int& mt0, int& b, int& t0) __attribute__((always_inline)) {
         const int nt_id = v / mblocks, mb = v - nt_id * mblocks;
         mt0 = mb * MTB;
-        b = nt_id / a.tiles_per_utt;
-        t0 = (nt_id - b * a.tiles_per_utt) * TL::BN;
+        if constexpr (RAGT) {
+            b = rag_find(a.rag.ts, a.rag.B, nt_id, b);
+            t0 = (nt_id - a.rag.ts[b]) * TL::BN;
+        } else {
+            b = nt_id / a.tiles_per_utt;
+            t0 = (nt_id - b * a.tiles_per_utt) * TL::BN;
+        }
     };
+    // RAGT: utterance b's length and first column at this launch's rate
+    auto ulen = [&](int b_) __attribute__((always_inline)) { return a.rag.tb[b_] * a.rag.mult; };
+    auto uoff = [&](int b_) __attribute__((always_inline)) { return a.rag.pre[b_] * a.rag.mult; };
     int tile, vtiles;
     tile_range(ntiles, tile, vtiles);
     SlabRegs<TL> regs;
@@ -841,8 +865,13 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     constexpr bool FILM_FIRST = FILM && TL::WN == 1;
     auto load_first = [&](int mt0_, int b_, int t0_) __attribute__((always_inline)) {
         if constexpr (FILM_FIRST) film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0_, a.MT, a.cond + (long)b_ * a.Ccond * len, len, t0_);
+        else if constexpr (RAGT) first_load<TL, TAPS, LERP, CLAMP>(regs, a.A6, a.MT, mt0_, a.x + uoff(b_), a.Cin, ulen(b_), a.dil, t0_, 0, 0u, a.cmax, 0, 0.f, rs);
         else first_load<TL, TAPS, LERP, CLAMP>(regs, a.A6, a.MT, mt0_, fT ? a.x : a.x + (long)b_ * a.xstride, a.Cin, len, a.dil, t0_, fT, fstride, a.cmax, a.lin, a.lscale);
     };
+    if constexpr (RAGT) {
+        len = ulen(b);
+        coloff = uoff(b);
+    }
     load_first(mt0, b, t0);
     for (int tile_no = 0; tile < vtiles; ++tile_no) {
         const int nxt = tile + 1;
@@ -855,12 +884,12 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         }
         auto load_next_tile = [&]() __attribute__((always_inline)) {
             if (nxt < vtiles) {
-                int mt0n, bn, t0n;
+                int mt0n, bn = b, t0n;
                 coords(nxt, mt0n, bn, t0n);
                 load_first(mt0n, bn, t0n);
             }
         };
-        const float* xb = fT ? a.x : a.x + (long)b * a.xstride;
+        const float* xb = RAGT ? a.x + coloff : (fT ? a.x : a.x + (long)b * a.xstride);
         // this tile's bias rows -> LDS: read back with ds_read (lgkmcnt), so the epilogue math never waits on vmcnt
         // while the next phase's prefetch is in flight (a global bias load would drag that whole prefetch with it)
         // (two copies by tile parity: without the LDS park no barrier separates a fast wave's next tile from a slow wave's epilogue)
@@ -888,7 +917,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         }
         const int rl = wm * WM * 32 + 4 * lh;                     // local row of accumulator register r of m-tile i: rl + 32 i + (r & 3) + 8 (r >> 2)
         // block-floating-point scales of this tile's inputs (identity unless an utterance's |max| leaves the fp16 window)
-        const Bfp sx = fT ? Bfp{1.f, 1.f} : bfp_load(a.amax_x, b);      // flat GEMM tiles: per column (make_map / the epilogue below)
+        const Bfp sx = (fT || RAGG) ? Bfp{1.f, 1.f} : bfp_load(a.amax_x, b);      // flat GEMM tiles: per column (make_map / the epilogue below)
         f32x16 hi[WM][WN], lo[WM][WN];
         auto clear = [&](f32x16 (&u)[WM][WN]) __attribute__((always_inline)) {
 #pragma unroll
@@ -995,17 +1024,19 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 // the residual tensor is never written or read back and its launch disappears (ep.bias = the two biases summed).
                 // One accumulator pair, one unit: the two images are packed with JOINT per-m-tile scales (api.hip) and the two
                 // inputs share the smaller of their block-floating-point scales.
-                const float* cb = a.cond + (long)b * a.Ccond * len;
+                const float* cb = RAGT ? a.cond + coloff : a.cond + (long)b * a.Ccond * len;
                 const Bfp s2 = bfp_min(sx, bfp_load(a.amax_c, b));
                 inv = s2.inv;
                 split_phase<TL, TAPS, A_U4, LRELU, S_FB, false, false, false>(
                     hi, lo, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
-                    [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0); }, s2.s);
-                split_phase<TL, 1, A_U4, false, S_FB, false, false, false>(hi, lo, regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile, s2.s);
+                    [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0, 0, 0u, 0, 0, 0.f, rs); }, s2.s, nullptr, 0, 0u, 0, 0, 0.f,
+                    0, NoMid(), nullptr, rs);
+                split_phase<TL, 1, A_U4, false, S_FB, false, false, false>(hi, lo, regs, a.sc6, a.MT, mt0, cb, a.Ccond, len, 0, t0, As, Xs, load_next_tile, s2.s, nullptr, 0, 0u, 0, 0,
+                                                                           0.f, 0, NoMid(), nullptr, rs);
             } else
             split_phase<TL, TAPS, A_U4, LRELU, Epi::kIgemm ? S_FB_G : S_FB, SCALED, LERP, CLAMP>(hi, lo, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                                                                                                   load_next_tile, sx.s, Ks, fT, fstride, a.cmax, a.lin, a.lscale, 0, NoMid(),
-                                                                                                  a.amax_x);
+                                                                                                  a.amax_x, rs, RAGG ? a.rag.col2b : nullptr, RAGG ? a.rag.mult : 1);
             if constexpr (Epi::kIgemm) {
                 // plain GEMM use (B = 1, len = all columns): the gemm_epi.h epilogue functors finish the element
                 const int l31 = lane & 31, wn = wave - wm * TL::NWV;
@@ -1018,7 +1049,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                         const int col = t0 + (wn * WN + j) * 32 + l31;
                         const int n = b * len + col;
                         if (col < len) {
-                            const float c = cw * (fT ? bfp_load(a.amax_x, col / fT).inv : inv), cl = c * kLoInv;
+                            const float c = cw * (RAGG ? bfp_load(a.amax_x, a.rag.col2b[col / a.rag.mult]).inv : (fT ? bfp_load(a.amax_x, col / fT).inv : inv)), cl = c * kLoInv;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const float v[4] = {comb(hi[i][j][4 * q], lo[i][j][4 * q], c, cl), comb(hi[i][j][4 * q + 1], lo[i][j][4 * q + 1], c, cl),
@@ -1042,12 +1073,18 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
 #pragma unroll
                         for (int j = 0; j < WN; ++j) hi[i][j][r] += bm;
                     }
-                tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), hi, ep.y, ep.res, b, ep.M, len, mt0, t0, mx_run, ep.y2, ep.f2);
+                tile_store<TL, Epi::kRes>(reinterpret_cast<float*>(smem_s), hi, ep.y, ep.res, RAGT ? 0 : b, ep.M, len, mt0, t0, mx_run, ep.y2, ep.f2, 0, 0.f, rs, coloff);
             }
         }
         TR_STAMP(regs, 7);
         tile = nxt;
-        if (tile < vtiles) coords(tile, mt0, b, t0);
+        if (tile < vtiles) {
+            coords(tile, mt0, b, t0);
+            if constexpr (RAGT) {
+                len = ulen(b);
+                coloff = uoff(b);
+            }
+        }
     }
     if constexpr (!Epi::kIgemm) {
         if (a.amax_y) amax_flush_wg(a.amax_y + mx_b, mx_run, red);
@@ -1141,6 +1178,27 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
         ncu = prop.multiProcessorCount;
     }
     const int slots = ncu * bpc;        // persistent: one resident workgroup per slot walks a contiguous range of the tiles
+    if (ctx->rag) {
+        // ragged batch (ragged.h): the driver passed B = 1 and len = the batch's columns at this rate (= the row stride)
+        if constexpr (!FILM && !LERP && !SCALED) {
+            if (B != 1 || flat || a.len % ctx->rag->Ttot != 0) return fail(ctx, TVC_ERR_STATE, "conv3s: a ragged batch runs as one long utterance");
+            static bool ready_rag[64] = {};
+            bool& rr = ready_rag[ctx->device & 63];
+            if (!rr) {
+                hipError_t e = hipFuncSetAttribute((const void*)conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED, LERP, CLAMP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv3s setup: %s", hipGetErrorString(e));
+                rr = true;
+            }
+            int ncol = a.tiles_per_utt;
+            TVC_CHECK(rag_view(ctx, s, a.len / ctx->rag->Ttot, Epi::kIgemm ? 0 : TL::BN, &a.rag, Epi::kIgemm ? nullptr : &ncol));
+            a.ntiles = (a.MT / TL::MTB) * ncol;
+            dim3 g((unsigned)(a.ntiles < slots ? a.ntiles : slots));
+            hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED, LERP, CLAMP, true>), g, dim3(TL::NTHR), lds, s, a, ep);
+            return 0;
+        } else {
+            return fail(ctx, TVC_ERR_STATE, "conv3s: this launch has no ragged-batch variant");
+        }
+    }
     dim3 g((unsigned)(a.ntiles < slots ? a.ntiles : slots));
     hipLaunchKernelGGL((conv3s_kernel<TL, TAPS, LRELU, Epi, FILM, SCALED, LERP, CLAMP>), g, dim3(TL::NTHR), lds, s, a, ep);
     return 0;
@@ -1208,7 +1266,7 @@ inline int gemm_s_launch_ragged(tvc_ctx* ctx, hipStream_t s, const PackedW& w, c
     return gemm_s_launch_k<MTB, NWV, BPC, 2, Epi, false, true>(ctx, s, w, x, B, (krows + 31) / 32 * 32, len, xstride, ep, nullptr, krows - 1, amax_x);
 }
 
-// Per-utterance |max| of a contiguous [B][n] tensor into slot[b] (zeroed first): the block-floating-point slot of a tensor whose
+// Per-utterance |max| of a [B][C][len] tensor into slot[b] (zeroed first): the block-floating-point slot of a tensor whose
 // producer does not track it (tensors that enter a stage through the C ABI, epilogue-functor outputs).  One pass over the tensor.
 static __global__ __launch_bounds__(256) void amax_rows_kernel(const float* __restrict__ x, long n, float* __restrict__ slot) {
     __shared__ float red[4];
@@ -1225,8 +1283,30 @@ static __global__ __launch_bounds__(256) void amax_rows_kernel(const float* __re
     }
     amax_flush_wg(slot + b, mx, red);
 }
-// slot must have been zeroed (one memset per stage covers all of a stage's slots); rows of n floats must be 16-byte aligned
-inline int run_amax_rows(tvc_ctx* ctx, hipStream_t s, const float* x, int B, long n, float* slot) {
+// ragged batch (ragged.h): x is [C][rs] over the whole batch; utterance blockIdx.y owns columns [pre * mult, (pre + tb) * mult) of every row
+static __global__ __launch_bounds__(256) void amax_rag_kernel(const float* __restrict__ x, int C, int rs, RagDev rg, float* __restrict__ slot) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int n = rg.tb[b] * rg.mult;
+    const float* p = x + (long)rg.pre[b] * rg.mult;
+    float mx = 0.f;
+    for (int c = blockIdx.x; c < C; c += gridDim.x) {
+        const float* r = p + (long)c * rs;
+        for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, fabsf(r[i]));
+    }
+    amax_flush_wg(slot + b, mx, red);
+}
+// slot must have been zeroed (one memset per stage covers all of a stage's slots); rows of C * len floats must be 16-byte aligned
+inline int run_amax_rows(tvc_ctx* ctx, hipStream_t s, const float* x, int B, int C, long len, float* slot) {
+    if (ctx->rag) {     // (the driver passed B = 1 and len = the batch's columns at this tensor's rate)
+        if (B != 1 || len % ctx->rag->Ttot != 0) return fail(ctx, TVC_ERR_STATE, "amax_rows: a ragged batch runs as one long utterance");
+        RagDev rg;
+        TVC_CHECK(rag_view(ctx, s, (int)(len / ctx->rag->Ttot), 0, &rg, nullptr));
+        const int gx = C < 8 ? C : (ctx->rag->B >= 64 ? 8 : 16);
+        hipLaunchKernelGGL(amax_rag_kernel, dim3((unsigned)gx, (unsigned)ctx->rag->B), dim3(256), 0, s, x, C, (int)len, rg, slot);
+        return launch_check(ctx, "amax_rows (ragged)");
+    }
+    const long n = (long)C * len;
     if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(ctx, TVC_ERR_ARG, "amax_rows: the tensor must be 16-byte aligned");
     // one atomic per workgroup: a few per utterance while the launch still fills the chip
     long gx = (n / 4 + 255) / 256 / 8;                     // >= 8 float4 per thread

@@ -57,11 +57,12 @@ struct Conv48Args {
     float* amax_y;
     int len, dil, lin, rlin, tiles_per_utt, ntiles;
     float lscale, rscale;
+    RagDev rag;            // RAG kernels (ragged.h): len / lin / rlin = row strides of the batch-wide tensors, tiles / extents from the table
 };
 
 // RES: 0 none, 1 direct, 2 interpolated.  C5: Upsample.c5 (1x1, 48 -> 24, decoder.py:171,189) applied to the finished tile
 // before it leaves the CU: the 48-channel block output is never written, only c5's 24 rows are.
-template <bool FILM, bool LERP, int RES, bool C5 = false>
+template <bool FILM, bool LERP, int RES, bool C5 = false, bool RAG = false>
 __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void conv48s_kernel(Conv48Args a) {
     constexpr int C = kC48, BN = kBN48, XP = kXP48, NT = kNT48;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_q[];
@@ -73,9 +74,12 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int mt = wave >> 2, nt = wave & 3;
-    const int len = a.len, dil = a.dil;
+    const int rs = a.len, dil = a.dil;                       // rs = row stride of cond / res / out (= every utterance's length unless RAG, ragged.h)
     const int XW = BN + 2 * dil;
-    const int lin = LERP ? a.lin : len;
+    const int rsl = LERP ? a.lin : rs;                         // row stride of x
+    const int xf = LERP ? rs / a.lin : 1, rf = RES == 2 ? rs / a.rlin : 1;     // RAG: an utterance's low-rate lengths = len / xf, len / rf
+    int bh = 0;                                                // RAG: utterance hint of the table walk
+    auto utt = [&](int tile) __attribute__((always_inline)) { return rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh).b; };
 
     for (int i = tid; i < 36 * 64; i += NT) Wt[i] = a.A6[i];
     if (FILM)
@@ -108,9 +112,10 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         ig[i] = g;                                             // g >= 6: idle item (loads a valid address, never stores)
     }
     auto fetch = [&](int tile) __attribute__((always_inline)) {
-        const int b = tile / a.tiles_per_utt;
-        const int px0 = (tile - b * a.tiles_per_utt) * BN - dil;
-        const float* xb = a.x + (long)b * C * lin;
+        const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
+        const int len = rt.len, lin = LERP ? len / xf : len;
+        const int px0 = rt.tin * BN - dil;
+        const float* xb = RAG ? a.x + (LERP ? rt.off / xf : rt.off) : a.x + (long)rt.b * C * rsl;
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
             const int g = ig[i] > 5 ? 5 : ig[i];
@@ -119,16 +124,16 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
             if (LERP) {
                 const Lerp lc = lerp_coord(p, a.lscale, lin);
                 lam[i] = lc.w1;
-                const unsigned o0 = 4u * (unsigned)(8 * g * lin + lc.i0), o1 = 4u * (unsigned)(8 * g * lin + lc.i1);
+                const unsigned o0 = 4u * (unsigned)(8 * g * rsl + lc.i0), o1 = 4u * (unsigned)(8 * g * rsl + lc.i1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    xr0[i][j] = ldg_so(xb + (long)j * lin, o0);
-                    xr1[i][j] = ldg_so(xb + (long)j * lin, o1);
+                    xr0[i][j] = ldg_so(xb + (long)j * rsl, o0);
+                    xr1[i][j] = ldg_so(xb + (long)j * rsl, o1);
                 }
             } else {
-                const unsigned o = 4u * (unsigned)(8 * g * lin + p);
+                const unsigned o = 4u * (unsigned)(8 * g * rsl + p);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xb + (long)j * lin, o);
+                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xb + (long)j * rsl, o);
             }
         }
     };
@@ -154,49 +159,52 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
     int tile, tend;
     tile_range(a.ntiles, tile, tend);
     if (tile >= tend) return;
+    bh = utt(tile);
     fetch(tile);
-    deposit(bfp_load(a.amax_x, tile / a.tiles_per_utt).s);
+    deposit(bfp_load(a.amax_x, bh).s);
     if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
     float mx_run = 0.f;
-    int mx_b = tile / a.tiles_per_utt;
+    int mx_b = bh;
 
     for (; tile < tend; ++tile) {
-        const int b = tile / a.tiles_per_utt;
+        const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
+        const int b = rt.b, len = rt.len;
+        bh = b;
         if (a.amax_y && b != mx_b) {
             amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 228);
             mx_run = 0.f;
             mx_b = b;
         }
         const Bfp sx = bfp_load(a.amax_x, b), sc = FILM ? bfp_load(a.amax_c, b) : Bfp{1.f, 1.f};
-        const int t0 = (tile - b * a.tiles_per_utt) * BN;
+        const int t0 = rt.tin * BN;
         const int next = tile + 1;
         const int n = nt * 32 + l31;
         const int t = t0 + n;
         const int tc = t < len ? t : len - 1;
-        const unsigned oo = 4u * (unsigned)((32 * mt + 4 * lh) * len + tc);   // rows 32 mt + 8 g + 4 lh + q, sample t (the wave's m-tile lives in the lane offset: bases stay uniform)
+        const unsigned oo = 4u * (unsigned)((32 * mt + 4 * lh) * rs + tc);   // rows 32 mt + 8 g + 4 lh + q, sample t (the wave's m-tile lives in the lane offset: bases stay uniform)
 
         // cond fragments of this wave's columns: K16 step s -> channels 16 s + 8 lh + j
         float cr[FILM ? 3 : 1][8];
         if (FILM) {
-            const float* cb = a.cond + (long)b * C * len;
-            const unsigned oc = 4u * (unsigned)(8 * lh * len + tc);
+            const float* cb = RAG ? a.cond + rt.off : a.cond + (long)b * C * rs;
+            const unsigned oc = 4u * (unsigned)(8 * lh * rs + tc);
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) cr[s][j] = ldg_so(cb + (long)(16 * s + j) * len, oc);
+                for (int j = 0; j < 8; ++j) cr[s][j] = ldg_so(cb + (long)(16 * s + j) * rs, oc);
         }
         // residual values of this lane's 16 rows
         float rv[RES ? 4 : 1][4];
         if (RES == 1) {
-            const float* rb = a.res + (long)b * C * len;
+            const float* rb = RAG ? a.res + rt.off : a.res + (long)b * C * rs;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rv[g][q] = 32 * mt + 8 * g < C ? ldg_so(rb + (long)(8 * g + q) * len, oo) : 0.f;   // rows past 48 do not exist
+                for (int q = 0; q < 4; ++q) rv[g][q] = 32 * mt + 8 * g < C ? ldg_so(rb + (long)(8 * g + q) * rs, oo) : 0.f;   // rows past 48 do not exist
         } else if (RES == 2) {
-            const float* rb = a.res + (long)b * C * a.rlin;
-            const Lerp lc = lerp_coord(tc, a.rscale, a.rlin);
+            const float* rb = RAG ? a.res + rt.off / rf : a.res + (long)b * C * a.rlin;
+            const Lerp lc = lerp_coord(tc, a.rscale, RAG ? len / rf : a.rlin);
             const unsigned o0 = 4u * (unsigned)((32 * mt + 4 * lh) * a.rlin + lc.i0), o1 = 4u * (unsigned)((32 * mt + 4 * lh) * a.rlin + lc.i1);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         float xv[C5 ? 4 : 1][4];
         float mx = 0.f;                   // |max| of what this lane stores (C5: of its part of the finished tile)
         {
-            float* ob = C5 ? nullptr : a.out + (long)b * C * len;
+            float* ob = C5 ? nullptr : (RAG ? a.out + rt.off : a.out + (long)b * C * rs);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (32 * mt + 8 * g >= C) continue;                                // uniform per wave
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
                         xv[g][q] = v;
                         mx = fmaxf(mx, fabsf(v));
                     } else if (t < len) {
-                        stg_so(ob + (long)(8 * g + q) * len, oo, v);
+                        stg_so(ob + (long)(8 * g + q) * rs, oo, v);
                         mx = fmaxf(mx, fabsf(v));
                     }
                 }
@@ -354,8 +362,8 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
                 }
                 float m5 = 0.f;
                 if (t < len) {
-                    float* o5 = a.out5 + (long)b * 24 * len;
-                    const unsigned o5o = 4u * (unsigned)(4 * lh * len + t);
+                    float* o5 = RAG ? a.out5 + rt.off : a.out5 + (long)b * 24 * rs;
+                    const unsigned o5o = 4u * (unsigned)(4 * lh * rs + t);
                     const float c = cw5 * s5.inv, cl = c * kLoInv;
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
@@ -363,7 +371,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float v = comb(a5[4 * g + q], l5[4 * g + q], c, cl) + b5v[q];
-                            stg_so(o5 + (long)(8 * g + q) * len, o5o, v);
+                            stg_so(o5 + (long)(8 * g + q) * rs, o5o, v);
                             m5 = fmaxf(m5, fabsf(v));
                         }
                     }
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         // ---- next tile's input: registers -> LDS, then request the one after --------------------------------
         slab_barrier();                                   // every wave is done reading Xs
         if (next < tend) {
-            deposit(bfp_load(a.amax_x, next / a.tiles_per_utt).s);
+            deposit(bfp_load(a.amax_x, utt(next)).s);
             if (next + 1 < tend) fetch(next + 1);
         }
         slab_barrier();
@@ -391,13 +399,20 @@ int launch48(tvc_ctx* ctx, hipStream_t s, Conv48Args a, int B) {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv48s_kernel<FILM, LERP, RES, C5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv48s_kernel<FILM, LERP, RES, C5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv48s setup: %s", hipGetErrorString(e));
         ncu = prop.multiProcessorCount;
     }
     a.tiles_per_utt = (a.len + kBN48 - 1) / kBN48;
     a.ntiles = a.tiles_per_utt * B;
+    a.rag = RagDev{};
+    if (ctx->rag) {
+        if (B != 1 || a.len % ctx->rag->Ttot != 0) return fail(ctx, TVC_ERR_STATE, "conv48s: a ragged batch runs as one long utterance");
+        TVC_CHECK(rag_view(ctx, s, a.len / ctx->rag->Ttot, kBN48, &a.rag, &a.ntiles));
+    }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
-    hipLaunchKernelGGL((conv48s_kernel<FILM, LERP, RES, C5>), dim3(grid), dim3(kNT48), lds, s, a);
+    if (ctx->rag) hipLaunchKernelGGL((conv48s_kernel<FILM, LERP, RES, C5, true>), dim3(grid), dim3(kNT48), lds, s, a);
+    else hipLaunchKernelGGL((conv48s_kernel<FILM, LERP, RES, C5>), dim3(grid), dim3(kNT48), lds, s, a);
     return launch_check(ctx, "conv48s");
 }
 
@@ -422,12 +437,13 @@ struct Conv48PArgs {
     const float* amax_x;
     const float* amax_c;
     float* amax_y;
+    RagDev rag;            // RAG kernels (ragged.h): len / lin / rlin = row strides of the batch-wide tensors, tiles / extents from the table
     int len, da, db, lin, rlin, tiles_per_utt, ntiles;
     float lscale, rscale;
 };
 constexpr int kXPP = 136;      // input tile columns: 128 + 2 * dil_a (dil_a <= 4)
 
-template <bool FILM, bool LERP, int RES>
+template <bool FILM, bool LERP, int RES, bool RAG = false>
 __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void conv48p_kernel(Conv48PArgs a) {
     constexpr int C = kC48, NT = kNT48, XP = kXPP, HP = 128;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_p[];
@@ -440,10 +456,13 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int mt = wave >> 2, nt = wave & 3;
-    const int len = a.len, da = a.da, db = a.db;
+    const int rs = a.len, da = a.da, db = a.db;                 // rs = row stride of cond / out (= every utterance's length unless RAG, ragged.h)
     const int BNO = 128 - 2 * db;                              // output columns per tile
     const int XW = 128 + 2 * da;
-    const int lin = LERP ? a.lin : len;
+    const int rsl = LERP ? a.lin : rs;                         // row stride of x
+    const int xf = LERP ? rs / a.lin : 1, rf = RES == 2 ? rs / a.rlin : 1;     // RAG: an utterance's low-rate lengths = len / xf, len / rf
+    int bh = 0;                                                // RAG: utterance hint of the table walk
+    auto utt = [&](int tile) __attribute__((always_inline)) { return rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh).b; };
 
     for (int i = tid; i < 36 * 64; i += NT) {
         Wa[i] = a.Aa[i];
@@ -475,9 +494,10 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         ig[i] = g;                                             // g >= 6: idle item (loads a valid address, never stores)
     }
     auto fetch = [&](int tile) __attribute__((always_inline)) {
-        const int b = tile / a.tiles_per_utt;
-        const int px0 = (tile - b * a.tiles_per_utt) * BNO - db - da;
-        const float* xb = a.x + (long)b * C * lin;
+        const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
+        const int len = rt.len, lin = LERP ? len / xf : len;
+        const int px0 = rt.tin * BNO - db - da;
+        const float* xb = RAG ? a.x + (LERP ? rt.off / xf : rt.off) : a.x + (long)rt.b * C * rsl;
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
             const int g = ig[i] > 5 ? 5 : ig[i];
@@ -486,16 +506,16 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
             if (LERP) {
                 const Lerp lc = lerp_coord(p, a.lscale, lin);
                 lam[i] = lc.w1;
-                const unsigned o0 = 4u * (unsigned)(8 * g * lin + lc.i0), o1 = 4u * (unsigned)(8 * g * lin + lc.i1);
+                const unsigned o0 = 4u * (unsigned)(8 * g * rsl + lc.i0), o1 = 4u * (unsigned)(8 * g * rsl + lc.i1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    xr0[i][j] = ldg_so(xb + (long)j * lin, o0);
-                    xr1[i][j] = ldg_so(xb + (long)j * lin, o1);
+                    xr0[i][j] = ldg_so(xb + (long)j * rsl, o0);
+                    xr1[i][j] = ldg_so(xb + (long)j * rsl, o1);
                 }
             } else {
-                const unsigned o = 4u * (unsigned)(8 * g * lin + p);
+                const unsigned o = 4u * (unsigned)(8 * g * rsl + p);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xb + (long)j * lin, o);
+                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xb + (long)j * rsl, o);
             }
         }
     };
@@ -519,42 +539,45 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
     int tile, tend;
     tile_range(a.ntiles, tile, tend);
     if (tile >= tend) return;
+    bh = utt(tile);
     fetch(tile);
-    deposit(bfp_load(a.amax_x, tile / a.tiles_per_utt).s);
+    deposit(bfp_load(a.amax_x, bh).s);
     if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
     float mx_run = 0.f;
-    int mx_b = tile / a.tiles_per_utt;
+    int mx_b = bh;
 
     for (; tile < tend; ++tile) {
-        const int b = tile / a.tiles_per_utt;
+        const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
+        const int b = rt.b, len = rt.len;
+        bh = b;
         if (a.amax_y && b != mx_b) {
             amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 260);
             mx_run = 0.f;
             mx_b = b;
         }
         const Bfp sx = bfp_load(a.amax_x, b), sc = FILM ? bfp_load(a.amax_c, b) : Bfp{1.f, 1.f};
-        const int t0 = (tile - b * a.tiles_per_utt) * BNO;
+        const int t0 = rt.tin * BNO;
         const int next = tile + 1;
         const int n = nt * 32 + l31;                       // this lane's column: of h in the first conv, of the output in the second
         const int t = t0 + n;
         const bool live = n < BNO && t < len;
         const int tc = t < len ? t : len - 1;
-        const unsigned oo = 4u * (unsigned)((32 * mt + 4 * lh) * len + tc);
+        const unsigned oo = 4u * (unsigned)((32 * mt + 4 * lh) * rs + tc);
 
         float cr[FILM ? 3 : 1][8];
         if (FILM) {
-            const float* cb = a.cond + (long)b * C * len;
-            const unsigned oc = 4u * (unsigned)(8 * lh * len + tc);
+            const float* cb = RAG ? a.cond + rt.off : a.cond + (long)b * C * rs;
+            const unsigned oc = 4u * (unsigned)(8 * lh * rs + tc);
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) cr[s][j] = ldg_so(cb + (long)(16 * s + j) * len, oc);
+                for (int j = 0; j < 8; ++j) cr[s][j] = ldg_so(cb + (long)(16 * s + j) * rs, oc);
         }
         float rv[RES ? 4 : 1][4];
         if (RES == 2) {
-            const float* rb = a.res + (long)b * C * a.rlin;
-            const Lerp lc = lerp_coord(tc, a.rscale, a.rlin);
+            const float* rb = RAG ? a.res + rt.off / rf : a.res + (long)b * C * a.rlin;
+            const Lerp lc = lerp_coord(tc, a.rscale, RAG ? len / rf : a.rlin);
             const unsigned o0 = 4u * (unsigned)((32 * mt + 4 * lh) * a.rlin + lc.i0), o1 = 4u * (unsigned)((32 * mt + 4 * lh) * a.rlin + lc.i1);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -706,7 +729,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         // ---- epilogue ---------------------------------------------------------------------------------------------------
         {
             float mx = 0.f;
-            float* ob = a.out + (long)b * C * len;
+            float* ob = RAG ? a.out + rt.off : a.out + (long)b * C * rs;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (32 * mt + 8 * g >= C) continue;                                // uniform per wave
@@ -722,7 +745,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
                     if (FILM) v = __fadd_rn(__fmul_rn(v, asc[4 * g + q] + bs[q]), ash[4 * g + q] + bh[q]);
                     if (RES) v = __fadd_rn(v, rv[g][q]);
                     if (live) {
-                        stg_so(ob + (long)(8 * g + q) * len, oo, v);
+                        stg_so(ob + (long)(8 * g + q) * rs, oo, v);
                         mx = fmaxf(mx, fabsf(v));
                     }
                 }
@@ -732,7 +755,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         // ---- next tile's input: registers -> LDS, then request the one after ------------------------------------------------
         slab_barrier();                                   // every wave is done reading Xs and Hs
         if (next < tend) {
-            deposit(bfp_load(a.amax_x, next / a.tiles_per_utt).s);
+            deposit(bfp_load(a.amax_x, utt(next)).s);
             if (next + 1 < tend) fetch(next + 1);
         }
         slab_barrier();
@@ -750,14 +773,21 @@ int launch48p(tvc_ctx* ctx, hipStream_t s, Conv48PArgs a, int B) {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv48p_kernel<FILM, LERP, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv48p_kernel<FILM, LERP, RES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "conv48p setup: %s", hipGetErrorString(e));
         ncu = prop.multiProcessorCount;
     }
     const int bno = 128 - 2 * a.db;
     a.tiles_per_utt = (a.len + bno - 1) / bno;
     a.ntiles = a.tiles_per_utt * B;
+    a.rag = RagDev{};
+    if (ctx->rag) {
+        if (B != 1 || a.len % ctx->rag->Ttot != 0) return fail(ctx, TVC_ERR_STATE, "conv48p: a ragged batch runs as one long utterance");
+        TVC_CHECK(rag_view(ctx, s, a.len / ctx->rag->Ttot, bno, &a.rag, &a.ntiles));
+    }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
-    hipLaunchKernelGGL((conv48p_kernel<FILM, LERP, RES>), dim3(grid), dim3(kNT48), lds, s, a);
+    if (ctx->rag) hipLaunchKernelGGL((conv48p_kernel<FILM, LERP, RES, true>), dim3(grid), dim3(kNT48), lds, s, a);
+    else hipLaunchKernelGGL((conv48p_kernel<FILM, LERP, RES>), dim3(grid), dim3(kNT48), lds, s, a);
     return launch_check(ctx, "conv48p");
 }
 

@@ -32,6 +32,7 @@ struct ConvS2Args {
     // [B][part][M / 8][len][8 fp16], k from the analytic bound pre_w * |x|max + pre_b >= |y|, which both kernels evaluate alike)
     uint4* ypre;
     float pre_w, pre_b;
+    RagDev rag;            // RAG kernels (ragged.h): len / lin = row strides of the batch-wide tensors, tiles / extents from the table
 };
 // |conv + bias| <= (max_m sum_k |w|) |x|max + max |b|: the bound the producer normalises its pre-split output by and the consumer undoes
 // (amax = the per-utterance |max| slot of the producer's INPUT; non-null for these launches)
@@ -57,7 +58,7 @@ struct CS2 {
     static constexpr int lds_bytes = 2 * BUF_U4 * 16 + TAB * 4 + 64;
 };
 
-template <bool LERP, bool PRE = false>
+template <bool LERP, bool PRE = false, bool RAG = false>
 __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) void conv_s2_kernel(ConvS2Args a) {
     using TL = CS2;
     constexpr int MTB = TL::MTB, NWV = TL::NWV, WN = TL::WN, NW = TL::NW, BN = TL::BN, XROW = TL::XROW, A_PER = TL::A_PER;
@@ -68,8 +69,9 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NWV, wn = wave - wm * NWV;
-    const int nslab = a.Cin / 16, len = a.len, dil = a.dil;
-    const int cs_ = LERP ? a.lin : len;                      // channel stride of x
+    const int nslab = a.Cin / 16, rs = a.len, dil = a.dil;   // rs = row stride of y (= every utterance's length unless RAG)
+    const int cs_ = LERP ? a.lin : rs;                       // channel stride of x
+    const int xf = LERP ? rs / a.lin : 1;                    // RAG: an utterance's low-rate length = its length / xf
     const int xw = BN + 2 * dil, nitems = 2 * xw;
 
     for (int i = tid; i < a.M; i += TL::NTHR) {
@@ -80,11 +82,15 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
     int tfirst, tlast;
     tile_range(a.ntiles, tfirst, tlast);
     if (tfirst >= tlast) return;
-    auto coords = [&](int v, int& mt0, int& b, int& t0) __attribute__((always_inline)) {
+    // (b is also the hint of the ragged table walk; len / off = the utterance's length and first column at the output rate)
+    auto coords = [&](int v, int& mt0, int& b, int& t0, int& len, int& off) __attribute__((always_inline)) {
         const int nt = v / a.mblocks, mb = v - nt * a.mblocks;
         mt0 = mb * MTB;
-        b = nt / a.tiles_per_utt;
-        t0 = (nt - b * a.tiles_per_utt) * BN;
+        const RagTile rt = rag_tile<RAG>(a.rag, nt, a.tiles_per_utt, rs, b);
+        b = rt.b;
+        t0 = rt.tin * BN;
+        len = rt.len;
+        off = rt.off;
     };
 
     // staging registers of the one slab in flight and this thread's item: (8-channel half g, column c) of the halo tile;
@@ -97,19 +103,20 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
     unsigned xo = 0, xo1 = 0;
     float lw0 = 0.f, lw1 = 0.f, xsc = 1.f;       // of the load cursor's tile
     float rw0 = 0.f, rw1 = 0.f, rxs = 1.f;       // of the slab in flight in the registers (the cursor may already stand on the next tile when it is split)
-    int lv = tfirst, ls = 0, lmt0, lb, lt0;
-    coords(lv, lmt0, lb, lt0);
+    int lv = tfirst, ls = 0, lmt0, lb = 0, lt0, llen, loff;
+    coords(lv, lmt0, lb, lt0, llen, loff);
     auto tile_offsets = [&]() __attribute__((always_inline)) {
         int p = lt0 - dil + ic;
-        p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+        p = p < 0 ? 0 : (p > llen - 1 ? llen - 1 : p);
+        const int cbase = 8 * ig * cs_ + (RAG ? (LERP ? loff / xf : loff) : 0);     // RAG: the utterance's first column rides in the lane offset
         if (LERP) {
-            const Lerp lc = lerp_coord(p, a.lscale, a.lin);
-            xo = (unsigned)(8 * ig * cs_ + lc.i0);
-            xo1 = (unsigned)(8 * ig * cs_ + lc.i1);
+            const Lerp lc = lerp_coord(p, a.lscale, RAG ? llen / xf : a.lin);
+            xo = (unsigned)(cbase + lc.i0);
+            xo1 = (unsigned)(cbase + lc.i1);
             lw0 = lc.w0;
             lw1 = lc.w1;
         } else {
-            xo = (unsigned)(8 * ig * cs_ + p);
+            xo = (unsigned)(cbase + p);
         }
         xsc = bfp_load(a.amax_x, lb).s;
     };
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
             const int tap = q / (MTB * kParts), rem = q - tap * (MTB * kParts);
             ar[i] = ldg_so4(abase, 16u * (unsigned)(tap * a.MT * kPU4 + rem * 64 + lane));
         }
-        const float* xc = a.x + ((long)lb * a.Cin + (long)ls * 16) * cs_;
+        const float* xc = a.x + ((RAG ? 0L : (long)lb * a.Cin) + (long)ls * 16) * cs_;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             xr[j] = ldg_so(xc + (long)j * cs_, 4u * xo);
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
             if (lv + 1 < tlast) {
                 ++lv;
                 ls = 0;
-                coords(lv, lmt0, lb, lt0);
+                coords(lv, lmt0, lb, lt0, llen, loff);
                 tile_offsets();
             } else {
                 ls = nslab - 1;
@@ -190,8 +197,8 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
     };
 
     // consumer cursor
-    int cv = tfirst, cs = 0, cmt0, cb, ct0;
-    coords(cv, cmt0, cb, ct0);
+    int cv = tfirst, cs = 0, cmt0, cb = 0, ct0, len, coff;
+    coords(cv, cmt0, cb, ct0, len, coff);
     float mx_run = 0.f;
     int flush_b = -1;
 
@@ -213,13 +220,13 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
             // epilogue straight from the accumulators: bias, store, running |max|
             const Bfp sx = bfp_load(a.amax_x, cb);
             const int row0 = (cmt0 + wm) * 32;
-            float* yb = a.y + ((long)cb * a.M + row0) * len;
+            float* yb = RAG ? a.y + (long)row0 * rs + coff : a.y + ((long)cb * a.M + row0) * rs;
             const float ps = PRE ? norm_from_amax(presplit_bound(a.pre_w, a.pre_b, a.amax_x, cb)).s : 1.f;
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int t = ct0 + (wn * WN + j) * 32 + l31;
                 const bool live = t < len;
-                const unsigned off = 4u * (unsigned)(4 * lh * len + (live ? t : len - 1));
+                const unsigned off = 4u * (unsigned)(4 * lh * rs + (live ? t : len - 1));
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (row0 + 8 * g < a.M) {                      // uniform
@@ -238,11 +245,11 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
                             split2<false>(v[2], v[3], p1[1], p2[1]);
                             const auto qx = __builtin_amdgcn_permlane32_swap(p1[0], p2[0], false, false);
                             const auto qy = __builtin_amdgcn_permlane32_swap(p1[1], p2[1], false, false);
-                            if (live) a.ypre[(((long)cb * 2 + lh) * (a.M >> 3) + ((row0 >> 3) + g)) * len + t] = make_uint4(qx[0], qy[0], qx[1], qy[1]);
+                            if (live) a.ypre[(((RAG ? 0L : (long)cb * 2) + lh) * (a.M >> 3) + ((row0 >> 3) + g)) * rs + (RAG ? coff : 0) + t] = make_uint4(qx[0], qy[0], qx[1], qy[1]);
                         } else if (live) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                stg_so(yb + (long)(8 * g + q) * len, off, e[q]);
+                                stg_so(yb + (long)(8 * g + q) * rs, off, e[q]);
                                 mx_run = fmaxf(mx_run, fabsf(e[q]));
                             }
                         }
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
             const int done_b = cb;
             ++cv;
             const bool last = cv >= tlast;
-            if (!last) coords(cv, cmt0, cb, ct0);
+            if (!last) coords(cv, cmt0, cb, ct0, len, coff);
             if (a.amax_y && (last || cb != done_b)) {          // the workgroup leaves utterance done_b: the waves' maxima meet in LDS,
                 const float m = wave_max(mx_run);              // one thread publishes them behind the next barrier
                 if (lane == 0) red[wave] = m;
@@ -302,6 +309,7 @@ inline bool conv_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const PackedW& w, 
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_s2_kernel<LERP, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, CS2::lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_s2_kernel<LERP, PRE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CS2::lds_bytes);
         if (e != hipSuccess) { *rc = fail(ctx, TVC_ERR_HIP, "conv_s2 setup: %s", hipGetErrorString(e)); return true; }
         ncu = prop.multiProcessorCount;
         ready = true;
@@ -327,8 +335,18 @@ inline bool conv_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const PackedW& w, 
     a.ypre = reinterpret_cast<uint4*>(y);
     a.pre_w = pre_w;
     a.pre_b = pre_b;
+    a.rag = RagDev{};
+    if (ctx->rag) {
+        // ragged batch (ragged.h): the driver passed B = 1 and len = the batch's columns at this rate (= the row stride)
+        if (B != 1 || len % ctx->rag->Ttot != 0) { *rc = fail(ctx, TVC_ERR_STATE, "conv_s2: a ragged batch runs as one long utterance"); return true; }
+        int ncol = 0;
+        *rc = rag_view(ctx, s, len / ctx->rag->Ttot, CS2::BN, &a.rag, &ncol);
+        if (*rc) return true;
+        a.ntiles = ncol * a.mblocks;
+    }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
-    hipLaunchKernelGGL((conv_s2_kernel<LERP, PRE>), dim3(grid), dim3(CS2::NTHR), CS2::lds_bytes, s, a);
+    if (ctx->rag) hipLaunchKernelGGL((conv_s2_kernel<LERP, PRE, true>), dim3(grid), dim3(CS2::NTHR), CS2::lds_bytes, s, a);
+    else hipLaunchKernelGGL((conv_s2_kernel<LERP, PRE>), dim3(grid), dim3(CS2::NTHR), CS2::lds_bytes, s, a);
     *rc = launch_check(ctx, "conv_s2");
     return true;
 }

@@ -38,12 +38,21 @@ __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
 
 // One wavefront per frame (grid (ceil(T / 4), B), four frames per workgroup): lane l < 60 owns the frame's samples 8 l ... 8 l + 7.
 // csum[b][m][t] = sum over the frame's 480 samples of inc_m: a lane adds its eight increments, the wave reduces - no LDS, no barrier.
+// Ragged batch (ragged.h) in the three oscillator kernels: f0 / amps / csum are [rows][T] over the whole batch (T = row stride), utterance
+// b = blockIdx.y owns frames pre[b] ... + tb[b]; its phase starts at zero and its interpolations clamp at ITS last frame.
 static __global__ __launch_bounds__(256) void harm_frame_sum_kernel(const float* __restrict__ f0, double* __restrict__ csum,
-                                                                    int T, float scale) {
+                                                                    int T, float scale, RagDev rg) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int t = 4 * blockIdx.x + (threadIdx.x >> 6);
+    const int rs = T;
+    long fbase = (long)b * T, cbase = (long)b * kHarm * T;
+    if (rg.tb) {
+        T = rg.tb[b];
+        fbase = cbase = rg.pre[b];
+        scale = __fdiv_rn((float)T, (float)(T * kHop));      // what the host computes for an utterance of its own
+    }
     if (t >= T) return;
-    const float* f = f0 + (long)b * T;
+    const float* f = f0 + fbase;
     double acc[kHarm];
 #pragma unroll
     for (int m = 0; m < kHarm; ++m) acc[m] = 0.0;
@@ -61,13 +70,17 @@ static __global__ __launch_bounds__(256) void harm_frame_sum_kernel(const float*
         double v = acc[m];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == m) csum[((long)b * kHarm + m) * T + t] = v;
+        if (lane == m) csum[cbase + (long)m * rs + t] = v;
     }
 }
 
 // grid (15, B), one wavefront: exclusive prefix over frames, in place
-static __global__ __launch_bounds__(64) void harm_frame_scan_kernel(double* __restrict__ csum, int T) {
+static __global__ __launch_bounds__(64) void harm_frame_scan_kernel(double* __restrict__ csum, int T, RagDev rg) {
     double* p = csum + ((long)blockIdx.y * kHarm + blockIdx.x) * T;
+    if (rg.tb) {
+        p = csum + (long)blockIdx.x * T + rg.pre[blockIdx.y];
+        T = rg.tb[blockIdx.y];
+    }
     const int lane = threadIdx.x;
     double carry = 0.0;
     for (int base = 0; base < T; base += 64) {
@@ -84,13 +97,21 @@ static __global__ __launch_bounds__(64) void harm_frame_scan_kernel(double* __re
 // barriers and a four-wave carry per harmonic).
 static __global__ __launch_bounds__(256) void harm_synth_kernel(const float* __restrict__ f0, const float* __restrict__ amps,
                                                                 const double* __restrict__ coff, float* __restrict__ source,
-                                                                int T, float scale_size, float scale_amp) {
+                                                                int T, float scale_size, float scale_amp, RagDev rg) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int t = 4 * blockIdx.x + (threadIdx.x >> 6);
+    const int rs = T;
+    const long Ls = (long)T * kHop;                      // row stride of `source`
+    long fbase = (long)b * T, abase = (long)b * kHarm * T, sbase = (long)b * 16 * Ls;
+    if (rg.tb) {
+        T = rg.tb[b];
+        fbase = abase = rg.pre[b];
+        sbase = (long)rg.pre[b] * kHop;
+        scale_size = __fdiv_rn((float)T, (float)(T * kHop));
+    }
     if (t >= T) return;
     const bool act = lane < kHop / 8;
-    const long L = (long)T * kHop;
-    const float* f = f0 + (long)b * T;
+    const float* f = f0 + fbase;
     const int p0 = t * kHop + 8 * (act ? lane : 0);
     float fs[8], uv[8];
     Lerp ca[8];
@@ -110,9 +131,9 @@ static __global__ __launch_bounds__(256) void harm_synth_kernel(const float* __r
             sum += d[e];
         }
         const double inc = wave_incl_scan(sum, lane);
-        double run = coff[((long)b * kHarm + m) * T + t] + (inc - sum);       // phase in front of this lane's first sample
+        double run = coff[abase + (long)m * rs + t] + (inc - sum);       // phase in front of this lane's first sample
         if (act) {
-            const float* am = amps + ((long)b * kHarm + m) * T;
+            const float* am = amps + abase + (long)m * rs;
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -124,7 +145,7 @@ static __global__ __launch_bounds__(256) void harm_synth_kernel(const float* __r
                 const float amp = lerp_eval(ca[e], am[ca[e].i0], am[ca[e].i1]);
                 o[e] = __fmul_rn(hsin, amp);
             }
-            float4* dst = reinterpret_cast<float4*>(source + ((long)b * 16 + m) * L + p0);
+            float4* dst = reinterpret_cast<float4*>(source + sbase + (long)m * Ls + p0);
             dst[0] = make_float4(o[0], o[1], o[2], o[3]);
             dst[1] = make_float4(o[4], o[5], o[6], o[7]);
         }
@@ -150,10 +171,17 @@ static __global__ void angle_fill_kernel(float* __restrict__ angle, long n, uint
 
 // grid (x, B): blockIdx.y = utterance; smax[b] = per-utterance |max| slot of `source` (block-floating-point guard of
 // FilterNet's first conv, conv3s.h): one atomic per workgroup
-static __global__ __launch_bounds__(256) void noise_ola_kernel(const float* __restrict__ frames, float* __restrict__ source, int B, int T, float* __restrict__ smax) {
+static __global__ __launch_bounds__(256) void noise_ola_kernel(const float* __restrict__ frames, float* __restrict__ source, int B, int T, float* __restrict__ smax, RagDev rg) {
     __shared__ float red[4];
-    const long L = (long)T * kHop;
+    const long Ls = (long)T * kHop;                      // row stride of `source`
     const long b = blockIdx.y;
+    long fbase = b * T, sbase = (b * 16 + 15) * Ls;
+    if (rg.tb) {       // ragged batch (ragged.h): utterance b's frames / samples start behind those of the utterances before it; the envelope ends at ITS end
+        T = rg.tb[b];
+        fbase = rg.pre[b];
+        sbase = 15 * Ls + (long)rg.pre[b] * kHop;
+    }
+    const long L = (long)T * kHop;
     float mx = 0.f;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < L; i += (long)gridDim.x * blockDim.x) {
         int p = (int)i;
@@ -164,9 +192,9 @@ static __global__ __launch_bounds__(256) void noise_ola_kernel(const float* __re
         if (q - (kNfft - 1) <= 0) f_lo = 0;
         float s = 0.f;
         for (int f = f_lo > 1 ? f_lo : 1; f <= f_hi; ++f)  // frame 0 is the zero pad (decoder.py:81)
-            s = __fadd_rn(s, frames[((long)b * T + (f - 1)) * kNfft + (q - f * kHop)]);
+            s = __fadd_rn(s, frames[(fbase + (f - 1)) * kNfft + (q - f * kHop)]);
         const float v = s / (float)(f_hi - f_lo + 1);
-        source[(b * 16 + 15) * L + p] = v;
+        source[sbase + p] = v;
         mx = fmaxf(mx, fabsf(v));
     }
     amax_flush_wg(smax + b, mx, red);
@@ -181,7 +209,8 @@ static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
     const int ncols = B * T;
     float* ef = ws.get<float>((size_t)B * T);
     float* x = ws.get<float>((size_t)B * kSrcCh * T);
-    float* xmax = ws.get<float>((size_t)B);
+    const int NB = ctx->rag ? ctx->rag->B : B;      // utterances (a ragged batch runs as B = 1, T = all its frames: ragged.h)
+    float* xmax = ws.get<float>((size_t)NB);
     if (!dry) {
         hipLaunchKernelGGL(window_max_kernel, dim3(grid_for((long)ncols * 64)), dim3(256), 0, s, energy, ef, (long)B, T, kHop);
         EpiSumCond ep{x, ctx->src_content_in.bias, ef, f0, ctx->src_e_w, ctx->src_e_b, ctx->src_f_w, ctx->src_f_b, kSrcCh, T, ncols};
@@ -191,8 +220,8 @@ static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
     }
     for (int i = 0; i < 3; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->src_mid[i], x, B, T));
     if (dry) return 0;
-    TVC_HIP(ctx, hipMemsetAsync(xmax, 0, (size_t)B * sizeof(float), s));
-    TVC_CHECK(run_amax_rows(ctx, s, x, B, (long)kSrcCh * T, xmax));
+    TVC_HIP(ctx, hipMemsetAsync(xmax, 0, (size_t)NB * sizeof(float), s));
+    TVC_CHECK(run_amax_rows(ctx, s, x, B, kSrcCh, T, xmax));
     // to_amps (128 -> 15 rows: one 32-row m-tile)
     EpiBias<ACT_ELU1, false> ea{amps, ctx->src_to_amps.bias, nullptr, kHarm, T, ncols, (long)kHarm * T, 0};
     TVC_CHECK((gemm_s_launch<1, 4, 2>(ctx, s, ctx->src_to_amps, x, B, kSrcCh, T, 0, ea, xmax)));
@@ -210,27 +239,31 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
     double* csum = ws.get<double>((size_t)B * kHarm * T);
     float* frames = ws.get<float>((size_t)B * T * kNfft);
     float* ang = angle ? nullptr : ws.get<float>((size_t)B * kBins * T);
-    float* smax_own = smax ? nullptr : ws.get<float>((size_t)B);
+    const int NB = ctx->rag ? ctx->rag->B : B;
+    const int Tg = ctx->rag ? ctx->rag->Tlong : T;      // frames of the longest utterance: the per-utterance grids' extent
+    float* smax_own = smax ? nullptr : ws.get<float>((size_t)NB);
     if (dry) return 0;
     if (!smax) {
         smax = smax_own;
-        TVC_HIP(ctx, hipMemsetAsync(smax, 0, (size_t)B * sizeof(float), s));
+        TVC_HIP(ctx, hipMemsetAsync(smax, 0, (size_t)NB * sizeof(float), s));
     }
+    RagDev rg;
+    TVC_CHECK(rag_view(ctx, s, 1, 0, &rg, nullptr));
     // harmonics -> source[:, 0:15]
     const float scale_size = (float)T / (float)L;         // F.interpolate(f0, Lw): size given
     const float scale_amp = (float)(1.0 / (double)kHop);  // F.interpolate(amps, scale_factor=480)
-    hipLaunchKernelGGL(harm_frame_sum_kernel, dim3((T + 3) / 4, B), dim3(256), 0, s, f0, csum, T, scale_size);
-    hipLaunchKernelGGL(harm_frame_scan_kernel, dim3(kHarm, B), dim3(64), 0, s, csum, T);
-    hipLaunchKernelGGL(harm_synth_kernel, dim3((T + 3) / 4, B), dim3(256), 0, s, f0, amps, csum, source, T, scale_size, scale_amp);
+    hipLaunchKernelGGL(harm_frame_sum_kernel, dim3((Tg + 3) / 4, NB), dim3(256), 0, s, f0, csum, T, scale_size, rg);
+    hipLaunchKernelGGL(harm_frame_scan_kernel, dim3(kHarm, NB), dim3(64), 0, s, csum, T, rg);
+    hipLaunchKernelGGL(harm_synth_kernel, dim3((Tg + 3) / 4, NB), dim3(256), 0, s, f0, amps, csum, source, T, scale_size, scale_amp, rg);
     // the 15 harmonic rows are sin(.) * voiced gate * interpolated amps: bounded by the amplitudes' own |max| (3 000 values per utterance)
-    TVC_CHECK(run_amax_rows(ctx, s, amps, B, (long)kHarm * T, smax));
+    TVC_CHECK(run_amax_rows(ctx, s, amps, B, kHarm, T, smax));
     // noise -> source[:, 15]: kernel * exp(i angle) -> inverse 1920-point FFT per frame (fft.hip) -> overlap-add
     if (!angle) {
         hipLaunchKernelGGL(angle_fill_kernel, dim3(grid_for((long)B * kBins * T)), dim3(256), 0, s, ang, (long)B * kBins * T, seed);
         angle = ang;
     }
-    TVC_CHECK(run_noise_ifft(ctx, s, kern, angle, frames, B, T));
-    hipLaunchKernelGGL(noise_ola_kernel, dim3(grid_for(L / 4, 256, B >= 32 ? 16 : 512 / B), B), dim3(256), 0, s, frames, source, B, T, smax);
+    TVC_CHECK(run_noise_ifft(ctx, s, kern, angle, frames, B, T, ctx->rag && angle != ang));
+    hipLaunchKernelGGL(noise_ola_kernel, dim3(grid_for((long)Tg * kHop / 4, 256, NB >= 32 ? 16 : 512 / NB), NB), dim3(256), 0, s, frames, source, B, T, smax, rg);
     return launch_check(ctx, "dsp");
 }
 
@@ -320,26 +353,27 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
     // |max| slots, [B] floats each, one memset
     enum { S_CONTENT = 0, S_SRC, S_X, S_SKIP0, S_DH1 = S_SKIP0 + 5, S_DH2 = S_DH1 + 4, S_UHA = S_DH2 + 4, S_UX1 = S_UHA + 5, S_UHB = S_UX1 + 5, S_UXU = S_UHB + 5,
            S_LEV = S_UXU + 5, S_COUNT = S_LEV + 5 };
-    float* slots = ws.get<float>((size_t)S_COUNT * B);
-    auto slot = [&](int i) { return slots + (size_t)i * B; };
+    const int NB = ctx->rag ? ctx->rag->B : B;      // utterances (a ragged batch runs as B = 1, T = all its frames: ragged.h)
+    float* slots = ws.get<float>((size_t)S_COUNT * NB);
+    auto slot = [&](int i) { return slots + (size_t)i * NB; };
 
     if (!dry) {
         ProfScope ps(ctx, s, dry, "filter.in+down0");
-        TVC_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)S_COUNT * B * sizeof(float), s));
+        TVC_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)S_COUNT * NB * sizeof(float), s));
         if (!cmax) {
-            TVC_CHECK(run_amax_rows(ctx, s, content, B, (long)kSslDim * T, slot(S_CONTENT)));
+            TVC_CHECK(run_amax_rows(ctx, s, content, B, kSslDim, T, slot(S_CONTENT)));
             cmax = slot(S_CONTENT);
         }
         if (!smax) {
-            TVC_CHECK(run_amax_rows(ctx, s, source, B, 16 * L, slot(S_SRC)));
-            TVC_CHECK(run_amax_rows(ctx, s, energy, B, L, slot(S_SRC)));
+            TVC_CHECK(run_amax_rows(ctx, s, source, B, 16, L, slot(S_SRC)));
+            TVC_CHECK(run_amax_rows(ctx, s, energy, B, 1, L, slot(S_SRC)));
             smax = slot(S_SRC);
         }
         EpiSumCond ep{x, ctx->flt_content_in.bias, nullptr, f0, nullptr, nullptr, ctx->flt_f_w, ctx->flt_f_b, ch[0], T, B * T};
         int rc = 0;
         if (!gemm_s2_try(&rc, ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax)) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax);
         TVC_CHECK(rc);
-        TVC_CHECK(run_amax_rows(ctx, s, x, B, (long)ch[0] * T, slot(S_X)));
+        TVC_CHECK(run_amax_rows(ctx, s, x, B, ch[0], T, slot(S_X)));
         TVC_CHECK(run_down0_split(ctx, s, ctx->flt_down0s, source, energy, skip[0], xi_pre[1], B, (int)L, smax, slot(S_SKIP0)));
     }
     // down path (xi = the 1/f-rate pick / two-sample mean of skip[i-1]: bounded by skip[i-1]'s |max|, same slot)
@@ -433,7 +467,7 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
                 EpiBias<ACT_NONE, false> ep{xlev[i], u.c5.bias, nullptr, u.cout, lo, nc, (long)u.cout * lo, 0};
                 if (u.c5.MT6 % 3 == 0) TVC_CHECK((gemm_s_launch<3, 4, 1>(ctx, s, u.c5, xu, B, C, lo, 0, ep, slot(S_UXU + i))));
                 else TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, u.c5, xu, B, C, lo, 0, ep, slot(S_UXU + i))));
-                TVC_CHECK(run_amax_rows(ctx, s, xlev[i], B, (long)u.cout * lo, slot(S_LEV + i)));
+                TVC_CHECK(run_amax_rows(ctx, s, xlev[i], B, u.cout, lo, slot(S_LEV + i)));
             }
         }
         ws.release(mk);
@@ -462,12 +496,13 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
     float* kern = kernel_out ? kernel_out : ws.get<float>((size_t)B * kBins * T);
     float* source = source_out ? source_out : ws.get<float>((size_t)B * 16 * L);
     // |max| slots shared by the stages: content (SourceNet's and FilterNet's input contraction), cat[source, energy] (FilterNet's first conv)
-    float* cmax = ws.get<float>((size_t)2 * B);
-    float* smax = cmax + B;
+    const int NB = ctx->rag ? ctx->rag->B : B;
+    float* cmax = ws.get<float>((size_t)2 * NB);
+    float* smax = cmax + NB;
     if (!dry) {
-        TVC_HIP(ctx, hipMemsetAsync(cmax, 0, (size_t)2 * B * sizeof(float), s));
-        TVC_CHECK(run_amax_rows(ctx, s, content, B, (long)kSslDim * T, cmax));
-        TVC_CHECK(run_amax_rows(ctx, s, energy, B, L, smax));
+        TVC_HIP(ctx, hipMemsetAsync(cmax, 0, (size_t)2 * NB * sizeof(float), s));
+        TVC_CHECK(run_amax_rows(ctx, s, content, B, kSslDim, T, cmax));
+        TVC_CHECK(run_amax_rows(ctx, s, energy, B, 1, L, smax));
     }
     size_t mk = ws.mark();
     {

@@ -20,8 +20,16 @@ template <bool DW, int CPT>
 static __global__ __launch_bounds__(1024) void dwconv_ln_kernel(const float* x, float* y,
                                                                const float* __restrict__ dw_w, const float* __restrict__ dw_b,
                                                                const float* __restrict__ g, const float* __restrict__ bta,
-                                                               int C, int T, int dil) {
+                                                               int C, int T, int dil, RagDev rg) {
     constexpr int NW = 16;
+    // ragged batch (ragged.h): x / y are [C][T] over the whole batch (T = row stride), utterance blockIdx.y owns columns pre[b] ... + tb[b]
+    const int rs = T;
+    long ubase = (long)blockIdx.y * C * T;
+    if (rg.tb) {
+        T = rg.tb[blockIdx.y];
+        ubase = rg.pre[blockIdx.y];
+        if ((int)blockIdx.x * 64 >= T) return;
+    }
     __shared__ float red[NW][64];
     // the per-channel constants - seven taps + bias, gamma, beta - are read by every lane of a wave alike: staged once per workgroup and
     // read back as LDS broadcasts instead of 10 vector loads per channel and thread (a thread's 24 channels: 240 of its 408 loads)
@@ -42,12 +50,11 @@ static __global__ __launch_bounds__(1024) void dwconv_ln_kernel(const float* x, 
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y;
     const int t = blockIdx.x * 64 + lane;
     const bool ok = t < T;
     const int tc = ok ? t : T - 1;
-    const float* xb = x + (long)b * C * T;
-    float* yb = y + (long)b * C * T;
+    const float* xb = x + ubase;
+    float* yb = y + ubase;
 
     int tt[7];
 #pragma unroll
@@ -61,7 +68,7 @@ static __global__ __launch_bounds__(1024) void dwconv_ln_kernel(const float* x, 
     for (int i = 0; i < CPT; ++i) {
         const int c = wave + i * NW;
         if (DW) {
-            const float* xr = xb + (long)c * T;
+            const float* xr = xb + (long)c * rs;
             float wj[7], a;
             if (STAGE) {
                 const float4 w0 = *reinterpret_cast<const float4*>(Wl + c * 8), w1 = *reinterpret_cast<const float4*>(Wl + c * 8 + 4);
@@ -76,7 +83,7 @@ static __global__ __launch_bounds__(1024) void dwconv_ln_kernel(const float* x, 
             for (int j = 0; j < 7; ++j) a = fmaf(wj[j], xr[tt[j]], a);
             v[i] = a;
         } else {
-            v[i] = xb[(long)c * T + tc];
+            v[i] = xb[(long)c * rs + tc];
         }
         sum += v[i];
     }
@@ -104,28 +111,37 @@ static __global__ __launch_bounds__(1024) void dwconv_ln_kernel(const float* x, 
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int c = wave + i * NW;
-        yb[(long)c * T + t] = fmaf((v[i] - mean) * rstd, STAGE ? Gl[0][c] : g[c], STAGE ? Gl[1][c] : bta[c]);
+        yb[(long)c * rs + t] = fmaf((v[i] - mean) * rstd, STAGE ? Gl[0][c] : g[c], STAGE ? Gl[1][c] : bta[c]);
     }
 }
 template <bool DW>
 static int dwconv_ln_launch(tvc_ctx* ctx, hipStream_t s, const float* x, float* y, const float* dw_w, const float* dw_b, const float* g,
                             const float* bta, int B, int C, int T, int dil) {
-    const dim3 grid((T + 63) / 64, B), blk(1024);
-    if (C == 384) hipLaunchKernelGGL((dwconv_ln_kernel<DW, 24>), grid, blk, 0, s, x, y, dw_w, dw_b, g, bta, C, T, dil);
-    else if (C == 128) hipLaunchKernelGGL((dwconv_ln_kernel<DW, 8>), grid, blk, 0, s, x, y, dw_w, dw_b, g, bta, C, T, dil);
+    RagDev rg;
+    TVC_CHECK(rag_view(ctx, s, 1, 0, &rg, nullptr));
+    const dim3 grid(((ctx->rag ? ctx->rag->Tlong : T) + 63) / 64, ctx->rag ? ctx->rag->B : B), blk(1024);
+    if (C == 384) hipLaunchKernelGGL((dwconv_ln_kernel<DW, 24>), grid, blk, 0, s, x, y, dw_w, dw_b, g, bta, C, T, dil, rg);
+    else if (C == 128) hipLaunchKernelGGL((dwconv_ln_kernel<DW, 8>), grid, blk, 0, s, x, y, dw_w, dw_b, g, bta, C, T, dil, rg);
     else return fail(ctx, TVC_ERR_ARG, "dwconv_ln: unsupported channel count %d", C);
     return 0;
 }
 
 // gx[b][c] = || h[b][c][:] ||_2   (one wavefront per row)
-static __global__ void grn_norm_kernel(const float* __restrict__ h, float* __restrict__ gx, long rows, int T) {
+// ragged batch (ragged.h): h is [C2][T] over the whole batch; row r = (utterance r / C2, channel r % C2) sums its own tb[b] columns
+static __global__ void grn_norm_kernel(const float* __restrict__ h, float* __restrict__ gx, long rows, int T, RagDev rg, int C2) {
     const int lane = threadIdx.x & 63;
     long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
     long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     for (long r = wave; r < rows; r += nwaves) {
         const float* p = h + r * T;
+        int n = T;
+        if (rg.tb) {
+            const int b = (int)(r / C2), c = (int)(r - (long)b * C2);
+            p = h + (long)c * T + rg.pre[b];
+            n = rg.tb[b];
+        }
         float s = 0.f;
-        for (int t = lane; t < T; t += 64) s = fmaf(p[t], p[t], s);
+        for (int t = lane; t < n; t += 64) s = fmaf(p[t], p[t], s);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) gx[r] = sqrtf(s);
@@ -170,13 +186,14 @@ int run_layernorm(tvc_ctx* ctx, hipStream_t s, float* x, const float* g, const f
 
 int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW& w, float* x, int B, int T) {
     const int C = w.C, C2 = 2 * w.C, ncols = B * T;
+    const int NB = ctx->rag ? ctx->rag->B : B;      // utterances (a ragged batch runs as B = 1, T = all its frames: ragged.h)
     size_t mk = ws.mark();
     float* y = ws.get<float>((size_t)B * C * T);
     float* h = ws.get<float>((size_t)B * C2 * T);
-    float* gx = ws.get<float>((size_t)B * C2);
-    float* nx = ws.get<float>((size_t)B * C2);
-    float* ymax = ws.get<float>((size_t)B);      // |max| slots of the two 1x1s' inputs (block-floating-point guard, conv3s.h)
-    float* hmax = ws.get<float>((size_t)B);
+    float* gx = ws.get<float>((size_t)NB * C2);
+    float* nx = ws.get<float>((size_t)NB * C2);
+    float* ymax = ws.get<float>((size_t)NB);      // |max| slots of the two 1x1s' inputs (block-floating-point guard, conv3s.h)
+    float* hmax = ws.get<float>((size_t)NB);
     ws.release(mk);
     if (dry) return 0;
     {
@@ -186,8 +203,8 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
         // the LayerNorm output is bounded by the layer's own gamma / beta whatever the data: no slot unless that bound leaves fp16's range
         const float* ym = nullptr;
         if (!(w.ln_bound < 32768.f)) {
-            TVC_HIP(ctx, hipMemsetAsync(ymax, 0, (size_t)B * sizeof(float), s));
-            TVC_CHECK(run_amax_rows(ctx, s, y, B, (long)C * T, ymax));
+            TVC_HIP(ctx, hipMemsetAsync(ymax, 0, (size_t)NB * sizeof(float), s));
+            TVC_CHECK(run_amax_rows(ctx, s, y, B, C, T, ymax));
             ym = ymax;
         }
         EpiBias<ACT_GELU, false> ep{h, w.c2.bias, nullptr, C2, T, ncols, (long)C2 * T, 0};
@@ -196,8 +213,10 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
         TVC_CHECK(rc);
     }
     {
-        hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)B * C2 * 64)), dim3(256), 0, s, h, gx, (long)B * C2, T);
-        hipLaunchKernelGGL(grn_finalize_kernel, dim3(B), dim3(256), 0, s, gx, w.grn_g, nx, C2, hmax);
+        RagDev rg;
+        TVC_CHECK(rag_view(ctx, s, 1, 0, &rg, nullptr));
+        hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)NB * C2 * 64)), dim3(256), 0, s, h, gx, (long)NB * C2, T, rg, C2);
+        hipLaunchKernelGGL(grn_finalize_kernel, dim3(NB), dim3(256), 0, s, gx, w.grn_g, nx, C2, hmax);
     }
     {
         EpiBias<ACT_NONE, true> ep{x, w.c3_bias_grn, x, C, T, ncols, (long)C * T, (long)C * T};
@@ -306,11 +325,12 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     float* lg = logits ? logits : ws.get<float>((size_t)B * kPitchClasses * T);
     // |max| slots (block-floating-point guard of the fp16 split, conv3s.h): the spectrogram and the two residual streams the output
     // projections read; the ConvNeXt layers keep their own (run_convnext)
-    float* slots = ws.get<float>((size_t)3 * B);
-    float *spec_max = slots, *xs_max = slots + B, *xp_max = slots + 2 * B;
+    const int NB = ctx->rag ? ctx->rag->B : B;      // utterances (ragged batch: B = 1, T = all frames)
+    float* slots = ws.get<float>((size_t)3 * NB);
+    float *spec_max = slots, *xs_max = slots + NB, *xp_max = slots + 2 * NB;
     if (!dry) {
-        TVC_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)3 * B * sizeof(float), s));
-        TVC_CHECK(run_amax_rows(ctx, s, spec, B, (long)kBins * T, spec_max));
+        TVC_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)3 * NB * sizeof(float), s));
+        TVC_CHECK(run_amax_rows(ctx, s, spec, B, kBins, T, spec_max));
         EpiSplit ep{xs, xp, ctx->enc_in.bias, kSslCh, kPitchCh, T, ncols};
         // 961 input rows: the last slab is clamped to row 960 (zero weights beyond)
         TVC_CHECK((gemm_s_launch_ragged<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->enc_in, spec, B, kBins, T, (long)kBins * T, ep, spec_max)));
@@ -321,7 +341,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     // stacked input 1x1: fork the pitch chain onto the context's side stream and join before returning, so its
     // small launches fill the gaps of the SSL chain instead of extending the critical path.  Each chain gets its own
     // scratch block (the per-layer mark/release scratch would alias otherwise).
-    const size_t ssl_scratch = ((size_t)B * kSslCh * T * 3 + (size_t)B * kSslCh * 4) * sizeof(float) + 4096;
+    const size_t ssl_scratch = ((size_t)B * kSslCh * T * 3 + (size_t)NB * kSslCh * 4) * sizeof(float) + (size_t)NB * 8 + 4096;
     char* ssl_blk = ws.get<char>(ssl_scratch);
     Ws wssl(ssl_blk, ssl_scratch, dry);
     hipStream_t sp = s;
@@ -333,7 +353,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     }
     for (int i = 0; i < 4; ++i) TVC_CHECK(run_convnext(ctx, sp, ws, dry, ctx->pit_mid[i], xp, B, T));
     if (!dry) {
-        TVC_CHECK(run_amax_rows(ctx, sp, xp, B, (long)kPitchCh * T, xp_max));
+        TVC_CHECK(run_amax_rows(ctx, sp, xp, B, kPitchCh, T, xp_max));
         EpiBias<ACT_NONE, false> ep{lg, ctx->pit_out.bias, nullptr, kPitchClasses, T, ncols, (long)kPitchClasses * T, 0};
         int rc = 0;
         if (!gemm_s2_try(&rc, ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep, xp_max)) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep, xp_max);
@@ -345,7 +365,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     if (!wssl.ok()) return fail(ctx, TVC_ERR_WORKSPACE, "encoder: SSL scratch block too small");
     if (dry) return 0;
     {
-        TVC_CHECK(run_amax_rows(ctx, s, xs, B, (long)kSslCh * T, xs_max));
+        TVC_CHECK(run_amax_rows(ctx, s, xs, B, kSslCh, T, xs_max));
         EpiBias<ACT_NONE, false> ep{ssl, ctx->ssl_out.bias, nullptr, kSslDim, T, ncols, (long)kSslDim * T, 0};
         int rc = 0;
         if (!gemm_s2_try(&rc, ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep, xs_max)) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep, xs_max);

@@ -99,16 +99,27 @@ __device__ __forceinline__ int bitrev6(int l) { return (int)(__brev((unsigned)l)
 // ---------------------------------------------------------------------------------------------------------------------
 // spec[b][k][t] = | sum_n hann[n] x_b[(t + 1) * 480 - 960 + n (reflected)] e^(-2 pi i k n / 1920) |, k = 0..960, t = 0..T-1
 __global__ __launch_bounds__(kFW * 64) void stft_fft_kernel(const float* __restrict__ wav, float* __restrict__ spec, const float2* __restrict__ tw960,
-                                                            const float2* __restrict__ tw1920, const float* __restrict__ hann, int L, int T) {
+                                                            const float2* __restrict__ tw1920, const float* __restrict__ hann, int L, int T, RagDev rg) {
     extern __shared__ __attribute__((aligned(16))) float2 smem_f[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2* Zb = smem_f + wave * kM;                                   // this wave's 960 bins
     float* Os = reinterpret_cast<float*>(smem_f);                      // [961][kFW] magnitudes, over the bins once every wave has read its own (61 KB: two workgroups per CU)
-    const int groups = (T + kFW - 1) / kFW;
+    // ragged batch (ragged.h): utterance b reads its own row of the caller's padded [rows][Tmax * 480] tensor over its own length (the
+    // reflection is at ITS end) and writes columns pre[b] ... of the [961][T] spectrogram of the whole batch (T = row stride)
+    const int rs = T;
+    const int groups = rg.tb ? (int)gridDim.x / rg.B : (T + kFW - 1) / kFW;
     const int b = blockIdx.x / groups, t0 = (blockIdx.x - b * groups) * kFW;
+    long wbase = (long)b * L, sbase = (long)b * kBins * T;
+    if (rg.tb) {
+        T = rg.tb[b];
+        L = T * kHop;
+        wbase = (long)rg.row[b] * rg.Tmax * kHop;
+        sbase = rg.pre[b];
+        if (t0 >= T) return;
+    }
     const int t = t0 + wave;
     if (t < T) {
-        const float* wb = wav + (long)b * L;
+        const float* wb = wav + wbase;
         const int start = (t + 1) * kHop - kNfft / 2;                  // frame t + 1 of the centred STFT (frame 0 is dropped)
         float2 v[15];
 #pragma unroll
@@ -157,16 +168,16 @@ __global__ __launch_bounds__(kFW * 64) void stft_fft_kernel(const float* __restr
     }
     __syncthreads();
     const int nf = T - t0 < kFW ? T - t0 : kFW;
-    float* sb = spec + (long)b * kBins * T + t0;
-    if (nf == kFW && (T & 3) == 0) {
+    float* sb = spec + sbase + t0;
+    if (nf == kFW && (rs & 3) == 0 && ((sbase + t0) & 3) == 0) {
         for (int i = tid; i < kBins * (kFW / 4); i += kFW * 64) {
             const int k = i / (kFW / 4), q = (i - k * (kFW / 4)) * 4;
-            *reinterpret_cast<float4*>(sb + (long)k * T + q) = *reinterpret_cast<const float4*>(Os + k * kFW + q);
+            *reinterpret_cast<float4*>(sb + (long)k * rs + q) = *reinterpret_cast<const float4*>(Os + k * kFW + q);
         }
     } else {
         for (int i = tid; i < kBins * kFW; i += kFW * 64) {
             const int k = i / kFW, f = i - k * kFW;
-            if (f < nf) sb[(long)k * T + f] = Os[i];
+            if (f < nf) sb[(long)k * rs + f] = Os[i];
         }
     }
 }
@@ -175,16 +186,32 @@ __global__ __launch_bounds__(kFW * 64) void stft_fft_kernel(const float* __restr
 // frames[(b T + t)][n] = irfft_1920(kernel[b][:, t] * exp(i angle[b][:, t]))[n]  (torch.fft.irfft semantics: 1/N, the
 // imaginary parts of bins 0 and 960 do not enter)
 __global__ __launch_bounds__(kFW * 64) void noise_ifft_kernel(const float* __restrict__ kern, const float* __restrict__ angle, float* __restrict__ frames,
-                                                              const float2* __restrict__ tw960, const float2* __restrict__ tw1920, int T) {
+                                                              const float2* __restrict__ tw960, const float2* __restrict__ tw1920, int T, RagDev rg) {
     extern __shared__ __attribute__((aligned(16))) float2 smem_f[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int YS = kBins + 1;                                      // row stride (962 float2: rows stay 16-byte aligned)
-    const int groups = (T + kFW - 1) / kFW;
+    // ragged batch (ragged.h): `kern` is [961][T] over the whole batch (utterance b at columns pre[b] ...), `angle` the caller's padded
+    // [rows][961][Tmax] tensor (as = its row stride), the frames of utterance b land behind those of the utterances before it
+    const int rs = T;
+    int as = T;
+    const int groups = rg.tb ? (int)gridDim.x / rg.B : (T + kFW - 1) / kFW;
     const int b = blockIdx.x / groups, t0 = (blockIdx.x - b * groups) * kFW;
+    long kbase = (long)b * kBins * T, abase = kbase, fbase = (long)b * T;
+    if (rg.tb) {
+        T = rg.tb[b];
+        kbase = fbase = rg.pre[b];
+        if (rg.row) {
+            as = rg.Tmax;
+            abase = (long)rg.row[b] * kBins * rg.Tmax;
+        } else {
+            abase = kbase;           // the library's own draw: laid out like `kern`
+        }
+        if (t0 >= T) return;
+    }
     const int nf = T - t0 < kFW ? T - t0 : kFW;
     {   // Y[f][k] = kernel * (cos, sin)(angle): the [961][T] tensors are read in runs of kFW frames
-        const float* kb = kern + (long)b * kBins * T + t0;
-        const float* ab = angle + (long)b * kBins * T + t0;
+        const float* kb = kern + kbase + t0;
+        const float* ab = angle + abase + t0;
         // a thread's 16 elements are requested together (clamped addresses, no branch in front of the loads), then converted
         constexpr int PER = (kBins * kFW + kFW * 64 - 1) / (kFW * 64);
         float av[PER], kv[PER];
@@ -195,8 +222,8 @@ __global__ __launch_bounds__(kFW * 64) void noise_ifft_kernel(const float* __res
             const int k = i / kFW;
             int f = i - k * kFW;
             f = f < nf ? f : nf - 1;
-            av[j] = ab[(long)k * T + f];
-            kv[j] = kb[(long)k * T + f];
+            av[j] = ab[(long)k * as + f];
+            kv[j] = kb[(long)k * rs + f];
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
@@ -237,7 +264,7 @@ __global__ __launch_bounds__(kFW * 64) void noise_ifft_kernel(const float* __res
     }
     __syncthreads();
     if (t < T) {
-        float* fr = frames + ((long)b * T + t) * kNfft;
+        float* fr = frames + (fbase + t) * kNfft;
         for (int i = lane; i < kM / 2; i += 64)                        // 4 consecutive samples per lane and store
             *reinterpret_cast<float4*>(fr + 4 * i) = *reinterpret_cast<const float4*>(Y + 2 * i);
     }
@@ -257,13 +284,17 @@ int run_stft_fft(tvc_ctx* ctx, hipStream_t s, const float* wav, float* spec, int
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "stft_fft setup: %s", hipGetErrorString(e));
         ready = true;
     }
-    const int groups = (T + kFW - 1) / kFW;
+    RagDev rg;
+    TVC_CHECK(rag_view(ctx, s, 1, 0, &rg, nullptr));
+    const int groups = ((ctx->rag ? ctx->rag->Tlong : T) + kFW - 1) / kFW;
+    if (ctx->rag) B = ctx->rag->B;
     hipLaunchKernelGGL(stft_fft_kernel, dim3((unsigned)(B * groups)), dim3(kFW * 64), lds, s, wav, spec, reinterpret_cast<const float2*>(ctx->fft_tw960),
-                       reinterpret_cast<const float2*>(ctx->fft_tw1920), ctx->fft_hann, (int)L, T);
+                       reinterpret_cast<const float2*>(ctx->fft_tw1920), ctx->fft_hann, (int)L, T, rg);
     return launch_check(ctx, "stft_fft");
 }
 
-int run_noise_ifft(tvc_ctx* ctx, hipStream_t s, const float* kern, const float* angle, float* frames, int B, int T) {
+// angle_padded (ragged batches only): `angle` is the caller's padded [rows][961][Tmax] tensor, not the batch-wide [961][T] layout
+int run_noise_ifft(tvc_ctx* ctx, hipStream_t s, const float* kern, const float* angle, float* frames, int B, int T, bool angle_padded) {
     if (!ctx->fft_tw960 || !ctx->fft_tw1920) return fail(ctx, TVC_ERR_STATE, "fft tables missing");
     static bool ready_dev[64] = {};
     bool& ready = ready_dev[ctx->device & 63];
@@ -273,9 +304,13 @@ int run_noise_ifft(tvc_ctx* ctx, hipStream_t s, const float* kern, const float* 
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "noise_ifft setup: %s", hipGetErrorString(e));
         ready = true;
     }
-    const int groups = (T + kFW - 1) / kFW;
+    RagDev rg;
+    TVC_CHECK(rag_view(ctx, s, 1, 0, &rg, nullptr));
+    if (!angle_padded) rg.row = nullptr;
+    const int groups = ((ctx->rag ? ctx->rag->Tlong : T) + kFW - 1) / kFW;
+    if (ctx->rag) B = ctx->rag->B;
     hipLaunchKernelGGL(noise_ifft_kernel, dim3((unsigned)(B * groups)), dim3(kFW * 64), lds, s, kern, angle, frames,
-                       reinterpret_cast<const float2*>(ctx->fft_tw960), reinterpret_cast<const float2*>(ctx->fft_tw1920), T);
+                       reinterpret_cast<const float2*>(ctx->fft_tw960), reinterpret_cast<const float2*>(ctx->fft_tw1920), T, rg);
     return launch_check(ctx, "noise_ifft");
 }
 

@@ -41,6 +41,7 @@ struct FilmS2Args {
     // pre_w * |max of the producer's input| + pre_b): staged by copy, amax_x = that input's slot
     const uint4* xpre;
     float pre_w, pre_b;
+    RagDev rag;            // RAG kernels (ragged.h): len / res_lin = row strides of the batch-wide tensors, tiles / extents from the table
 };
 
 // Workgroup tile 96 x 256: 8 waves side by side, each all 96 rows (WM = 3 m-tiles) of 32 columns - 144 accumulator registers of the 256 a
@@ -65,7 +66,7 @@ __device__ __forceinline__ void split8u(const float (&v)[8], uint4& p1, uint4& p
     p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
 }
 
-template <bool XPRE>
+template <bool XPRE, bool RAG = false>
 __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::NW / 4))) void film_s2_kernel(FilmS2Args a) {
     using TL = FS2;
     constexpr int MTB = TL::MTB, WM = TL::WM, NWV = TL::NWV, WN = TL::WN, NW = TL::NW, BN = TL::BN, XROW = TL::XROW, A_PER = TL::A_PER, XS = TL::XS;
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NWV, wn = wave - wm * NWV;
-    const int C = a.C, nslab = C / 16, len = a.len, dil = a.dil;
+    const int C = a.C, nslab = C / 16, rs = a.len, dil = a.dil;      // rs = row stride of x / cond / y (= every utterance's length unless RAG)
+    const int rf = a.res_lin > 0 ? rs / a.res_lin : 1;               // RAG: an utterance's low-rate length = its length / rf
     const int xw = BN + 2 * dil, nitems = 2 * xw;
 
     for (int i = tid; i < 6 * C; i += TL::NTHR) {
@@ -87,11 +89,15 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
     int tfirst, tlast;
     tile_range(a.ntiles, tfirst, tlast);
     if (tfirst >= tlast) return;
-    auto coords = [&](int v, int& mb, int& b, int& t0) __attribute__((always_inline)) {
+    // (b is also the hint of the ragged table walk; len / off = the utterance's length and first column)
+    auto coords = [&](int v, int& mb, int& b, int& t0, int& len, int& off) __attribute__((always_inline)) {
         const int nt = v / a.mblocks;
         mb = v - nt * a.mblocks;
-        b = nt / a.tiles_per_utt;
-        t0 = (nt - b * a.tiles_per_utt) * BN;
+        const RagTile rt = rag_tile<RAG>(a.rag, nt, a.tiles_per_utt, rs, b);
+        b = rt.b;
+        t0 = rt.tin * BN;
+        len = rt.len;
+        off = rt.off;
     };
 
     // this thread's two staging items: (8-channel half, column) of the conv's halo tile and of the cond tile; threads beyond the
@@ -113,18 +119,19 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
     unsigned xo[XS], co = 0;
     float xs = 1.f, cs_ = 1.f;        // of the load cursor's tile
     float rxs = 1.f, rcs = 1.f;       // of the slab in flight
-    int lv = tfirst, ls = 0, lmb, lb, lt0;
-    coords(lv, lmb, lb, lt0);
+    int lv = tfirst, ls = 0, lmb, lb = 0, lt0, llen, loff;
+    coords(lv, lmb, lb, lt0, llen, loff);
     auto tile_offsets = [&]() __attribute__((always_inline)) {
+        const int ub = RAG ? loff : 0;             // RAG: the utterance's first column rides in the lane offsets
 #pragma unroll
         for (int k = 0; k < XS; ++k) {
             int p = lt0 - dil + ic[k];
-            p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
-            xo[k] = (unsigned)(8 * ig[k] * len + p);
+            p = p < 0 ? 0 : (p > llen - 1 ? llen - 1 : p);
+            xo[k] = (unsigned)(8 * ig[k] * rs + ub + p);
         }
         int pc = lt0 + cc;
-        pc = pc > len - 1 ? len - 1 : pc;
-        co = (unsigned)(8 * cg * len + pc);
+        pc = pc > llen - 1 ? llen - 1 : pc;
+        co = (unsigned)(8 * cg * rs + ub + pc);
         xs = XPRE ? 1.f : norm_from_amax(a.amax_x[lb]).s;
         cs_ = norm_from_amax(a.amax_c[lb]).s;
     };
@@ -137,24 +144,25 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
             q = q < TL::A_PIECES ? q : TL::A_PIECES - 1;
             ar[i] = ldg_so4(abase, 16u * (unsigned)(q * 64 + lane));
         }
-        const float* xc = a.x + ((long)lb * C + (long)ls * 16) * len;
-        const float* cc_ = a.cond + ((long)lb * C + (long)ls * 16) * len;
-        if (XPRE) {      // item (8-channel half ig, column): one 16-byte load per part; xo = 8 ig len + p -> plane row 2 ls + ig, column p
-            const uint4* xp = a.xpre + ((long)lb * 2 * (C >> 3) + 2 * ls) * len;
+        const long ubase = RAG ? 0L : (long)lb * C;
+        const float* xc = a.x + (ubase + (long)ls * 16) * rs;
+        const float* cc_ = a.cond + (ubase + (long)ls * 16) * rs;
+        if (XPRE) {      // item (8-channel half ig, column): one 16-byte load per part; xo = 8 ig rs + p -> plane row 2 ls + ig, column p
+            const uint4* xp = a.xpre + ((RAG ? 0L : (long)lb * 2 * (C >> 3)) + 2 * ls) * rs;
 #pragma unroll
             for (int k = 0; k < XS; ++k) {
-                const unsigned e = xo[k] - (unsigned)(7 * ig[k] * len);            // = ig len + p
+                const unsigned e = xo[k] - (unsigned)(7 * ig[k] * rs);            // = ig rs + p
                 xq[k][0] = __builtin_bit_cast(uint4, ldg_so4(xp, 16u * e));
-                xq[k][1] = __builtin_bit_cast(uint4, ldg_so4(xp + (long)(C >> 3) * len, 16u * e));
+                xq[k][1] = __builtin_bit_cast(uint4, ldg_so4(xp + (long)(C >> 3) * rs, 16u * e));
             }
         } else {
 #pragma unroll
             for (int k = 0; k < XS; ++k)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xr[k][j] = ldg_so(xc + (long)j * len, 4u * xo[k]);
+                for (int j = 0; j < 8; ++j) xr[k][j] = ldg_so(xc + (long)j * rs, 4u * xo[k]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) cr[j] = ldg_so(cc_ + (long)j * len, 4u * co);
+        for (int j = 0; j < 8; ++j) cr[j] = ldg_so(cc_ + (long)j * rs, 4u * co);
         rxs = xs;
         rcs = cs_;
     };
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
             if (lv + 1 < tlast) {
                 ++lv;
                 ls = 0;
-                coords(lv, lmb, lb, lt0);
+                coords(lv, lmb, lb, lt0, llen, loff);
                 tile_offsets();
             } else {
                 ls = nslab - 1;       // past the last step the cursor parks on it
@@ -265,8 +273,8 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
     };
 
     // consumer cursor
-    int cv = tfirst, cs = 0, cmb, cb, ct0;
-    coords(cv, cmb, cb, ct0);
+    int cv = tfirst, cs = 0, cmb, cb = 0, ct0, len, coff;
+    coords(cv, cmb, cb, ct0, len, coff);
     float mx_run = 0.f;
     int flush_b = -1;
 
@@ -316,16 +324,16 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
                         sh[i][j][r] = 0.f;
                     }
             }
-            float* yb = a.y + ((long)cb * C + row0) * len;                // uniform; a lane adds its 32-bit offset
+            float* yb = RAG ? a.y + (long)row0 * rs + coff : a.y + ((long)cb * C + row0) * rs;                // uniform; a lane adds its 32-bit offset
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int t = ct0 + (wn * WN + j) * 32 + e31;
                 const bool live = t < len;
                 const int tc = live ? t : len - 1;
-                const unsigned off = 4u * (unsigned)(4 * eh * len + tc);
+                const unsigned off = 4u * (unsigned)(4 * eh * rs + tc);
                 if (a.res_lin > 0) {       // the residual is F.interpolate of the low-rate tensor, evaluated here
-                    const Lerp lc = lerp_coord(tc, a.res_scale, a.res_lin);
-                    const float* rb = a.res + ((long)cb * C + row0) * a.res_lin;
+                    const Lerp lc = lerp_coord(tc, a.res_scale, RAG ? len / rf : a.res_lin);
+                    const float* rb = RAG ? a.res + (long)row0 * a.res_lin + coff / rf : a.res + ((long)cb * C + row0) * a.res_lin;
                     const unsigned o0 = 4u * (unsigned)(4 * eh * a.res_lin + lc.i0), o1 = 4u * (unsigned)(4 * eh * a.res_lin + lc.i1);
 #pragma unroll
                     for (int h8 = 0; h8 < 2; ++h8) {
@@ -340,10 +348,10 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
                         for (int r = 0; r < 8; ++r) hi[i][j][8 * h8 + r] = __fadd_rn(hi[i][j][8 * h8 + r], lerp_eval(lc, x0[r], x1[r]));
                     }
                 } else {
-                    const float* rb = a.res + ((long)cb * C + row0) * len;
+                    const float* rb = RAG ? a.res + (long)row0 * rs + coff : a.res + ((long)cb * C + row0) * rs;
                     float rv[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = ldg_so(rb + (long)((r & 3) + 8 * (r >> 2)) * len, off);
+                    for (int r = 0; r < 16; ++r) rv[r] = ldg_so(rb + (long)((r & 3) + 8 * (r >> 2)) * rs, off);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hi[i][j][r] = __fadd_rn(hi[i][j][r], rv[r]);
                 }
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
                 for (int r = 0; r < 16; ++r) {
                     const float e = hi[i][j][r];
                     if (live) {
-                        stg_so(yb + (long)((r & 3) + 8 * (r >> 2)) * len, off, e);
+                        stg_so(yb + (long)((r & 3) + 8 * (r >> 2)) * rs, off, e);
                         mx_run = fmaxf(mx_run, fabsf(e));
                     }
                     hi[i][j][r] = 0.f;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
             const int done_b = cb;
             ++cv;
             const bool last = cv >= tlast;
-            if (!last) coords(cv, cmb, cb, ct0);
+            if (!last) coords(cv, cmb, cb, ct0, len, coff);
             if (a.amax_y && (last || cb != done_b)) {          // the workgroup leaves utterance done_b: the waves' maxima meet in LDS,
                 const float m = wave_max(mx_run);              // one thread publishes them behind the next barrier
                 if (lane == 0) red[wave] = m;
@@ -406,6 +414,8 @@ inline bool film_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const FilmU& fu, c
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FS2::lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS2::lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS2::lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS2::lds_bytes);
         if (e != hipSuccess) {
             *rc = fail(ctx, TVC_ERR_HIP, "film_s2 setup: %s", hipGetErrorString(e));
             return true;
@@ -434,8 +444,19 @@ inline bool film_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const FilmU& fu, c
     a.pre_b = pre_b;
     a.amax_c = bfp.c;
     a.amax_y = bfp.y;
+    if (ctx->rag) {
+        // ragged batch (ragged.h): the driver passed B = 1 and len = the batch's columns at this rate (= the row stride)
+        if (B != 1 || len % ctx->rag->Ttot != 0) { *rc = fail(ctx, TVC_ERR_STATE, "film_s2: a ragged batch runs as one long utterance"); return true; }
+        int ncol = 0;
+        *rc = rag_view(ctx, s, len / ctx->rag->Ttot, FS2::BN, &a.rag, &ncol);
+        if (*rc) return true;
+        a.ntiles = ncol * a.mblocks;
+    }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
-    if (pre) hipLaunchKernelGGL(film_s2_kernel<true>, dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
+    if (ctx->rag) {
+        if (pre) hipLaunchKernelGGL((film_s2_kernel<true, true>), dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
+        else hipLaunchKernelGGL((film_s2_kernel<false, true>), dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
+    } else if (pre) hipLaunchKernelGGL(film_s2_kernel<true>, dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
     else hipLaunchKernelGGL(film_s2_kernel<false>, dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
     *rc = launch_check(ctx, "film_s2");
     return true;

@@ -60,6 +60,8 @@ struct Up24SArgs {
     const float* amax_x;
     const float* amax_c;
     float* amax_y;
+    RagDev rag;          // RAG kernels (ragged.h): `len` = row stride of the batch-wide tensors, tiles / extents from the table; the second half
+                         // writes utterance b's waveform to row rag.row[b] of the caller's padded [rows][Tmax * 480] output
 };
 
 // two fp16 parts of 4 fp32 values (8 bytes each)
@@ -109,7 +111,7 @@ __device__ __forceinline__ void conv24_phase(f32x16& hi, f32x16& lo, const u32x4
     }
 }
 
-template <class CF>
+template <class CF, bool RAG>
 __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE))) void up24s_kernel(Up24SArgs a) {
     constexpr int C = CF::C, W = CF::W, D1 = CF::D1, D2 = CF::D2, H = CF::H, E = CF::E, NT = CF::NT;
     constexpr int XP = CF::XP, HP = CF::HP, PS = CF::PS, XW = CF::XW, XPER = CF::XPER;
@@ -121,8 +123,10 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     float* R = Fl + CF::FL;                                       // [24][PS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int len = a.len;
-    const int lin = CF::SECOND ? len : len / a.xf;
+    const int rs = a.len;                                  // row stride of cond / x1 (= every utterance's length unless RAG)
+    const int rsl = CF::SECOND ? rs : rs / a.xf;           // row stride of the input x
+    int bh = 0;                                            // RAG: utterance hint of the table walk
+    auto utt = [&](int tile) __attribute__((always_inline)) { return rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh).b; };
 
     // ---- once per workgroup: weights and biases -> LDS -------------------------------------------------
     for (int i = tid; i < CF::PIECES * 64 + 304 / 4; i += NT) Wt[i] = a.img[i];
@@ -142,25 +146,26 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         ig8[i] = 8 * (g > 2 ? 2 : g);
     }
     auto fetch = [&](int tile) __attribute__((always_inline)) {
-        const int b = tile / a.tiles_per_utt;
-        const int px0 = (tile - b * a.tiles_per_utt) * W - E - H;
-        const float* xb = a.x + (long)b * C * lin;
+        const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
+        const int len = rt.len, lin = CF::SECOND ? len : len / a.xf;         // this utterance's extents (output rate / input rate)
+        const int px0 = rt.tin * W - E - H;
+        const float* xb = RAG ? a.x + (CF::SECOND ? rt.off : rt.off / a.xf) : a.x + (long)rt.b * C * rsl;
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
             int p = px0 + ic[i];
             p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
             if (CF::SECOND) {
-                const unsigned o = 4u * (unsigned)(ig8[i] * lin + p);
+                const unsigned o = 4u * (unsigned)(ig8[i] * rsl + p);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xb + (long)j * lin, o);
+                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xb + (long)j * rsl, o);
             } else {
                 const Lerp lc = lerp_coord(p, a.interp_scale, lin);
                 lam[i] = lc.w1;
-                const unsigned o0 = 4u * (unsigned)(ig8[i] * lin + lc.i0), o1 = 4u * (unsigned)(ig8[i] * lin + lc.i1);
+                const unsigned o0 = 4u * (unsigned)(ig8[i] * rsl + lc.i0), o1 = 4u * (unsigned)(ig8[i] * rsl + lc.i1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    xr0[i][j] = ldg_so(xb + (long)j * lin, o0);
-                    xr1[i][j] = ldg_so(xb + (long)j * lin, o1);
+                    xr0[i][j] = ldg_so(xb + (long)j * rsl, o0);
+                    xr1[i][j] = ldg_so(xb + (long)j * rsl, o1);
                 }
             }
         }
@@ -198,16 +203,19 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     int tile, tend;
     tile_range(a.ntiles, tile, tend);
     if (tile < tend) {
+        bh = utt(tile);
         fetch(tile);
-        deposit(bfp_load(a.amax_x, tile / a.tiles_per_utt).s);
+        deposit(bfp_load(a.amax_x, bh).s);
     }
     slab_barrier();
     const float wsa = Fl[297], wsb = Fl[298], wssc = Fl[299], wssh = Fl[300], wl1 = Fl[301], bamax = Fl[302];
     float mx_run = 0.f;
-    int mx_b = tile < tend ? tile / a.tiles_per_utt : 0;
+    int mx_b = bh;
 
     for (; tile < tend; ++tile) {
-        const int b = tile / a.tiles_per_utt;
+        const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
+        const int b = rt.b, len = rt.len;
+        bh = b;
         if (!CF::SECOND && a.amax_y && b != mx_b) {
             amax_flush_wg(a.amax_y + mx_b, mx_run, Fl + 304);
             mx_run = 0.f;
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         // bounded by sum|w_a| * amax_x + max|b_a| (never measured: it does not leave the CU)
         const Bfp sx = bfp_load(a.amax_x, b), sc = bfp_load(a.amax_c, b);
         const Bfp sh_ = a.amax_x ? bfp_from_amax(fmaf(wl1, a.amax_x[b], bamax)) : Bfp{1.f, 1.f};
-        const int t0 = (tile - b * a.tiles_per_utt) * W;
+        const int t0 = rt.tin * W;
         const int ph0 = t0 - E - D2;      // position of Hs column 0
         const int p20 = t0 - E;           // position of second-conv column 0
         const int next = tile + 1;
@@ -226,14 +234,14 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         // step 1 = channels 16 + j for lh = 0 (the other half is the zero unit)
         float cr0[8], cr1[8];
         if (wave < CF::NT2) {
-            const float* cb = a.cond + (long)b * C * len;
+            const float* cb = RAG ? a.cond + rt.off : a.cond + (long)b * C * rs;
             int t = p20 + wave * 32 + l31;
             t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
-            const unsigned o0 = 4u * (unsigned)(8 * lh * len + t), o1 = 4u * (unsigned)t;
+            const unsigned o0 = 4u * (unsigned)(8 * lh * rs + t), o1 = 4u * (unsigned)t;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                cr0[j] = ldg_so(cb + (long)j * len, o0);
-                cr1[j] = ldg_so(cb + (long)(16 + j) * len, o1);
+                cr0[j] = ldg_so(cb + (long)j * rs, o0);
+                cr1[j] = ldg_so(cb + (long)(16 + j) * rs, o1);
             }
         }
         if (next < tend) fetch(next);   // lands in registers during the whole tile
@@ -323,8 +331,8 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 lsc = TVC_MFMA16(fa[0][0], cf[s][1], lsc);
                 lsh = TVC_MFMA16(fa[1][0], cf[s][1], lsh);
             }
-            float* ob = CF::SECOND ? nullptr : a.out + (long)b * C * len;
-            const unsigned oo = 4u * (unsigned)(4 * lh * len + t);
+            float* ob = CF::SECOND ? nullptr : (RAG ? a.out + rt.off : a.out + (long)b * C * rs);
+            const unsigned oo = 4u * (unsigned)(4 * lh * rs + t);
             float mx = 0.f;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                     if (CF::SECOND)
                         R[m * PS + n] = v;                                     // x2 stays on chip
                     else if (n < W && t < len) {
-                        stg_so(ob + (long)(8 * g + q) * len, oo, v);           // x1 (uniform row base + lane offset)
+                        stg_so(ob + (long)(8 * g + q) * rs, oo, v);            // x1 (uniform row base + lane offset)
                         mx = fmaxf(mx, fabsf(v));
                     }
                 }
@@ -398,12 +406,13 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 }
                 const int o = 4 * g + part;                  // lanes 0..3 of a group store outputs 4g..4g+3
                 const float v = part == 0 ? o4[0] : (part == 1 ? o4[1] : (part == 2 ? o4[2] : o4[3]));
-                if (part < 4 && o < W && t0 + o < len) a.out[(long)b * len + t0 + o] = v + W7[168];
+                float* wrow = RAG ? a.out + (long)a.rag.row[b] * a.rag.Tmax * kHop : a.out + (long)b * rs;
+                if (part < 4 && o < W && t0 + o < len) wrow[t0 + o] = v + W7[168];
             }
         }
         // ---- next tile's input: registers -> LDS ----------------------------------------------------------
         slab_barrier();                                   // every wave is done with Xs, Hs and R
-        if (next < tend) deposit(bfp_load(a.amax_x, next / a.tiles_per_utt).s);
+        if (next < tend) deposit(bfp_load(a.amax_x, utt(next)).s);
         slab_barrier();
     }
     if (!CF::SECOND && a.amax_y && tend > (int)((long)a.ntiles * blockIdx.x / gridDim.x)) amax_flush_wg(a.amax_y + mx_b, mx_run, Fl + 304);
@@ -417,7 +426,8 @@ static int launch_up24s(tvc_ctx* ctx, hipStream_t s, Up24SArgs a, int B) {
     if (!ncu) {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)up24s_kernel<CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)up24s_kernel<CF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)up24s_kernel<CF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "up24s setup: %s", hipGetErrorString(e));
         ncu = prop.multiProcessorCount;
     }
@@ -425,8 +435,13 @@ static int launch_up24s(tvc_ctx* ctx, hipStream_t s, Up24SArgs a, int B) {
     a.ntiles = a.tiles_per_utt * B;
     static_assert(CF::WGS_PER_CU * CF::LDS_BYTES <= 160 * 1024, "LDS for the workgroups that share a CU");
     const int slots = ncu * CF::WGS_PER_CU;
+    if (ctx->rag) {
+        if (B != 1 || a.len != ctx->rag->Ttot * kHop) return fail(ctx, TVC_ERR_STATE, "up24s: a ragged batch runs as one long utterance");
+        TVC_CHECK(rag_view(ctx, s, kHop, CF::W, &a.rag, &a.ntiles));
+    }
     int grid = a.ntiles < slots ? a.ntiles : slots;
-    hipLaunchKernelGGL((up24s_kernel<CF>), dim3(grid), dim3(CF::NT), lds, s, a);
+    if (ctx->rag) hipLaunchKernelGGL((up24s_kernel<CF, true>), dim3(grid), dim3(CF::NT), lds, s, a);
+    else hipLaunchKernelGGL((up24s_kernel<CF, false>), dim3(grid), dim3(CF::NT), lds, s, a);
     return launch_check(ctx, "up24s");
 }
 
@@ -476,8 +491,10 @@ struct Down0SArgs {
     int len, tiles_per_utt, ntiles;
     const float* amax_x;   // per-utterance |max| of cat[source, energy] (block-floating-point guard, conv3s.h), nullable
     float* amax_y;         // ... of the output (written), nullable
+    RagDev rag;            // RAG kernels (ragged.h): `len` = row stride of the batch-wide tensors, tiles / extents from the table
 };
 
+template <bool RAG>
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void down0s_kernel(Down0SArgs a) {
     constexpr int W = 254, XW = 256, XP = XW, NT = 512;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_d[];
@@ -486,22 +503,25 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
     float* Bi = reinterpret_cast<float*>(Wt + 10 * 64);        // bias [32] ([31] = weight scale), [32..39] = |max| exchange
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int len = a.len;
+    const int rs = a.len;                // row stride (= every utterance's length unless RAG)
     for (int i = tid; i < 10 * 64 + 8; i += NT) Wt[i] = a.img[i];
 
     // staging: thread -> (group tid >> 8 of the 16 source rows, column tid & 255); threads 0..255 also carry the energy row
     const int g = tid >> 8, c = tid & 255;
     float xa[8], xe = 0.f;
+    int bh = 0;                          // RAG: utterance hint of the table walk
     auto fetch = [&](int tile) __attribute__((always_inline)) {
-        const int b = tile / a.tiles_per_utt;
-        int p = (tile - b * a.tiles_per_utt) * W - 1 + c;
+        const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
+        const int b = rt.b, len = rt.len;
+        int p = rt.tin * W - 1 + c;
         p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
-        const float* sb = a.source + (long)b * 16 * len;
-        const unsigned o = 4u * (unsigned)(8 * g * len + p);
+        const float* sb = RAG ? a.source + rt.off : a.source + (long)b * 16 * rs;
+        const unsigned o = 4u * (unsigned)(8 * g * rs + p);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xa[j] = ldg_so(sb + (long)j * len, o);
-        xe = ldg_so(a.energy + (long)b * len, 4u * (unsigned)p);
+        for (int j = 0; j < 8; ++j) xa[j] = ldg_so(sb + (long)j * rs, o);
+        xe = ldg_so(RAG ? a.energy + rt.off : a.energy + (long)b * rs, 4u * (unsigned)p);
     };
+    auto utt = [&](int tile) __attribute__((always_inline)) { return rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh).b; };
     auto deposit = [&](int buf, float xs) __attribute__((always_inline)) {
         u32x4* X = Xs + buf * 6 * XP;
 #pragma unroll
@@ -521,24 +541,27 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
     int tile, tend, cur = 0;                             // a contiguous range of tiles per workgroup (amax_flush_wg, conv3s.h)
     tile_range(a.ntiles, tile, tend);
     if (tile >= tend) return;
+    bh = utt(tile);
     fetch(tile);
-    deposit(0, bfp_load(a.amax_x, tile / a.tiles_per_utt).s);
+    deposit(0, bfp_load(a.amax_x, bh).s);
     if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
-    const int len2 = len / 5;
+    const int len2 = rs / 5;             // row stride of the 1/5-rate copy
     const float cw = Bi[31];
     float mx_run = 0.f;
-    int mx_b = tile / a.tiles_per_utt;
+    int mx_b = bh;
     for (; tile < tend; ++tile, cur ^= 1) {
-        const int b = tile / a.tiles_per_utt;
+        const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
+        const int b = rt.b, len = rt.len;
+        bh = b;
         if (a.amax_y && b != mx_b) {
             amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 32);
             mx_run = 0.f;
             mx_b = b;
         }
-        const int t0 = (tile - b * a.tiles_per_utt) * W;
+        const int t0 = rt.tin * W;
         const int next = tile + 1, next2 = next + 1;
-        if (next < tend) deposit(cur ^ 1, bfp_load(a.amax_x, next / a.tiles_per_utt).s);            // tile i + 1 (requested one tile ago) -> the other buffer
+        if (next < tend) deposit(cur ^ 1, bfp_load(a.amax_x, utt(next)).s);            // tile i + 1 (requested one tile ago) -> the other buffer
         if (next2 < tend) fetch(next2);               // tile i + 2 flies across this tile
         f32x16 acc, alo;
 #pragma unroll
@@ -549,8 +572,9 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
         const int t = t0 + n;
         float mx = 0.f;
         if (n < W && t < len) {
-            float* ob = a.out + (long)b * 24 * len;
-            const unsigned oo = 4u * (unsigned)(4 * lh * len + t);
+            float* ob = RAG ? a.out + rt.off : a.out + (long)b * 24 * rs;
+            float* y2b = a.y2 ? (RAG ? a.y2 + rt.off / 5 : a.y2 + (long)b * 24 * len2) : nullptr;
+            const unsigned oo = 4u * (unsigned)(4 * lh * rs + t);
             const int q5 = t / 5;
             const bool pick = a.y2 != nullptr && t - 5 * q5 == 2;
 #pragma unroll
@@ -559,9 +583,9 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float v = comb(acc[4 * gg + q], alo[4 * gg + q], cc, ccl) + bv[q];
-                    stg_so(ob + (long)(8 * gg + q) * len, oo, v);
+                    stg_so(ob + (long)(8 * gg + q) * rs, oo, v);
                     mx = fmaxf(mx, fabsf(v));
-                    if (pick) a.y2[((long)b * 24 + 8 * gg + 4 * lh + q) * len2 + q5] = v;
+                    if (pick) y2b[(long)(8 * gg + 4 * lh + q) * len2 + q5] = v;
                 }
             }
         }
@@ -582,14 +606,20 @@ int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float*
     if (!ncu) {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)down0s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)down0s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)down0s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "down0s setup: %s", hipGetErrorString(e));
         ncu = prop.multiProcessorCount;
     }
-    Down0SArgs a{source, energy, out, y2, reinterpret_cast<const u32x4*>(blob), len, (len + 253) / 254, 0, amax_x, amax_y};
+    Down0SArgs a{source, energy, out, y2, reinterpret_cast<const u32x4*>(blob), len, (len + 253) / 254, 0, amax_x, amax_y, RagDev{}};
     a.ntiles = a.tiles_per_utt * B;
+    if (ctx->rag) {
+        if (B != 1 || len != ctx->rag->Ttot * kHop) return fail(ctx, TVC_ERR_STATE, "down0s: a ragged batch runs as one long utterance");
+        TVC_CHECK(rag_view(ctx, s, kHop, 254, &a.rag, &a.ntiles));
+    }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
-    hipLaunchKernelGGL(down0s_kernel, dim3(grid), dim3(512), lds, s, a);
+    if (ctx->rag) hipLaunchKernelGGL(down0s_kernel<true>, dim3(grid), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(down0s_kernel<false>, dim3(grid), dim3(512), lds, s, a);
     return launch_check(ctx, "down0s");
 }
 
@@ -615,6 +645,7 @@ struct Down24FArgs {
     float b1_w, b1_b, b2_w, b2_b;      // |h1| <= b1_w |xi|max + b1_b, |h2| <= b2_w |h1|bound + b2_b
     const float* amax_x;   // per-utterance |max| of xi (read, nullable), of out (written, nullable)
     float* amax_y;
+    RagDev rag;            // RAG kernels (ragged.h): `len` = row stride of the batch-wide tensors, tiles / extents from the table
 };
 struct D24F {
     static constexpr int W = 244, XW = W + 14, XP = 264, HP = 256, NT = 512;
@@ -622,6 +653,7 @@ struct D24F {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
+template <bool RAG>
 static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu(2))) void down24f_kernel(Down24FArgs a) {
     constexpr int W = D24F::W, XW = D24F::XW, XP = D24F::XP, HP = D24F::HP, NT = D24F::NT;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_df[];
@@ -635,7 +667,9 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
     float* Bi = reinterpret_cast<float*>(Wr + 8 * 64);         // the three blobs' 64 floats (bias, [62 + mt] = scales), then the |max| exchange
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int len = a.len;
+    const int rs = a.len;                // row stride (= every utterance's length unless RAG)
+    int bh = 0;                          // RAG: utterance hint of the table walk
+    auto utt = [&](int tile) __attribute__((always_inline)) { return rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh).b; };
     for (int i = tid; i < 10 * 64; i += NT) {
         W1[i] = a.img1[i];
         W2[i] = a.img2[i];
@@ -651,9 +685,10 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
     // staging items (8-channel group, column): 3 * XW = 774, two per thread
     float xa[2][8];
     auto fetch = [&](int tile) __attribute__((always_inline)) {
-        const int b = tile / a.tiles_per_utt;
-        const int px0 = (tile - b * a.tiles_per_utt) * W - 7;
-        const float* xb = a.x + (long)b * 24 * len;
+        const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
+        const int len = rt.len;
+        const int px0 = rt.tin * W - 7;
+        const float* xb = RAG ? a.x + rt.off : a.x + (long)rt.b * 24 * rs;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * NT;
@@ -662,9 +697,9 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
             g = g > 2 ? 2 : g;                                 // idle items load a valid address
             int p = px0 + c;
             p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
-            const unsigned o = 4u * (unsigned)(8 * g * len + p);
+            const unsigned o = 4u * (unsigned)(8 * g * rs + p);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xa[i][j] = ldg_so(xb + (long)j * len, o);
+            for (int j = 0; j < 8; ++j) xa[i][j] = ldg_so(xb + (long)j * rs, o);
         }
     };
     auto deposit = [&](int buf, float xs) __attribute__((always_inline)) {
@@ -723,23 +758,26 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
     int tile, tend, cur = 0;
     tile_range(a.ntiles, tile, tend);
     if (tile >= tend) return;
+    bh = utt(tile);
     fetch(tile);
-    deposit(0, bfp_load(a.amax_x, tile / a.tiles_per_utt).s);
+    deposit(0, bfp_load(a.amax_x, bh).s);
     if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
-    const int len2 = len >> 2;
+    const int len2 = rs >> 2;            // row stride of the 1/4-rate copy
     float mx_run = 0.f;
-    int mx_b = tile / a.tiles_per_utt;
+    int mx_b = bh;
     for (; tile < tend; ++tile, cur ^= 1) {
-        const int b = tile / a.tiles_per_utt;
+        const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
+        const int b = rt.b, len = rt.len;
+        bh = b;
         if (a.amax_y && b != mx_b) {
             amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 192);
             mx_run = 0.f;
             mx_b = b;
         }
-        const int t0 = (tile - b * a.tiles_per_utt) * W;
+        const int t0 = rt.tin * W;
         const int next = tile + 1, next2 = next + 1;
-        if (next < tend) deposit(cur ^ 1, bfp_load(a.amax_x, next / a.tiles_per_utt).s);   // tile i + 1 (requested one tile ago) -> the other buffer
+        if (next < tend) deposit(cur ^ 1, bfp_load(a.amax_x, utt(next)).s);   // tile i + 1 (requested one tile ago) -> the other buffer
         if (next2 < tend) fetch(next2);                        // tile i + 2 flies across this tile
         const Sc sc = scales(b);
         const int n = wave * 32 + l31;                         // this lane's column of every conv's tile
@@ -749,12 +787,12 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
         // down_res's B fragments (xi at the output position, raw), requested before the first multiply
         float xq0[8], xq1[8];
         {
-            const float* xb2 = a.x + (long)b * 24 * len;
-            const unsigned o0 = 4u * (unsigned)(8 * lh * len + tc), o1 = 4u * (unsigned)tc;
+            const float* xb2 = RAG ? a.x + rt.off : a.x + (long)b * 24 * rs;
+            const unsigned o0 = 4u * (unsigned)(8 * lh * rs + tc), o1 = 4u * (unsigned)tc;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                xq0[j] = ldg_so(xb2 + (long)j * len, o0);                // K16 step 0: channels 8 lh + j
-                xq1[j] = ldg_so(xb2 + (long)(16 + j) * len, o1);         // step 1: channels 16 + j on lh = 0, the zero unit on lh = 1
+                xq0[j] = ldg_so(xb2 + (long)j * rs, o0);                // K16 step 0: channels 8 lh + j
+                xq1[j] = ldg_so(xb2 + (long)(16 + j) * rs, o1);         // step 1: channels 16 + j on lh = 0, the zero unit on lh = 1
             }
         }
         // ---- c1: Xs -> H1 (position t0 - 6 + n needs xi at t0 - 7 + n + tap) ---------------------------------------------------
@@ -837,8 +875,9 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
         }
         float mx = 0.f;
         {
-            float* ob = a.out + (long)b * 48 * len;
-            const unsigned oo = 4u * (unsigned)(4 * lh * len + tc);
+            float* ob = RAG ? a.out + rt.off : a.out + (long)b * 48 * rs;
+            float* y2b = a.y2 ? (RAG ? a.y2 + (rt.off >> 2) : a.y2 + (long)b * 48 * len2) : nullptr;
+            const unsigned oo = 4u * (unsigned)(4 * lh * rs + tc);
             const bool pair = a.y2 != nullptr && (t & 3) == 1 && t + 1 < len;      // 1/4-rate copy: mean of samples 4 d + 1, 4 d + 2
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -853,9 +892,9 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
                         const float vn = __shfl_down(v, 1);                        // sample t + 1 (same tile: W % 4 == 0)
                         const int m = 32 * mt + 8 * g + 4 * lh + q;
                         if (live) {
-                            stg_so(ob + (long)(32 * mt + 8 * g + q) * len, oo, v);
+                            stg_so(ob + (long)(32 * mt + 8 * g + q) * rs, oo, v);
                             mx = fmaxf(mx, fabsf(v));
-                            if (pair) a.y2[((long)b * 48 + m) * len2 + (t >> 2)] = fmaf(0.5f, v, __fmul_rn(0.5f, vn));
+                            if (pair) y2b[(long)m * len2 + (t >> 2)] = fmaf(0.5f, v, __fmul_rn(0.5f, vn));
                         }
                     }
                 }
@@ -878,7 +917,8 @@ int run_down24_fused(tvc_ctx* ctx, hipStream_t s, const DownW& d, const float* x
     if (!ncu) {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)down24f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, D24F::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)down24f_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, D24F::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)down24f_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, D24F::LDS_BYTES);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "down24f setup: %s", hipGetErrorString(e));
         ncu = prop.multiProcessorCount;
     }
@@ -899,8 +939,13 @@ int run_down24_fused(tvc_ctx* ctx, hipStream_t s, const DownW& d, const float* x
     a.b2_b = d.b2_b;
     a.amax_x = amax_xi;
     a.amax_y = amax_out;
+    if (ctx->rag) {
+        if (B != 1 || len != ctx->rag->Ttot * (kHop / 5)) return fail(ctx, TVC_ERR_STATE, "down24f: a ragged batch runs as one long utterance");
+        TVC_CHECK(rag_view(ctx, s, kHop / 5, D24F::W, &a.rag, &a.ntiles));
+    }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
-    hipLaunchKernelGGL(down24f_kernel, dim3(grid), dim3(D24F::NT), D24F::LDS_BYTES, s, a);
+    if (ctx->rag) hipLaunchKernelGGL(down24f_kernel<true>, dim3(grid), dim3(D24F::NT), D24F::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(down24f_kernel<false>, dim3(grid), dim3(D24F::NT), D24F::LDS_BYTES, s, a);
     return launch_check(ctx, "down24f");
 }
 

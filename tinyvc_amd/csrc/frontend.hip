@@ -34,10 +34,50 @@ static __global__ void energy_pool_kernel(const float* __restrict__ wav, float* 
     }
 }
 
+// ragged batch (ragged.h): utterance b = blockIdx.y pools its own row of the caller's padded tensor over its own length into
+// e[eoff(b) ...] (eoff(b) = floor(7.5 pre[b]): the pooled lengths floor(7.5 tb) of the utterances before it fit in front), then
+// F.interpolate(e_b, L_b) lands at samples pre[b] * 480 ... of the batch-wide energy row
+static __global__ __launch_bounds__(256) void energy_rag_kernel(const float* __restrict__ wav, float* __restrict__ e, float* __restrict__ energy, RagDev rg, int phase) {
+    const int b = blockIdx.y;
+    const int T = rg.tb[b], L = T * kHop, ne = (L + 2 * 32 - 128) / 64 + 1;
+    float* eb = e + (15L * rg.pre[b]) / 2;
+    if (phase == 0) {
+        const float* x = wav + (long)rg.row[b] * rg.Tmax * kHop;
+        const int lane = threadIdx.x & 63;
+        const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+        for (int j = wave; j < ne; j += nwaves) {
+            const int lo = 64 * j - 32;
+            float m = -INFINITY;
+            for (int k = lane; k < 128; k += 64) {
+                const int p = lo + k;
+                if (p >= 0 && p < L) m = fmaxf(m, fabsf(x[p]));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0) eb[j] = m;
+        }
+    } else {
+        const float scale = __fdiv_rn((float)ne, (float)L);      // F.interpolate(e, L): `size` given -> scale = float(in) / float(out)
+        float* y = energy + (long)rg.pre[b] * kHop;
+        for (int d = blockIdx.x * blockDim.x + threadIdx.x; d < L; d += gridDim.x * blockDim.x) {
+            const Lerp c = lerp_coord(d, scale, ne);
+            y[d] = lerp_eval(c, eb[c.i0], eb[c.i1]);
+        }
+    }
+}
+
 int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, float* energy, int B, int64_t L) {
     const int ne = (int)((L + 2 * 32 - 128) / 64 + 1);
-    float* e = ws.get<float>((size_t)B * ne);
+    float* e = ws.get<float>((size_t)B * ne + 8);
     if (dry) return 0;
+    if (ctx->rag) {
+        RagDev rg;
+        TVC_CHECK(rag_view(ctx, s, kHop, 0, &rg, nullptr));
+        const int gx = ctx->rag->B >= 32 ? 8 : 64;
+        hipLaunchKernelGGL(energy_rag_kernel, dim3(gx, ctx->rag->B), dim3(256), 0, s, wav, e, energy, rg, 0);
+        hipLaunchKernelGGL(energy_rag_kernel, dim3(gx * 4, ctx->rag->B), dim3(256), 0, s, wav, e, energy, rg, 1);
+        return launch_check(ctx, "energy (ragged)");
+    }
     hipLaunchKernelGGL(energy_pool_kernel, dim3(grid_for((long)B * ne * 64)), dim3(256), 0, s, wav, e, B, (int)L, ne);
     // F.interpolate(e, L): `size` given -> scale = float(in) / float(out)
     float scale = (float)ne / (float)L;

@@ -37,6 +37,7 @@ struct Gemm2Args {
     int Cin, T, ncols;     // ncols = B * T
     const float* kscale;   // SCALED: [B][Cin] factor applied to the input while it is staged
     int ncoltiles, mblocks, vtiles;
+    const int* col2b;      // ragged batch (ragged.h; B = 1, T = all frames): frame -> utterance, for the per-utterance scalars (amax_x, kscale); else nullptr
 };
 
 template <int NWV_, int WN_>
@@ -100,9 +101,10 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
             int p = n0 + c;
             p = p < a.ncols ? p : a.ncols - 1;               // columns past the end are computed, never stored
             const int b = p / a.T, t = p - b * a.T;
+            const int bu = a.col2b ? a.col2b[p] : b;         // whose |max| slot and GRN factors
             xo[i] = (unsigned)b * a.xstride + (unsigned)(gk * 8 * a.T + t);
-            ko[i] = (unsigned)(b * a.Cin + gk * 8);
-            xsc[i] = bfp_load(a.amax_x, b).s;
+            ko[i] = (unsigned)(bu * a.Cin + gk * 8);
+            xsc[i] = bfp_load(a.amax_x, bu).s;
         }
     };
     int lv = next_valid(blockIdx.x), ls = 0, lmt0 = 0, ln0 = 0;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(2 * NWV * 64) void gemm_s2_kernel(Gemm2Args a, Epi 
                 for (int j = 0; j < WN; ++j) {
                     const int n = cn0 + (wn * WN + j) * 32 + l31;
                     const int nc = n < a.ncols ? n : a.ncols - 1;
-                    const float c = cw * bfp_load(a.amax_x, nc / a.T).inv, cl = c * kLoInv;
+                    const float c = cw * bfp_load(a.amax_x, a.col2b ? a.col2b[nc] : nc / a.T).inv, cl = c * kLoInv;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float v[4] = {comb(hi[i][j][4 * q], lo[i][j][4 * q], c, cl), comb(hi[i][j][4 * q + 1], lo[i][j][4 * q + 1], c, cl),
@@ -299,6 +301,11 @@ inline int gemm_s2_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const
     a.mblocks = w.MT6 / TL::MTB;
     a.ncoltiles = (a.ncols + TL::BN - 1) / TL::BN;
     a.vtiles = (a.ncoltiles + 7) / 8 * 8 * a.mblocks;
+    a.col2b = nullptr;
+    if (ctx->rag) {
+        if (B != 1 || T != ctx->rag->Ttot) return fail(ctx, TVC_ERR_STATE, "gemm_s2: a ragged batch runs as one long utterance at the frame rate");
+        a.col2b = ctx->rag->d_col2b;
+    }
     const int slots = ncu / 8 * 8;       // one persistent workgroup per CU, a multiple of 8 (XCD walk)
     dim3 g((unsigned)(a.vtiles < slots ? a.vtiles : slots));
     hipLaunchKernelGGL((gemm_s2_kernel<NWV, WN, Epi, SCALED>), g, dim3(TL::NTHR), TL::lds_bytes, s, a, ep);

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/tinyvc_hip.h"
+#include "ragged.h"
 
 namespace tvc {
 
@@ -103,6 +104,7 @@ struct tvc_ctx {
     };
     std::vector<Lane> lanes;
     hipEvent_t ev_ragged = nullptr;
+    tvc::RagHost* rag = nullptr;              // the ragged batch the drivers are currently running for (ragged.h); nullptr = equal lengths
     bool enc_ready = false, dec_ready = false;  // which checkpoint groups tvc_finalize_weights packed
     char enc_missing[160] = {0}, dec_missing[160] = {0};
     std::map<std::string, tvc::HostTensor> host;  // staged checkpoint tensors
@@ -225,7 +227,7 @@ inline int launch_check(tvc_ctx* ctx, const char* what) {
 // ---- stage drivers (each enqueues kernels on `s`; `dry` = measure workspace only) ----------
 int run_stft(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* spec, int B, int64_t L);
 int run_stft_fft(tvc_ctx*, hipStream_t, const float* wav, float* spec, int B, int64_t L);
-int run_noise_ifft(tvc_ctx*, hipStream_t, const float* kern, const float* angle, float* frames, int B, int T);
+int run_noise_ifft(tvc_ctx*, hipStream_t, const float* kern, const float* angle, float* frames, int B, int T, bool angle_padded = false);
 int run_energy(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* energy, int B, int64_t L);
 int run_encoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* spec, float* ssl, float* f0,
                 float* logits, int B, int T);
