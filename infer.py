@@ -125,28 +125,48 @@ def main(argv=None):
         wf = gen.engine(device).resample(wf.to(device), sr, SAMPLE_RATE).mean(dim=0, keepdim=True)       # mono, 24 kHz (infer.py:63-64), on the GPU
         jobs.append((path, wf))
 
+    # files too short for the STFT's reflect padding (torch.stft raises on them in the reference) are reported, not fatal for the rest
+    short = [p for p, wf in jobs if wf.shape[1] <= 960]
+    for p in short:
+        print(f"Skipping {p}: {960} samples or fewer @24 kHz (the STFT needs more)")
+    jobs = [(p, wf) for p, wf in jobs if wf.shape[1] > 960]
     if not jobs:
         return 0
-    # one call for the whole directory: a ragged batch (every file converted over its own length, equal-length files batched,
-    # the batches concurrent on the GPU); the reference's loop converts them one by one (infer.py:60-66)
     lengths = [wf.shape[1] for _p, wf in jobs]
-    Lmax = -(-max(lengths) // 480) * 480
-    batch = torch.zeros(len(jobs), Lmax, device=device)
-    for i, (_p, wf) in enumerate(jobs):
-        batch[i, :wf.shape[1]] = wf[0]
     print(f"Converting {len(jobs)} file(s), {min(lengths)} .. {max(lengths)} samples ...")
+    outs = [None] * len(jobs)
     if args.chunked and not args.no_chunking:
-        outs = []
         for length in sorted(set(lengths)):      # streams of one group advance in lock step: chunked mode batches equal lengths
             rows = [i for i, n in enumerate(lengths) if n == length]
-            o = convert_chunked(gen, batch[rows, :length], tgt, args.pitch_shift, args.chunk_size, args.buffer_size, args.phase_vocoder).cpu()
-            outs += list(zip(rows, o))
-        outs = [o for _i, o in sorted(outs, key=lambda t: t[0])]
-    elif len(set(lengths)) == 1:
-        outs = list(gen.convert(batch[:, :lengths[0]], tgt, args.pitch_shift).cpu())
+            batch = torch.cat([jobs[i][1][:, :length] for i in rows], dim=0)
+            o = convert_chunked(gen, batch, tgt, args.pitch_shift, args.chunk_size, args.buffer_size, args.phase_vocoder).cpu()
+            for i, y in zip(rows, o):
+                outs[i] = y
     else:
-        out = gen.convert(batch, tgt, args.pitch_shift, lengths=lengths).cpu()
-        outs = [out[i, :-(-lengths[i] // 480) * 480] for i in range(len(jobs))]
+        # Ragged batches (every file converted over its own length, exactly as if it were alone; the reference's loop converts them one by
+        # one, infer.py:60-66).  Files are taken in order of length and cut into calls whose PADDED size stays under a budget, so memory is
+        # bounded by the budget - not by (number of files) x (longest file) - and the padding inside a call stays small.
+        order = sorted(range(len(jobs)), key=lambda i: lengths[i])
+        budget = int(os.environ.get("TVC_INFER_BATCH_SAMPLES", 32 * 1024 * 1024))      # padded samples per call (x 4 B in, x 4 B out, x 8 for the noise phases)
+        start = 0
+        while start < len(order):
+            end = start + 1
+            while end < len(order) and (end + 1 - start) * (-(-lengths[order[end]] // 480) * 480) <= budget:
+                end += 1
+            rows = order[start:end]
+            lens = [lengths[i] for i in rows]
+            Lmax = -(-max(lens) // 480) * 480
+            batch = torch.zeros(len(rows), Lmax, device=device)
+            for r, i in enumerate(rows):
+                batch[r, :lengths[i]] = jobs[i][1][0]
+            if len(set(lens)) == 1:
+                out = gen.convert(batch[:, :lens[0]], tgt, args.pitch_shift).cpu()
+            else:
+                out = gen.convert(batch, tgt, args.pitch_shift, lengths=lens).cpu()
+            for r, i in enumerate(rows):
+                outs[i] = out[r, :-(-lengths[i] // 480) * 480]
+            del batch, out
+            start = end
     for (path, _wf), y in zip(jobs, outs):
         name = os.path.splitext(os.path.basename(path))[0]
         audio_io.save(os.path.join(args.outputs, f"{name}.wav"), y[None], SAMPLE_RATE)

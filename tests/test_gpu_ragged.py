@@ -159,3 +159,40 @@ def test_infer_py_converts_a_directory_of_different_lengths_in_one_call(tmp_path
         y, sr = audio_io.load(str(d / "out" / f"{name}.wav"))
         assert sr == 24000 and y.shape == (1, -(-n // 480) * 480) and torch.isfinite(y).all() and float(y.abs().max()) > 1e-3
     assert os.path.exists(d / "out" / "d.wav")
+
+
+def test_infer_py_bounds_its_batches_and_skips_files_it_cannot_convert(tmp_path, monkeypatch, capsys):
+    """memory must not grow as (number of files) x (longest file).  With a small padded-sample budget the directory is cut
+    into several calls in order of length; a file of 960 samples or fewer is reported and skipped instead of aborting the run."""
+    import infer
+    d = tmp_path
+    torch.save(synth.synth_state_dict("encoder"), d / "encoder.pt")
+    torch.save(synth.synth_state_dict("decoder"), d / "decoder.pt")
+    torch.save(synth.synth_index(300, seed=2), d / "index.pt")
+    (d / "inputs").mkdir()
+    lens = {"a": 70000, "b": 9000, "c": 64000, "d": 30011, "e": 500, "f": 66000}
+    for i, (name, n) in enumerate(lens.items()):
+        audio_io.save(str(d / "inputs" / f"{name}.wav"), synth.synth_wave(1, n, seed=80 + i), 24000)
+    monkeypatch.setenv("TVC_INFER_BATCH_SAMPLES", str(150000))
+    gen = infer.load_generator(str(d / "encoder.pt"), str(d / "decoder.pt"), torch.device(DEV))
+    calls = []
+    orig = type(gen).convert
+
+    def spy(self, wf, *a, **k):
+        calls.append(tuple(wf.shape))
+        return orig(self, wf, *a, **k)
+
+    type(gen).convert = spy
+    try:
+        rc = infer.main(["-i", str(d / "inputs"), "-o", str(d / "out"), "-encp", str(d / "encoder.pt"), "-decp", str(d / "decoder.pt"),
+                         "-idx", str(d / "index.pt"), "-d", DEV])
+    finally:
+        type(gen).convert = orig
+    assert rc == 0
+    assert "Skipping" in capsys.readouterr().out and not os.path.exists(d / "out" / "e.wav")
+    assert len(calls) >= 2 and all(b * l <= 150000 or b == 1 for b, l in calls), calls
+    for name, n in lens.items():
+        if name == "e":
+            continue
+        y, sr = audio_io.load(str(d / "out" / f"{name}.wav"))
+        assert sr == 24000 and y.shape == (1, -(-n // 480) * 480) and torch.isfinite(y).all() and float(y.abs().max()) > 1e-3
