@@ -123,6 +123,12 @@ int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, fl
 int64_t tvc_knn_prepared_elems_f16(int64_t N);
 int tvc_knn_prepare_index_f16(tvc_ctx* ctx, void* stream, const void* rows_f16, float* prepared,
                               int64_t N);
+
+/* The library remembers the N every blob was prepared with (by device address) and refuses calls that pass another N.  Call this
+ * before the memory of a prepared blob is reused for anything else than a fresh tvc_knn_prepare_index_* (for instance a COPY of
+ * another blob): an address that is recycled must not inherit the record.  (No reference counterpart: feature_retrieval.py:25-27
+ * re-normalises the index on every call and keeps no prepared state.) */
+int tvc_knn_forget(tvc_ctx* ctx, const float* prepared);
 /* match_features(source, reference, k=4, alpha=0, metrics='cos')
  * (reference module/tinyvc/feature_retrieval.py:15-33): src [B,768,T] against one shared prepared
  * index -> out [B,768,T]; idx_out [B,T,4] int64 (nullable) = topk indices, ties -> lowest index. */
@@ -164,7 +170,9 @@ int tvc_decoder_f32(tvc_ctx* ctx, void* stream, const float* content, const floa
                     int B, int T, void* ws, size_t ws_bytes);
 /* Stage outputs of the decoder for parity tests (any pointer may be NULL):
  * amps [B,15,T], kernel [B,961,T] (SourceNet.forward, decoder.py:126-134),
- * source [B,16,L] (Decoder.dsp, decoder.py:259-266). Same arguments as tvc_decoder_f32. */
+ * source [B,16,L] (Decoder.dsp, decoder.py:259-266). Same arguments as tvc_decoder_f32.
+ * `wave` may be NULL too: the call then stops behind the last stage asked for - amps / kernel only = SourceNet.forward
+ * alone (no DSP, no FilterNet pass), + source = up to Decoder.dsp. */
 int tvc_decoder_stages_f32(tvc_ctx* ctx, void* stream, const float* content, const float* f0,
                            const float* energy, const float* noise_angle, uint64_t seed,
                            float* wave, float* amps, float* kernel, float* source, int B, int T,

@@ -193,6 +193,9 @@ def test_decoder_stages(models, case):
     check("noise (oracle in)", src2[:, 15], g["noise"], 2e-6)            # measured 2.0e-7
     check("source", source[:, :, ::dm], g["source_d"], 2e-6)             # measured 1.6e-7
     check("decoder wave", wave, g["wave"], 2.5e-6, atol=2.5e-6)         # measured 2.4e-7 / 2.1e-7
+    # the sub-module API (SourceNet.forward, decoder.py:126-134) runs SourceNet alone - no DSP, no FilterNet pass - and returns the same tensors
+    a2, k2 = dec.source_net(content, f0s, energy)
+    assert torch.equal(a2, amps) and torch.equal(k2, kern)
 
 
 @pytest.mark.parametrize("case", CASES)

@@ -509,11 +509,20 @@ void build_fft_tables(Packer& pk, tvc_ctx* ctx) {
 // Prepared kNN blobs of this process: device pointer -> N it was prepared for.  The kernels take the blob's geometry (offsets of the
 // inverse norms and the fp16 image) from the caller's N, so a call whose N differs from the one the blob was prepared with would read
 // out of bounds: such a call is refused.  (A blob this process did not prepare - e.g. a copy - is unknown here and trusted.)
+// The record is made only after the prepare launches succeeded; tvc_knn_forget drops it when the memory is handed to something else
+// (a device address is recycled: a blob copied to where a blob of another size once lived must not inherit that record), and the
+// registry is bounded: past kMaxBlobRecords it starts over (a forgotten record only loses this check).
 static std::mutex g_blob_mu;
 static std::map<const void*, int64_t> g_blobs;
+constexpr size_t kMaxBlobRecords = 4096;
 static void blob_record(const void* p, int64_t N) {
     std::lock_guard<std::mutex> lk(g_blob_mu);
+    if (g_blobs.size() >= kMaxBlobRecords && !g_blobs.count(p)) g_blobs.clear();
     g_blobs[p] = N;
+}
+static void blob_forget(const void* p) {
+    std::lock_guard<std::mutex> lk(g_blob_mu);
+    g_blobs.erase(p);
 }
 static int blob_check(tvc_ctx* ctx, const void* p, int64_t N, const char* what) {
     std::lock_guard<std::mutex> lk(g_blob_mu);
@@ -878,16 +887,26 @@ int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, fl
     if (!ctx) return TVC_ERR_ARG;
     if (!index || !prepared || N <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_prepare_index_f32: bad argument");
     TVC_HIP(ctx, hipSetDevice(ctx->device));
+    blob_forget(prepared);
+    TVC_CHECK(run_prepare_index(ctx, (hipStream_t)stream, index, prepared, N));
     blob_record(prepared, N);
-    return run_prepare_index(ctx, (hipStream_t)stream, index, prepared, N);
+    return TVC_OK;
+}
+
+int tvc_knn_forget(tvc_ctx* ctx, const float* prepared) {
+    if (!ctx) return TVC_ERR_ARG;
+    blob_forget(prepared);
+    return TVC_OK;
 }
 
 int tvc_knn_prepare_index_f16(tvc_ctx* ctx, void* stream, const void* rows_f16, float* prepared, int64_t N) {
     if (!ctx) return TVC_ERR_ARG;
     if (!rows_f16 || !prepared || N <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_prepare_index_f16: bad argument");
     TVC_HIP(ctx, hipSetDevice(ctx->device));
+    blob_forget(prepared);
+    TVC_CHECK(run_prepare_index_f16(ctx, (hipStream_t)stream, rows_f16, prepared, N));
     blob_record(prepared, N);
-    return run_prepare_index_f16(ctx, (hipStream_t)stream, rows_f16, prepared, N);
+    return TVC_OK;
 }
 
 int tvc_knn_match_f32(tvc_ctx* ctx, void* stream, const float* src, const float* prepared, int64_t N, float* out,
@@ -948,7 +967,7 @@ int tvc_decoder_stages_f32(tvc_ctx* ctx, void* stream, const float* content, con
                            const float* noise_angle, uint64_t seed, float* wave, float* amps, float* kernel,
                            float* source, int B, int T, void* wsp, size_t ws_bytes) {
     TVC_CHECK(need_ready(ctx, NEED_DEC));
-    if (!content || !f0 || !energy || !wave || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_decoder_f32: bad argument");
+    if (!content || !f0 || !energy || B <= 0 || T <= 0 || (!wave && !amps && !kernel && !source)) return fail(ctx, TVC_ERR_ARG, "tvc_decoder_f32: bad argument");
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(run_decoder(ctx, s, ws, true, content, f0, energy, noise_angle, seed, wave, amps, kernel, source, B, T),

@@ -510,11 +510,13 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
         TVC_CHECK(run_source_net(ctx, s, ws, dry, content, f0, energy, amps, kern, B, T, cmax));
     }
     ws.release(mk);
+    if (!wave && !source_out) return 0;          // SourceNet.forward alone (decoder.py:126-134): the caller asked for amps / kernel only
     {
         ProfScope ps(ctx, s, dry, "dsp");
         TVC_CHECK(run_dsp(ctx, s, ws, dry, f0, amps, kern, angle, seed, source, B, T, smax));
     }
     ws.release(mk);
+    if (!wave) return 0;                         // ... or for Decoder.dsp's output (decoder.py:259-266) without the FilterNet pass
     ProfScope ps(ctx, s, dry, "filter_net");
     TVC_CHECK(run_filter(ctx, s, ws, dry, content, f0, energy, source, wave, B, T, nullptr, cmax, smax));
     ws.release(mk);

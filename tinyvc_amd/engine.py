@@ -310,6 +310,21 @@ class Engine:
                                                  _ptr(amps), _ptr(kern), _ptr(source), B, T, p, n), "tvc_decoder_stages_f32")
         return wave, amps, kern, source
 
+    def source_net(self, content, f0, energy):
+        """SourceNet.forward (decoder.py:126-134) alone: (amps [B,15,T], kernel [B,961,T]) - no DSP, no FilterNet pass."""
+        content = _prep(content, "content", self.device)
+        f0 = _prep(f0, "f0", self.device)
+        energy = _prep(energy, "energy", self.device)
+        B, C, T = content.shape
+        if C != spec.SSL_DIM or tuple(f0.shape) != (B, 1, T) or tuple(energy.shape) != (B, 1, T * spec.HOP):
+            raise ValueError("source_net shapes: content [B,768,T], f0 [B,1,T], energy [B,1,T*480]")
+        amps = torch.empty(B, spec.NUM_HARMONICS + 1, T, dtype=_F32, device=self.device)
+        kern = torch.empty(B, spec.FFT_BIN, T, dtype=_F32, device=self.device)
+        p, n = self._wsargs(B, T * spec.HOP)
+        self._ok(self.lib.tvc_decoder_stages_f32(self.ctx, self._stream(), _ptr(content), _ptr(f0), _ptr(energy), None, 0, None,
+                                                 _ptr(amps), _ptr(kern), None, B, T, p, n), "tvc_decoder_stages_f32 (SourceNet)")
+        return amps, kern
+
     def filter_net(self, content, f0, energy, source, blocks=False):
         """FilterNet.forward -> wave [B, L]; blocks=True also returns (skips[5], ups[4]): the Downsample / Upsample
         block outputs of decoder.py:227-232 (ups[4] is folded into the output conv, see tvc_filter_net_f32)."""

@@ -36,8 +36,7 @@ class SourceNet(nn.Module):
     @torch.no_grad()
     def forward(self, content, f0, energy):    # decoder.py:126-134 -> (amps, kernel)
         dec = self.__dict__["_decoder"]
-        _w, amps, kern, _s = dec.engine(content.device).decoder(content, f0, energy, stages=True)
-        return amps, kern
+        return dec.engine(content.device).source_net(content, f0, energy)
 
 
 class Downsample(nn.Module):
