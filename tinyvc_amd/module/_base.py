@@ -22,9 +22,11 @@ def _bump(*_args):
 
 # torch calls these for every Parameter / sub-module registration of every nn.Module in the process - also the ones behind
 # `module.weight = nn.Parameter(...)`, `gen.decoder = other` and load_state_dict(assign=True) on any descendant, stock nn.Conv1d
-# leaves included.  A registration anywhere only costs the next call one walk of its own parameter tree.
-torch.nn.modules.module.register_module_parameter_registration_hook(_bump)
-torch.nn.modules.module.register_module_module_registration_hook(_bump)
+# leaves included.  A registration anywhere only costs the next call one walk of its own parameter tree.  The hooks are process-global
+# (torch has no per-module form); `_HOOK_HANDLES` keeps their handles so an embedding application can remove them
+# (`for h in _HOOK_HANDLES: h.remove()` - the periodic re-walk in `_param_list` then remains as the only invalidation).
+_HOOK_HANDLES = (torch.nn.modules.module.register_module_parameter_registration_hook(_bump),
+                 torch.nn.modules.module.register_module_module_registration_hook(_bump))
 
 
 class HipModule(nn.Module):
@@ -42,7 +44,10 @@ class HipModule(nn.Module):
         running (or keeps replaying a captured stream graph) on a child's replaced weights."""
         d = self.__dict__
         c = d.get("_plist")
-        if c is None or c[0] != _EPOCH[0]:
+        n = d["_plist_uses"] = d.get("_plist_uses", 0) + 1
+        # Mutations that bypass the registration hooks (`module._parameters[k] = ...`, `del module.weight`) are caught by a re-walk every
+        # 256th use: at most 256 calls run on the replaced weights, and the walk costs < 1 us per call amortised.
+        if c is None or c[0] != _EPOCH[0] or (n & 255) == 0:
             c = d["_plist"] = (_EPOCH[0], list(self.parameters()))
         return c[1]
 
