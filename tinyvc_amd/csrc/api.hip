@@ -374,7 +374,7 @@ struct Packer {
     }
     // Weight blob of the downs.0 kernel (filter_up24s.hip): the 17 -> 24 k3 conv in the same 10-piece layout
     // as a 24-channel conv (input rows 17..23 zero), then 32 floats: bias [24], [31] = the image's power-of-two scale.
-    void down0s(const float** slot, const std::string& name) {
+    void down0s(const float** slot, const std::string& name, float* bound_w, float* bound_b) {
         const HostTensor* w = find(name + ".weight");
         const HostTensor* b = find(name + ".bias");
         if (!w || !b) return;
@@ -396,7 +396,18 @@ struct Packer {
                     const size_t base = ((size_t)(s * 2) * 64 + lane) * 8 + j;
                     split2(v, sc, &o[base], &o[base + 512]);
                 }
-        for (int m = 0; m < C; ++m) img[10 * 256 + m] = b->data[m];
+        double l1max = 0.0;
+        float bmax = 0.f;
+        for (int m = 0; m < C; ++m) {
+            img[10 * 256 + m] = b->data[m];
+            double l1 = 0.0;
+            for (int k = 0; k < CI * 3; ++k) l1 += std::fabs((double)w->data[(size_t)m * CI * 3 + k]);
+            l1max = std::max(l1max, l1);
+            bmax = std::max(bmax, std::fabs(b->data[m]));
+        }
+        // |out| <= l1max |x|max + bmax (rounded up a little: the bound must hold for the fp32-rounded sums too): the scale of the pre-split planes
+        img[10 * 256 + 29] = *bound_w = (float)(l1max * 1.0001);
+        img[10 * 256 + 30] = *bound_b = bmax * 1.0001f;
         img[10 * 256 + 31] = sc;
         fix.push_back({slot, ab.put(img)});
     }
@@ -656,7 +667,7 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
     pk.conv({"filter_net.content_in"}, &ctx->flt_content_in, kSslDim, 1);
     pk.raw("filter_net.f0_in.weight", &ctx->flt_f_w, ch[0]);
     pk.raw("filter_net.f0_in.bias", &ctx->flt_f_b, ch[0]);
-    pk.down0s(&ctx->flt_down0s, "filter_net.downs.0");
+    pk.down0s(&ctx->flt_down0s, "filter_net.downs.0", &ctx->down0_bw, &ctx->down0_bb);
     for (int i = 1; i <= 4; ++i) {
         DownW& d = ctx->downs[i - 1];
         d.cin = ch[5 - i];

@@ -374,7 +374,8 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
         if (!gemm_s2_try(&rc, ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax)) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax);
         TVC_CHECK(rc);
         TVC_CHECK(run_amax_rows(ctx, s, x, B, ch[0], T, slot(S_X)));
-        TVC_CHECK(run_down0_split(ctx, s, ctx->flt_down0s, source, energy, skip[0], xi_pre[1], B, (int)L, smax, slot(S_SKIP0)));
+        // skips[0] is read as FiLM cond only (ups[4]): it is written as the two halves' ready operand; the fp32 tensor exists for the parity tap alone
+        TVC_CHECK(run_down0_split(ctx, s, ctx->flt_down0s, source, energy, skip[0], taps ? taps->skips[0] : nullptr, xi_pre[1], B, (int)L, smax, slot(S_SKIP0)));
     }
     // down path (xi = the 1/f-rate pick / two-sample mean of skip[i-1]: bounded by skip[i-1]'s |max|, same slot)
     for (int i = 1; i <= 4; ++i) {
@@ -433,7 +434,7 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
         if (!dry && C == 24) {
             // last level: Upsample block + output_layer in two launches, waveform written directly
             ProfScope ps(ctx, s, dry, "filter.up4+out");
-            TVC_CHECK(run_up24_split(ctx, s, u, x, cond, x1, wave, B, lo, mx_in, mcond, slot(S_UX1 + i)));
+            TVC_CHECK(run_up24_split(ctx, s, u, x, cond, ctx->down0_bw, ctx->down0_bb, x1, wave, B, lo, mx_in, smax, slot(S_UX1 + i)));
         } else if (!dry) {
             static const char* names[4] = {"filter.up0", "filter.up1", "filter.up2", "filter.up3"};
             ProfScope ps(ctx, s, dry, names[i]);
@@ -475,7 +476,7 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
         mx_in = slot(S_LEV + i);
     }
     if (!dry && taps) {   // parity taps: the block outputs are still live in the workspace
-        for (int i = 0; i < 5; ++i)
+        for (int i = 1; i < 5; ++i)      // (skips[0] was written into the tap by its producer)
             if (taps->skips[i])
                 TVC_HIP(ctx, hipMemcpyAsync(taps->skips[i], skip[i], (size_t)B * ch[4 - i] * len_dn[i] * sizeof(float), hipMemcpyDeviceToDevice, s));
         long l = T;
@@ -510,13 +511,13 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
         TVC_CHECK(run_source_net(ctx, s, ws, dry, content, f0, energy, amps, kern, B, T, cmax));
     }
     ws.release(mk);
-    if (!wave && !source_out) return 0;          // SourceNet.forward alone (decoder.py:126-134): the caller asked for amps / kernel only
+    if (!dry && !wave && !source_out) return 0;  // SourceNet.forward alone (decoder.py:126-134): the caller asked for amps / kernel only
     {
         ProfScope ps(ctx, s, dry, "dsp");
         TVC_CHECK(run_dsp(ctx, s, ws, dry, f0, amps, kern, angle, seed, source, B, T, smax));
     }
     ws.release(mk);
-    if (!wave) return 0;                         // ... or for Decoder.dsp's output (decoder.py:259-266) without the FilterNet pass
+    if (!dry && !wave) return 0;                 // ... or for Decoder.dsp's output (decoder.py:259-266) without the FilterNet pass
     ProfScope ps(ctx, s, dry, "filter_net");
     TVC_CHECK(run_filter(ctx, s, ws, dry, content, f0, energy, source, wave, B, T, nullptr, cmax, smax));
     ws.release(mk);

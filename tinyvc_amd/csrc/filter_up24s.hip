@@ -18,6 +18,7 @@
 //   HBM     per tile: input tile + halo and cond in, one tile out; the next tile's input is in flight in registers
 //           across the whole tile (raw s_barrier: __syncthreads would wait for it).
 #include "conv3s.h"
+#include "conv_s2.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
 
@@ -51,12 +52,14 @@ struct U24S {
 
 struct Up24SArgs {
     const float* x;      // half A: low-rate input [B][24][len/xf]; half B: x1 [B][24][len]
-    const float* cond;   // [B][24][len]
+    const uint4* cond;   // skips[0] as down0s_kernel writes it: the FiLM 1x1s' READY B operand, two fp16 planes [B][part][3 groups][len][8 fp16] of
+                         // cond * 2^k, k from the bound cbw |max of downs.0's input| + cbb >= |cond| (amax_c = that input's slot; both kernels evaluate it alike)
+    float cbw, cbb;
     float* out;          // half A: x1 [B][24][len]; half B: waveform [B][len]
     const u32x4* img;    // weight blob (api.hip up24s_half)
     int len, xf, tiles_per_utt, ntiles;
     float interp_scale;
-    // block-floating-point guard (conv3s.h): per-utterance |max| slots of x / cond (read, nullable) and of `out` (half A: written, nullable)
+    // block-floating-point guard (conv3s.h): per-utterance |max| slots of x / of the tensor cond was computed from (read, nullable) and of `out` (half A: written, nullable)
     const float* amax_x;
     const float* amax_c;
     float* amax_y;
@@ -223,25 +226,26 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         }
         // block-floating-point scales: input (per-utterance |max| slot), cond, and the on-chip intermediate h = lrelu(conv_a + b_a),
         // bounded by sum|w_a| * amax_x + max|b_a| (never measured: it does not leave the CU)
-        const Bfp sx = bfp_load(a.amax_x, b), sc = bfp_load(a.amax_c, b);
+        const Bfp sx = bfp_load(a.amax_x, b);
+        const Bfp sc = a.amax_c ? norm_from_amax(fmaf(a.cbw, a.amax_c[b], a.cbb)) : Bfp{1.f, 1.f};      // the scale down0s_kernel wrote the planes with
         const Bfp sh_ = a.amax_x ? bfp_from_amax(fmaf(wl1, a.amax_x[b], bamax)) : Bfp{1.f, 1.f};
         const int t0 = rt.tin * W;
         const int ph0 = t0 - E - D2;      // position of Hs column 0
         const int p20 = t0 - E;           // position of second-conv column 0
         const int next = tile + 1;
 
-        // FiLM cond of this wave's second-conv tile, straight into B-fragment order: step 0 = channels 8 lh + j,
-        // step 1 = channels 16 + j for lh = 0 (the other half is the zero unit)
-        float cr0[8], cr1[8];
+        // FiLM cond of this wave's second-conv tile: the producer left it split, scaled and in B-fragment order - K16 step 0 = channel
+        // group lh, step 1 = group 2 for lh = 0 (the other half is the zero unit): four 16-byte loads, no arithmetic
+        u32x4 cq[2][2];
         if (wave < CF::NT2) {
-            const float* cb = RAG ? a.cond + rt.off : a.cond + (long)b * C * rs;
+            const uint4* cb = RAG ? a.cond + rt.off : a.cond + (long)b * 6 * rs;
             int t = p20 + wave * 32 + l31;
             t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
-            const unsigned o0 = 4u * (unsigned)(8 * lh * rs + t), o1 = 4u * (unsigned)t;
+            const unsigned o0 = 16u * (unsigned)(lh * rs + t), o1 = 16u * (unsigned)t;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                cr0[j] = ldg_so(cb + (long)j * rs, o0);
-                cr1[j] = ldg_so(cb + (long)(16 + j) * rs, o1);
+            for (int p = 0; p < 2; ++p) {
+                cq[0][p] = ldg_so4(cb + (long)(3 * p) * rs, o0);
+                cq[1][p] = ldg_so4(cb + (long)(3 * p + 2) * rs, o1);
             }
         }
         if (next < tend) fetch(next);   // lands in registers during the whole tile
@@ -283,19 +287,12 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
             const int t = p20 + n;
             f16x8 cf[2][2];
             {
+                const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    cr0[j] *= sc.s;
-                    cr1[j] *= sc.s;
+                for (int p = 0; p < 2; ++p) {
+                    cf[0][p] = __builtin_bit_cast(f16x8, cq[0][p]);
+                    cf[1][p] = __builtin_bit_cast(f16x8, lh ? z : cq[1][p]);
                 }
-                uint4 p1, p2;
-                split8(cr0, p1, p2);
-                cf[0][0] = __builtin_bit_cast(f16x8, p1);
-                cf[0][1] = __builtin_bit_cast(f16x8, p2);
-                split8(cr1, p1, p2);
-                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-                cf[1][0] = __builtin_bit_cast(f16x8, lh ? z : p1);
-                cf[1][1] = __builtin_bit_cast(f16x8, lh ? z : p2);
             }
             const float cb = wsb * sh_.inv, cbl = cb * kLoInv, c1 = wssc * sc.inv, c1l = c1 * kLoInv, c2 = wssh * sc.inv, c2l = c2 * kLoInv;
             float hv[3][4];                                                        // conv_b + b_b of this lane's 12 real rows
@@ -450,7 +447,7 @@ constexpr int U24S_WA = 250, U24S_WB = 250;     // output samples per tile of th
 // Upsample block with cin == 24 followed by FilterNet.output_layer:
 // x [B][24][len/f], cond [B][24][len] -> wave [B][len]; x1 is scratch [B][24][len].
 // amax_x / amax_c: per-utterance |max| slots of x / cond; amax_x1: scratch slot [B] (zeroed) for the block's intermediate x1.
-int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, const float* cond, float* x1, float* wave, int B, int len,
+int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, const float* cond_planes, float cbw, float cbb, float* x1, float* wave, int B, int len,
                    const float* amax_x, const float* amax_c, float* amax_x1) {
     if (!u.s24a || !u.s24b) return fail(ctx, TVC_ERR_STATE, "up24s: the split weight blobs of the 24-channel block are missing");
     if ((long)len * 24 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "up24s: utterance too long for 32-bit element offsets");
@@ -460,7 +457,9 @@ int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, co
     a.len = len;
     a.xf = u.factor;
     a.interp_scale = (float)(1.0 / (double)u.factor);
-    a.cond = cond;
+    a.cond = reinterpret_cast<const uint4*>(cond_planes);
+    a.cbw = cbw;
+    a.cbb = cbb;
     a.amax_c = amax_c;
     a.x = x;
     a.amax_x = amax_x;
@@ -485,7 +484,9 @@ int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, co
 struct Down0SArgs {
     const float* source;   // [B][16][L]
     const float* energy;   // [B][1][L]
-    float* out;            // [B][24][L]
+    float* out;            // optional (parity taps) [B][24][L] fp32
+    uint4* planes;         // the output as the FiLM 1x1s' ready B operand (up24s_kernel): two fp16 planes [B][part][3 groups][L][8 fp16] of out * 2^k,
+                           // k from the analytic bound Bi[29] |x|max + Bi[30] >= |out| (amax_x non-null)
     float* y2;             // optional [B][24][L / 5]: F.interpolate(out, scale_factor = 1/5) = the sample at 5 d + 2
     const u32x4* img;      // 10 weight pieces + 32 floats: bias, [31] = the image's scale (api.hip down0s)
     int len, tiles_per_utt, ntiles;
@@ -569,24 +570,39 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
         const int n = wave * 32 + l31;
         conv24_phase<XP, 1>(acc, alo, Xs + cur * 6 * XP, Wt, n, 0, XW - 1, lane);
         const float cc = cw * bfp_load(a.amax_x, b).inv, ccl = cc * kLoInv;
+        const float ps = a.amax_x ? norm_from_amax(fmaf(Bi[29], a.amax_x[b], Bi[30])).s : 1.f;      // the planes' scale (up24s_kernel undoes it)
         const int t = t0 + n;
         float mx = 0.f;
-        if (n < W && t < len) {
-            float* ob = RAG ? a.out + rt.off : a.out + (long)b * 24 * rs;
+        {
+            const bool live = n < W && t < len;
+            const int tc = t < len ? t : len - 1;
+            float* ob = a.out ? (RAG ? a.out + rt.off : a.out + (long)b * 24 * rs) : nullptr;
+            uint4* pb = RAG ? a.planes + rt.off : a.planes + (long)b * 6 * rs;
             float* y2b = a.y2 ? (RAG ? a.y2 + rt.off / 5 : a.y2 + (long)b * 24 * len2) : nullptr;
-            const unsigned oo = 4u * (unsigned)(4 * lh * rs + t);
-            const int q5 = t / 5;
-            const bool pick = a.y2 != nullptr && t - 5 * q5 == 2;
+            const unsigned oo = 4u * (unsigned)(4 * lh * rs + tc);
+            const int q5 = tc / 5;
+            const bool pick = live && a.y2 != nullptr && tc - 5 * q5 == 2;
 #pragma unroll
             for (int gg = 0; gg < 3; ++gg) {
                 const f32x4s bv = *reinterpret_cast<const f32x4s*>(Bi + 8 * gg + 4 * lh);
+                float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = comb(acc[4 * gg + q], alo[4 * gg + q], cc, ccl) + bv[q];
-                    stg_so(ob + (long)(8 * gg + q) * rs, oo, v);
-                    mx = fmaxf(mx, fabsf(v));
-                    if (pick) y2b[(long)(8 * gg + 4 * lh + q) * len2 + q5] = v;
+                    v[q] = comb(acc[4 * gg + q], alo[4 * gg + q], cc, ccl) + bv[q];
+                    if (live) {
+                        if (ob) stg_so(ob + (long)(8 * gg + q) * rs, oo, v[q]);
+                        mx = fmaxf(mx, fabsf(v[q]));
+                        if (pick) y2b[(long)(8 * gg + 4 * lh + q) * len2 + q5] = v[q];
+                    }
+                    v[q] *= ps;
                 }
+                // a position's 16-byte operand row = [lanes 0-31's four channels | lanes 32-63's four]: v_permlane32_swap hands the lower half of
+                // the wave both halves of the part-1 row and the upper half those of part 2 (every lane takes part: no branch around it)
+                u32x2 p1, p2;
+                split4(v, p1, p2);
+                const auto qx = __builtin_amdgcn_permlane32_swap(p1[0], p2[0], false, false);
+                const auto qy = __builtin_amdgcn_permlane32_swap(p1[1], p2[1], false, false);
+                if (live) pb[(long)(3 * lh + gg) * rs + tc] = make_uint4(qx[0], qy[0], qx[1], qy[1]);
             }
         }
         mx_run = fmaxf(mx_run, mx);
@@ -595,7 +611,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
     if (a.amax_y) amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 32);
 }
 
-int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len,
+int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float* source, const float* energy, float* planes, float* out_fp32, float* y2, int B, int len,
                     const float* amax_x, float* amax_y) {
     if (!blob) return fail(ctx, TVC_ERR_STATE, "down0s: the split weight blob of downs.0 is missing");
     if ((long)len * 24 * 4 >= (1L << 32)) return fail(ctx, TVC_ERR_ARG, "down0s: utterance too long for 32-bit byte offsets");
@@ -611,7 +627,7 @@ int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float*
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "down0s setup: %s", hipGetErrorString(e));
         ncu = prop.multiProcessorCount;
     }
-    Down0SArgs a{source, energy, out, y2, reinterpret_cast<const u32x4*>(blob), len, (len + 253) / 254, 0, amax_x, amax_y, RagDev{}};
+    Down0SArgs a{source, energy, out_fp32, reinterpret_cast<uint4*>(planes), y2, reinterpret_cast<const u32x4*>(blob), len, (len + 253) / 254, 0, amax_x, amax_y, RagDev{}};
     a.ntiles = a.tiles_per_utt * B;
     if (ctx->rag) {
         if (B != 1 || len != ctx->rag->Ttot * kHop) return fail(ctx, TVC_ERR_STATE, "down0s: a ragged batch runs as one long utterance");

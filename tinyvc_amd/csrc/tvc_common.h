@@ -138,6 +138,7 @@ struct tvc_ctx {
     // filter net
     tvc::PackedW flt_content_in;
     const float* flt_down0s = nullptr;   // downs.0 weight blob of the split-precision kernel (filter_up24s.hip)
+    float down0_bw = 0.f, down0_bb = 0.f; // |downs.0 output| <= down0_bw |input|max + down0_bb: the scale skips[0] is written / read with
     const float* flt_f_w = nullptr;
     const float* flt_f_b = nullptr;
     tvc::DownW downs[4];
@@ -265,9 +266,11 @@ int run_prepare_index_f16(tvc_ctx*, hipStream_t, const void* rows_f16, float* pr
 
 // fused FilterNet kernels (filter_up24s.hip, conv48s.hip)
 // (the amax_* arguments are the per-utterance |max| slots of the block-floating-point guard, conv3s.h)
-int run_up24_split(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond, float* x1, float* out, int B, int len, const float* amax_x,
-                   const float* amax_c, float* amax_x1);
-int run_down0_split(tvc_ctx*, hipStream_t, const float* blob, const float* source, const float* energy, float* out, float* y2, int B, int len,
+// skips[0] travels as the FiLM 1x1s' ready operand (two fp16 planes, scaled by the bound cbw |max of downs.0's input| + cbb): run_down0_split writes
+// it (out_fp32: optional fp32 copy for the parity taps), run_up24_split reads it (amax_c = the slot of downs.0's INPUT)
+int run_up24_split(tvc_ctx*, hipStream_t, const UpW& u, const float* x, const float* cond_planes, float cbw, float cbb, float* x1, float* out, int B, int len,
+                   const float* amax_x, const float* amax_c, float* amax_x1);
+int run_down0_split(tvc_ctx*, hipStream_t, const float* blob, const float* source, const float* energy, float* planes, float* out_fp32, float* y2, int B, int len,
                     const float* amax_x, float* amax_y);
 int run_down24_fused(tvc_ctx*, hipStream_t, const DownW& d, const float* xi, float* out, float* y2, int B, int len, const float* amax_xi, float* amax_out);
 int run_conv48s(tvc_ctx*, hipStream_t, const PackedW& w, const float* x, int lin, float lscale, const PackedW* film, const float* bsc, const float* bsh,
