@@ -367,12 +367,6 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 const int g = g0 + (tid >> 3);
                 float o4[4] = {0.f, 0.f, 0.f, 0.f};
                 if (4 * g < W) {
-                    int cols[10];
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) {
-                        int c = 4 * g + E - 3 + i;
-                        cols[i] = c < lo ? lo : (c > hi ? hi : c);
-                    }
 #pragma unroll
                     for (int cc = 0; cc < 3; ++cc) {
                         const int c = part * 3 + cc;
@@ -383,9 +377,13 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                             xv[0] = r0[0]; xv[1] = r0[1]; xv[2] = r0[2]; xv[3] = r0[3];
                             xv[4] = r1[0]; xv[5] = r1[1]; xv[6] = r1[2]; xv[7] = r1[3];
                             xv[8] = r2[0]; xv[9] = r2[1];
-                        } else {
+                        } else {             // a tile at an utterance's end: the layer's replicate padding = a column clamp (rare: not worth keeping the ten columns in registers)
 #pragma unroll
-                            for (int i = 0; i < 10; ++i) xv[i] = R[c * PS + cols[i]];
+                            for (int i = 0; i < 10; ++i) {
+                                int col = 4 * g + E - 3 + i;
+                                col = col < lo ? lo : (col > hi ? hi : col);
+                                xv[i] = R[c * PS + col];
+                            }
                         }
 #pragma unroll
                         for (int j = 0; j < 7; ++j) wv[j] = W7[c * 7 + j];
@@ -569,8 +567,11 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
         for (int r = 0; r < 16; ++r) acc[r] = alo[r] = 0.f;
         const int n = wave * 32 + l31;
         conv24_phase<XP, 1>(acc, alo, Xs + cur * 6 * XP, Wt, n, 0, XW - 1, lane);
-        const float cc = cw * bfp_load(a.amax_x, b).inv, ccl = cc * kLoInv;
-        const float ps = a.amax_x ? norm_from_amax(fmaf(Bi[29], a.amax_x[b], Bi[30])).s : 1.f;      // the planes' scale (up24s_kernel undoes it)
+        // the planes' scale 2^k (up24s_kernel undoes it) rides in the epilogue's constants: (acc c + lo cl + bias) 2^k is formed as
+        // acc (c 2^k) + lo (cl 2^k) + bias 2^k - powers of two, the same bits - and the fp32 values the tap / the 1/5-rate copy / the |max| want are vs 2^-k
+        const Bfp pn = a.amax_x ? norm_from_amax(fmaf(Bi[29], a.amax_x[b], Bi[30])) : Bfp{1.f, 1.f};
+        const float ps = pn.s, pinv = pn.inv;
+        const float cc = cw * bfp_load(a.amax_x, b).inv * ps, ccl = cc * kLoInv;
         const int t = t0 + n;
         float mx = 0.f;
         {
@@ -588,13 +589,12 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    v[q] = comb(acc[4 * gg + q], alo[4 * gg + q], cc, ccl) + bv[q];
+                    v[q] = comb(acc[4 * gg + q], alo[4 * gg + q], cc, ccl) + bv[q] * ps;
                     if (live) {
-                        if (ob) stg_so(ob + (long)(8 * gg + q) * rs, oo, v[q]);
+                        if (ob) stg_so(ob + (long)(8 * gg + q) * rs, oo, v[q] * pinv);
                         mx = fmaxf(mx, fabsf(v[q]));
-                        if (pick) y2b[(long)(8 * gg + 4 * lh + q) * len2 + q5] = v[q];
+                        if (pick) y2b[(long)(8 * gg + 4 * lh + q) * len2 + q5] = v[q] * pinv;
                     }
-                    v[q] *= ps;
                 }
                 // a position's 16-byte operand row = [lanes 0-31's four channels | lanes 32-63's four]: v_permlane32_swap hands the lower half of
                 // the wave both halves of the part-1 row and the upper half those of part 2 (every lane takes part: no branch around it)
@@ -605,7 +605,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
                 if (live) pb[(long)(3 * lh + gg) * rs + tc] = make_uint4(qx[0], qy[0], qx[1], qy[1]);
             }
         }
-        mx_run = fmaxf(mx_run, mx);
+        mx_run = fmaxf(mx_run, mx * pinv);
         slab_barrier();
     }
     if (a.amax_y) amax_flush_wg(a.amax_y + mx_b, mx_run, Bi + 32);
