@@ -48,14 +48,18 @@ struct FilmS2Args {
 // wave has at two waves per SIMD.  The 12-wave layout of conv_s2.h (3 x 4 waves of 32 x 64: MW = 3, WN = 2) needs 96 accumulators + 28
 // staging registers + fragments > the 168 registers of three waves per SIMD: it compiles (the code below is written for both) but spills
 // its staging registers inside the step loop.
-struct FS2 {
-    static constexpr int MTB = 3, MW = 1, WM = MTB / MW, NWV = MW == 1 ? 8 : 4, WN = 8 / NWV, NW = MW * NWV, NTHR = NW * 64, BN = 256, MAXD = 27, XROW = BN + 2 * MAXD;
+// NWV_ = 7: a 224-column tile for levels whose length fills 256-column tiles badly (400 samples = the 384-channel level of a 4 s utterance: 2 x 224 = 448
+// columns instead of 512, -12 % of the launch); the columns are independent, so the tile width changes no value.
+template <int NWV_>
+struct FS2T {
+    static constexpr int MTB = 3, MW = 1, WM = MTB / MW, NWV = NWV_, WN = 1, NW = MW * NWV, NTHR = NW * 64, BN = NWV * WN * 32, MAXD = 27, XROW = BN + 2 * MAXD;
     static constexpr int A_CONV = 3 * MTB * 2, A_PIECES = A_CONV + 2 * MTB * 2, A_PER = (A_PIECES + NW - 1) / NW;
     static constexpr int XS = (2 * XROW + NTHR - 1) / NTHR;       // conv staging items per thread
     static constexpr int A_U4 = A_PIECES * 64, X_U4 = 2 * 2 * XROW, C_U4 = 2 * 2 * BN, BUF_U4 = A_U4 + X_U4 + C_U4;
     static constexpr int lds_bytes = 2 * BUF_U4 * 16 + 6 * 384 * 4 + 64;
     static_assert(2 * BN <= NTHR, "one cond item per thread");
 };
+using FS2 = FS2T<8>;
 
 // fp16(v) and the fp16 of what it left behind
 __device__ __forceinline__ void split8u(const float (&v)[8], uint4& p1, uint4& p2) {
@@ -66,9 +70,9 @@ __device__ __forceinline__ void split8u(const float (&v)[8], uint4& p1, uint4& p
     p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
 }
 
-template <bool XPRE, bool RAG = false>
-__global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::NW / 4))) void film_s2_kernel(FilmS2Args a) {
-    using TL = FS2;
+template <bool XPRE, bool RAG = false, int NWV_ = 8>
+__global__ __launch_bounds__(FS2T<NWV_>::NTHR) __attribute__((amdgpu_waves_per_eu(2))) void film_s2_kernel(FilmS2Args a) {
+    using TL = FS2T<NWV_>;
     constexpr int MTB = TL::MTB, WM = TL::WM, NWV = TL::NWV, WN = TL::WN, NW = TL::NW, BN = TL::BN, XROW = TL::XROW, A_PER = TL::A_PER, XS = TL::XS;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_fs[];
     float* Tb = reinterpret_cast<float*>(smem_fs + 2 * TL::BUF_U4);      // six rows of 384
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(FS2::NTHR) __attribute__((amdgpu_waves_per_eu(FS2::
         ic[k] = item - ig[k] * xw;
         xdst[k] = ig[k] * XROW + ic[k];
     }
-    const int cg = (tid >> 8) & 1, cc = tid & 255;
+    const int cg = tid >= BN ? 1 : 0, cc = tid - cg * BN;      // (NTHR = 2 BN)
     const int cdst = cg * BN + cc;
     unsigned xo[XS], co = 0;
     float xs = 1.f, cs_ = 1.f;        // of the load cursor's tile
@@ -416,6 +420,8 @@ inline bool film_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const FilmU& fu, c
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS2::lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS2::lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS2::lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel<false, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, FS2T<7>::lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)film_s2_kernel<true, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, FS2T<7>::lds_bytes);
         if (e != hipSuccess) {
             *rc = fail(ctx, TVC_ERR_HIP, "film_s2 setup: %s", hipGetErrorString(e));
             return true;
@@ -456,6 +462,13 @@ inline bool film_s2_try(int* rc, tvc_ctx* ctx, hipStream_t s, const FilmU& fu, c
     if (ctx->rag) {
         if (pre) hipLaunchKernelGGL((film_s2_kernel<true, true>), dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
         else hipLaunchKernelGGL((film_s2_kernel<false, true>), dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
+    } else if ((len + 223) / 224 * 224 < (len + 255) / 256 * 256) {
+        // the narrower tile computes fewer padded columns at this length
+        a.tiles_per_utt = (len + 223) / 224;
+        a.ntiles = a.tiles_per_utt * B * a.mblocks;
+        const int g7 = a.ntiles < ncu ? a.ntiles : ncu;
+        if (pre) hipLaunchKernelGGL((film_s2_kernel<true, false, 7>), dim3(g7), dim3(FS2T<7>::NTHR), FS2T<7>::lds_bytes, s, a);
+        else hipLaunchKernelGGL((film_s2_kernel<false, false, 7>), dim3(g7), dim3(FS2T<7>::NTHR), FS2T<7>::lds_bytes, s, a);
     } else if (pre) hipLaunchKernelGGL(film_s2_kernel<true>, dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
     else hipLaunchKernelGGL(film_s2_kernel<false>, dim3(grid), dim3(FS2::NTHR), FS2::lds_bytes, s, a);
     *rc = launch_check(ctx, "film_s2");
