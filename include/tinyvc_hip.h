@@ -205,9 +205,11 @@ int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* p
  * them to a common length would change results - GRN and the phase scan run over the whole time axis, convnext.py:31-34).
  * wav / wave [B, Lmax] row-major, utterance b occupies its first lens[b] samples (lens[b] % 480 == 0, 960 < lens[b] <= Lmax; the
  * tail of a wave row is zero-filled); noise_angle [B, 961, Lmax/480] (utterance b uses its first lens[b]/480 frames) or NULL.
- * `lens` is a HOST array (lengths are launch geometry).  Utterances of equal length run as one batch each; the batches run
- * concurrently on streams of the context, forked from and joined into `stream`.  Every utterance gets exactly the samples a
- * B = 1 tvc_convert_f32 call gives it.  Workspace: tvc_workspace_bytes_ragged. */
+ * `lens` is a HOST array (lengths are launch geometry; they travel to the device as kernel arguments, asynchronously on `stream`).
+ * The utterances share every kernel launch - the kernels take per-utterance lengths (csrc/ragged.h) -, in at most four batches per
+ * call by length class (frames < 11, < 43, < 128, the rest: the kernels a FilterNet level runs depend on the utterance's length there),
+ * one after the other on `stream`.  Every utterance gets exactly the samples a B = 1 tvc_convert_f32 call gives it.  A single
+ * utterance may be up to 80 000 frames.  Workspace: tvc_workspace_bytes_ragged. */
 int tvc_workspace_bytes_ragged(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, int64_t N, size_t* out_bytes);
 int tvc_convert_ragged_f32(tvc_ctx* ctx, void* stream, const float* wav, int64_t Lmax, const int64_t* lens, const float* prepared_index,
                            int64_t N, float pitch_shift, const float* noise_angle, uint64_t seed, float* wave, int B, void* ws,

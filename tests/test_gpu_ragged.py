@@ -60,9 +60,9 @@ def test_ragged_batch_equals_one_call_per_utterance_and_the_oracle(gen):
 
 
 def test_long_utterances_run_as_one_ragged_batch_inside_the_kernels(gen):
-    """Utterances of >= 128 frames (2.56 s) share every kernel launch (csrc/ragged.h): per-utterance lengths inside the kernels.  Seven
-    different lengths - odd and even frame counts, one not padded to a frame, a duplicate - mixed with two short ones that take the
-    grouped path in the same call.  Contract unchanged: every utterance equals its own B = 1 call bit for bit."""
+    """Utterances share every kernel launch (csrc/ragged.h): per-utterance lengths inside the kernels.  Seven different lengths of >= 128
+    frames - odd and even frame counts, one not padded to a frame, a duplicate - mixed with two short ones (another class: its own batch of
+    the same call).  Contract unchanged: every utterance equals its own B = 1 call bit for bit."""
     enc_sd, dec_sd = state_dicts(0)
     frames = [200, 131, 256, 17, 145, 128, 200, 9, 173]
     lens = [480 * f - (23 if i % 3 == 1 else 0) for i, f in enumerate(frames)]
@@ -116,6 +116,38 @@ def test_sixty_four_distinct_lengths_are_one_batch(gen):
     ms = (time.perf_counter() - t0) / 3 * 1e3
     print(f"[ragged] 64 distinct lengths: {ms:.2f} ms per call")
     assert ms < 20.0
+
+
+def test_short_utterances_of_every_class_share_their_launches(gen):
+    """Which FiLM kernel a FilterNet level runs depends on the utterance's length (decoder.hip film_conv), so a ragged call is cut into
+    classes at 11, 43 and 128 frames and every class is one in-kernel batch.  48 utterances of 48 different lengths from 3 to 140 frames
+    (all four classes): each equals its B = 1 call bit for bit, and the call costs a few batch steps, not 48 sequential conversions."""
+    import time
+    frames = [3 + (i * 137) // 47 for i in range(48)]
+    assert len(set(frames)) == 48 and min(frames) == 3 and max(frames) == 140
+    lens = [480 * f for f in frames]
+    wf = torch.zeros(48, max(lens))
+    for b, n in enumerate(lens):
+        wf[b, :n] = synth.synth_wave(1, n, seed=900 + b)[0]
+    wf = wf.to(DEV)
+    tgt = synth.synth_index(1000, seed=2).to(DEV)
+    angle = synth.synth_angle(48, max(frames), 7).to(DEV)
+    out = gen.convert(wf, tgt, -0.5, noise_angle=angle, lengths=lens)
+    bad = []
+    for b, f in enumerate(frames):
+        one = gen.convert(wf[b:b + 1, :lens[b]], tgt, -0.5, noise_angle=angle[b:b + 1, :, :f].contiguous())
+        if not torch.equal(out[b, :lens[b]], one[0]):
+            bad.append((b, f))
+        assert not out[b, lens[b]:].any()
+    assert not bad, f"ragged batch != B = 1 call for (utterance, frames): {bad}"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        gen.convert(wf, tgt, -0.5, noise_angle=angle, lengths=lens)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    print(f"[ragged] 48 utterances of 3 ... 140 frames (four classes): {ms:.2f} ms per call")
+    assert ms < 15.0
 
 
 def test_ragged_arguments_are_validated(gen):

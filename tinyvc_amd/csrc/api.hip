@@ -587,14 +587,6 @@ void tvc_ctx_destroy(tvc_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
-    for (auto& ln : ctx->lanes) {
-        if (ln.s) (void)hipStreamDestroy(ln.s);
-        if (ln.side) (void)hipStreamDestroy(ln.side);
-        if (ln.fork) (void)hipEventDestroy(ln.fork);
-        if (ln.join) (void)hipEventDestroy(ln.join);
-        if (ln.done) (void)hipEventDestroy(ln.done);
-    }
-    if (ctx->ev_ragged) (void)hipEventDestroy(ctx->ev_ragged);
     frontdoor_release(ctx);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->const_arena) (void)hipFree(ctx->const_arena);
@@ -1029,37 +1021,35 @@ int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* p
 
 // ---- ragged batches ---------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int kLanes = 4;
-struct RaggedGroup {
-    int64_t L;
-    std::vector<int> rows;
-    int lane;
-};
-// Utterances of at least kRagMinFrames frames (2.56 s) are converted as ragged batches INSIDE the kernels (ragged.h): every level of
-// FilterNet is then at least one 256-column tile long, which is what selects the kernels a conversion runs (film_s2 / conv_s2 against
-// conv3s's narrow tiles, decoder.hip film_conv) - so every utterance of the batch takes exactly the path its own B = 1 call takes and
-// the result is bit-identical to it.  Shorter ones keep the host-side plan: equal-length groups as ordinary batches on the lanes.
-constexpr int kRagMinFrames = 128;
+// Every utterance of a ragged call is converted inside the kernels (ragged.h), in batches of utterances that select the SAME kernels: which
+// FiLM kernel a FilterNet level runs depends on the utterance's own length there (film_s2 / the pre-split hand-over need one 256-column tile:
+// 2 T, 6 T, 24 T >= 256, decoder.hip film_conv), so the frame counts split into four classes at 11, 43 and 128 frames; inside a class every
+// utterance takes exactly the path its own B = 1 call takes and the result is bit-identical to it.
+constexpr int kRagClassBounds[3] = {11, 43, 128};
 constexpr int kRagMaxFrames = 80000;       // frames per in-kernel batch: 24 rows x 480 x 4 B x frames stays below the 32-bit byte offsets of the 24-channel kernels
 struct RagBatchPlan {
     std::vector<int> rows, frames;
     int Ttot = 0;
 };
-int ragged_split(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, std::vector<RagBatchPlan>* batches, std::vector<int>* short_rows) {
+int ragged_split(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, std::vector<RagBatchPlan>* batches) {
+    std::vector<RagBatchPlan> open(4);          // the batch being filled, per class
     for (int b = 0; b < B; ++b) {
         if (lens[b] <= 0 || lens[b] % kHop || lens[b] > Lmax || lens[b] < kNfft / 2 + 1)
             return fail(ctx, TVC_ERR_ARG, "ragged batch: lens[%d] = %lld must be a multiple of 480 in (960, Lmax]", b, (long long)lens[b]);
         const int T = (int)(lens[b] / kHop);
-        if (T < kRagMinFrames) {
-            short_rows->push_back(b);
-            continue;
-        }
         if (T > kRagMaxFrames) return fail(ctx, TVC_ERR_ARG, "ragged batch: lens[%d] = %lld is longer than a batch may be; convert it with tvc_convert_f32", b, (long long)lens[b]);
-        if (batches->empty() || batches->back().Ttot + T > kRagMaxFrames) batches->emplace_back();
-        batches->back().rows.push_back(b);
-        batches->back().frames.push_back(T);
-        batches->back().Ttot += T;
+        const int cls = (T >= kRagClassBounds[0]) + (T >= kRagClassBounds[1]) + (T >= kRagClassBounds[2]);
+        RagBatchPlan& p = open[cls];
+        if (p.Ttot + T > kRagMaxFrames) {
+            batches->push_back(p);
+            p = RagBatchPlan();
+        }
+        p.rows.push_back(b);
+        p.frames.push_back(T);
+        p.Ttot += T;
     }
+    for (int c = 3; c >= 0; --c)
+        if (!open[c].rows.empty()) batches->push_back(open[c]);
     return 0;
 }
 // one in-kernel ragged batch: [tables][convert workspace]; the drivers run it as ONE utterance of Ttot frames (B = 1) with ctx->rag set
@@ -1073,69 +1063,8 @@ int ragged_batch(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const RagBatchPl
     ctx->rag = nullptr;
     return rc;
 }
-// equal-length groups of the SHORT utterances, longest first, dealt to the lane with the least work so far
-int ragged_plan(tvc_ctx* ctx, const std::vector<int>& rows, const int64_t* lens, std::vector<RaggedGroup>* groups) {
-    std::map<int64_t, std::vector<int>, std::greater<int64_t>> by_len;
-    for (int b : rows) by_len[lens[b]].push_back(b);
-    double load[kLanes] = {0, 0, 0, 0};
-    for (auto& kv : by_len) {
-        int best = 0;
-        for (int l = 1; l < kLanes; ++l)
-            if (load[l] < load[best]) best = l;
-        load[best] += (double)kv.first * (double)kv.second.size() + 50000.0;      // (+ a launch-bound floor per group)
-        groups->push_back({kv.first, kv.second, best});
-    }
-    return 0;
-}
-// one group's scratch: [gathered wav][gathered angle][gathered out][convert workspace]; B_g == 1 rows are used in place
-int ragged_group(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const RaggedGroup& g, const float* wav, int64_t Lmax, const float* prepared, int64_t N,
-                 float pitch_shift, const float* angle, uint64_t seed, float* wave) {
-    const int Bg = (int)g.rows.size();
-    const int64_t L = g.L, T = L / kHop, Tmax = Lmax / kHop;
-    const bool gather = Bg > 1 && L != Lmax;
-    const bool gather_angle = angle && T != Tmax;
-    float* gw = gather || Bg > 1 ? ws.get<float>((size_t)Bg * L) : nullptr;
-    float* go = gather || Bg > 1 ? ws.get<float>((size_t)Bg * L) : nullptr;
-    float* ga = angle && (gather_angle || Bg > 1) ? ws.get<float>((size_t)Bg * kBins * T) : nullptr;
-    const float* in = gw;
-    float* out = go;
-    const float* ang = ga;
-    if (Bg == 1) {
-        in = wav + (size_t)g.rows[0] * Lmax;
-        out = wave + (size_t)g.rows[0] * Lmax;
-        if (angle && !gather_angle) ang = angle + (size_t)g.rows[0] * kBins * Tmax;
-    }
-    if (!dry) {
-        for (int i = 0; i < Bg; ++i) {
-            const int b = g.rows[i];
-            if (Bg > 1) TVC_HIP(ctx, hipMemcpyAsync(gw + (size_t)i * L, wav + (size_t)b * Lmax, (size_t)L * sizeof(float), hipMemcpyDeviceToDevice, s));
-            if (ga) TVC_HIP(ctx, hipMemcpy2DAsync(ga + (size_t)i * kBins * T, (size_t)T * sizeof(float), angle + (size_t)b * kBins * Tmax, (size_t)Tmax * sizeof(float),
-                                                   (size_t)T * sizeof(float), kBins, hipMemcpyDeviceToDevice, s));
-        }
-    }
-    TVC_CHECK(convert_impl(ctx, s, ws, dry, in, prepared, N, pitch_shift, ang, seed + (uint64_t)g.rows[0] * 0x9E3779B97F4A7C15ull, out, Bg, L));
-    if (!dry) {
-        for (int i = 0; i < Bg; ++i) {
-            const int b = g.rows[i];
-            if (Bg > 1) TVC_HIP(ctx, hipMemcpyAsync(wave + (size_t)b * Lmax, go + (size_t)i * L, (size_t)L * sizeof(float), hipMemcpyDeviceToDevice, s));
-        }
-    }
-    return 0;
-}
-// lanes' workspace regions: lane l starts at off[l]; every group of a lane reuses its region from the start.  Sized for a call with AND
-// without caller-supplied noise phases (the library's own draw needs a buffer the injected phases do not).
-int ragged_sizes(tvc_ctx* ctx, const std::vector<RaggedGroup>& groups, int64_t Lmax, int64_t N, size_t* lane_bytes) {
-    for (int l = 0; l < kLanes; ++l) lane_bytes[l] = 0;
-    for (auto& g : groups)
-        for (int with_angle = 0; with_angle < 2; ++with_angle) {
-            Ws ws(nullptr, 0, true);
-            TVC_CHECK(ragged_group(ctx, nullptr, ws, true, g, nullptr, Lmax, nullptr, N, 0.f, with_angle ? (const float*)256 : nullptr, 0, nullptr));
-            const size_t need = (ws.peak + 4095) & ~size_t(4095);
-            if (need > lane_bytes[g.lane]) lane_bytes[g.lane] = need;
-        }
-    return 0;
-}
-// the in-kernel batches run one after the other on the caller's stream and share one region
+// the batches of a call run one after the other on the caller's stream and share one workspace region.  Sized for a call with AND without
+// caller-supplied noise phases (the library's own draw needs a buffer the injected phases do not).
 int ragged_batch_bytes(tvc_ctx* ctx, const std::vector<RagBatchPlan>& batches, int64_t Lmax, int64_t N, size_t* bytes) {
     *bytes = 0;
     for (auto& p : batches)
@@ -1147,28 +1076,16 @@ int ragged_batch_bytes(tvc_ctx* ctx, const std::vector<RagBatchPlan>& batches, i
         }
     return 0;
 }
-struct RaggedCall {
-    std::vector<RagBatchPlan> batches;
-    std::vector<RaggedGroup> groups;
-    size_t batch_bytes = 0, lb[kLanes] = {0, 0, 0, 0};
-    size_t total() const { return batch_bytes + lb[0] + lb[1] + lb[2] + lb[3] + 4096; }
-};
-int ragged_call_plan(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, int64_t N, RaggedCall* c) {
-    std::vector<int> short_rows;
-    TVC_CHECK(ragged_split(ctx, B, Lmax, lens, &c->batches, &short_rows));
-    TVC_CHECK(ragged_plan(ctx, short_rows, lens, &c->groups));
-    TVC_CHECK(ragged_batch_bytes(ctx, c->batches, Lmax, N, &c->batch_bytes));
-    TVC_CHECK(ragged_sizes(ctx, c->groups, Lmax, N, c->lb));
-    return 0;
-}
 }  // namespace
 
 int tvc_workspace_bytes_ragged(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, int64_t N, size_t* out_bytes) {
     TVC_CHECK(need_ready(ctx, NEED_NONE));
     if (!out_bytes || !lens || B <= 0 || Lmax <= 0 || Lmax % kHop != 0 || N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_workspace_bytes_ragged: need B>0, Lmax%%480==0, N>=4");
-    RaggedCall c;
-    TVC_CHECK(ragged_call_plan(ctx, B, Lmax, lens, N, &c));
-    *out_bytes = c.total();
+    std::vector<RagBatchPlan> batches;
+    TVC_CHECK(ragged_split(ctx, B, Lmax, lens, &batches));
+    size_t bytes = 0;
+    TVC_CHECK(ragged_batch_bytes(ctx, batches, Lmax, N, &bytes));
+    *out_bytes = bytes + 4096;
     return TVC_OK;
 }
 
@@ -1180,73 +1097,18 @@ int tvc_convert_ragged_f32(tvc_ctx* ctx, void* stream, const float* wav, int64_t
     TVC_CHECK(blob_check(ctx, prepared, N, "tvc_convert_ragged_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    RaggedCall c;
-    TVC_CHECK(ragged_call_plan(ctx, B, Lmax, lens, N, &c));
-    if (c.total() - 4096 > ws_bytes) return fail(ctx, TVC_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", c.total() - 4096, ws_bytes);
-    if (!c.groups.empty() && ctx->lanes.empty()) {      // created on first use (not inside a stream capture); published only when complete
-        std::vector<tvc_ctx::Lane> lanes(kLanes);
-        hipEvent_t ev = nullptr;
-        bool ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
-        for (auto& ln : lanes)
-            ok = ok && hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&ln.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ln.join, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            for (auto& ln : lanes) {
-                if (ln.s) (void)hipStreamDestroy(ln.s);
-                if (ln.side) (void)hipStreamDestroy(ln.side);
-                if (ln.fork) (void)hipEventDestroy(ln.fork);
-                if (ln.join) (void)hipEventDestroy(ln.join);
-                if (ln.done) (void)hipEventDestroy(ln.done);
-            }
-            if (ev) (void)hipEventDestroy(ev);
-            return fail(ctx, TVC_ERR_HIP, "ragged batch: could not create the lanes' streams / events");
-        }
-        ctx->lanes.swap(lanes);
-        ctx->ev_ragged = ev;
-    }
+    std::vector<RagBatchPlan> batches;
+    TVC_CHECK(ragged_split(ctx, B, Lmax, lens, &batches));
+    size_t bytes = 0;
+    TVC_CHECK(ragged_batch_bytes(ctx, batches, Lmax, N, &bytes));
+    if (bytes > ws_bytes) return fail(ctx, TVC_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", bytes, ws_bytes);
     // the whole padded output is cleared once: every kernel writes its utterance's own samples only
     TVC_HIP(ctx, hipMemsetAsync(wave, 0, (size_t)B * Lmax * sizeof(float), s));
-    int rc = 0;
-    bool used[kLanes] = {false, false, false, false};
-    if (!c.groups.empty()) {
-        // fork: every lane that has work starts behind what is already queued on the caller's stream
-        TVC_HIP(ctx, hipEventRecord(ctx->ev_ragged, s));
-        size_t off[kLanes];
-        off[0] = c.batch_bytes;
-        for (int l = 1; l < kLanes; ++l) off[l] = off[l - 1] + c.lb[l - 1];
-        hipStream_t side0 = ctx->side;
-        hipEvent_t fork0 = ctx->ev_fork, join0 = ctx->ev_join;
-        for (auto& g : c.groups) {
-            tvc_ctx::Lane& ln = ctx->lanes[g.lane];
-            if (!used[g.lane]) {
-                if (hipStreamWaitEvent(ln.s, ctx->ev_ragged, 0) != hipSuccess) { rc = fail(ctx, TVC_ERR_HIP, "ragged: stream wait"); break; }
-                used[g.lane] = true;
-            }
-            ctx->side = ln.side;             // the pitch branch of this group forks onto the lane's own side stream
-            ctx->ev_fork = ln.fork;
-            ctx->ev_join = ln.join;
-            Ws ws((char*)wsp + off[g.lane], c.lb[g.lane], false);
-            rc = ragged_group(ctx, ln.s, ws, false, g, wav, Lmax, prepared, N, pitch_shift, noise_angle, seed, wave);
-            if (rc) break;
-        }
-        ctx->side = side0;
-        ctx->ev_fork = fork0;
-        ctx->ev_join = join0;
+    for (auto& p : batches) {
+        Ws ws(wsp, bytes, false);
+        TVC_CHECK(ragged_batch(ctx, s, ws, false, p, wav, Lmax, prepared, N, pitch_shift, noise_angle, seed, wave));
     }
-    // the in-kernel batches, one after the other on the caller's stream (beside the lanes)
-    for (auto& p : c.batches) {
-        if (rc) break;
-        Ws ws(wsp, c.batch_bytes, false);
-        rc = ragged_batch(ctx, s, ws, false, p, wav, Lmax, prepared, N, pitch_shift, noise_angle, seed, wave);
-    }
-    // join (also on an error path: the caller's stream must not run ahead of what was queued)
-    for (int l = 0; l < kLanes; ++l)
-        if (used[l]) {
-            (void)hipEventRecord(ctx->lanes[l].done, ctx->lanes[l].s);
-            (void)hipStreamWaitEvent(s, ctx->lanes[l].done, 0);
-        }
-    return rc;
+    return TVC_OK;
 }
 
 int tvc_profile_enable(tvc_ctx* ctx, int on) {

@@ -491,7 +491,8 @@ __device__ __forceinline__ void split_phase(f32x16 (&hi)[TL::WM][TL::WN], f32x16
 // tile is loaded, split and written once instead of twice and a slab carries 6 MFMAs per wave instead of 3.
 template <class TL>
 __device__ __forceinline__ void film_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ F6, int MT, int mt0, int mtoff,
-                                          const float* __restrict__ xb, int len, int s) {
+                                          const float* __restrict__ xb, int len, int s, int rs_ = 0) {
+    const int rs = rs_ ? rs_ : len;                      // row stride of the cond tensor (ragged batches: not the utterance's length)
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER;
     constexpr int KG = TL::KG, GP = 2 * MTB * kParts, PIECES = KG * GP, A_PER = (PIECES + NW - 1) / NW;   // per 16-channel group: scale and shift pieces of MTB m-tiles
     static_assert(A_PER <= SlabRegs<TL>::A_MAX, "FiLM weight pieces must fit the staging registers");
@@ -504,32 +505,32 @@ __device__ __forceinline__ void film_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
         const int grp = q2 / (MTB * kParts), rem = q2 - grp * (MTB * kParts);
         r.ar[i] = ldg_so4(F6 + ((long)s * KG * MT + mt0) * kPU4, 16u * (unsigned)((kg * MT + grp * mtoff) * kPU4 + rem * 64 + lane));
     }
-    const float* xc = xb + (long)s * 16 * KG * len;
+    const float* xc = xb + (long)s * 16 * KG * rs;
 #pragma unroll
     for (int i = 0; i < X_PER; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.xr[i][j] = ldg_so(xc + (long)j * len, 4u * m.xo[i]);
+        for (int j = 0; j < 8; ++j) r.xr[i][j] = ldg_so(xc + (long)j * rs, 4u * m.xo[i]);
 }
 template <class TL>
 __device__ __forceinline__ void film_first_load(SlabRegs<TL>& r, const uint4* __restrict__ F6, int MT, int mt0, int mtoff,
-                                                const float* __restrict__ xb, int len, int t0) {
+                                                const float* __restrict__ xb, int len, int t0, int rs_ = 0) {
     SlabMap<TL> m;
-    make_map<TL>(m, len, 0, t0);
-    film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, 0);
+    make_map<TL>(m, len, 0, t0, 0, 0u, 0, 0, 0.f, 1.f, nullptr, rs_);
+    film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, 0, rs_);
 }
 // (scale, shift) accumulator pairs: (asc, lsc), (ash, lsh)
 template <class TL, class Next>
 __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16 (&lsc)[TL::WM][TL::WN], f32x16 (&ash)[TL::WM][TL::WN], f32x16 (&lsh)[TL::WM][TL::WN],
                                            SlabRegs<TL>& r, const uint4* __restrict__ F6,
                                            int MT, int mt0, int mtoff, const float* __restrict__ xb, int Cin, int len, int t0, uint4* As, uint4* Xs,
-                                           Next next, float xs) {
+                                           Next next, float xs, int rs_ = 0) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
     constexpr int KG = TL::KG, GP = 2 * MTB * kParts, PIECES = KG * GP, A_PER = (PIECES + NW - 1) / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NWV, wn = wave - wm * NWV;
     SlabMap<TL> m;
-    make_map<TL>(m, len, 0, t0);
+    make_map<TL>(m, len, 0, t0, 0, 0u, 0, 0, 0.f, 1.f, nullptr, rs_);
     const int nslab = Cin / (16 * KG);
     const uint4* as0 = As + wm * WM * kPU4 + lane;
     const uint4* xs0 = Xs + lh * XROW + wn * WN * 32 + l31;
@@ -553,7 +554,7 @@ __device__ __forceinline__ void film_phase(f32x16 (&asc)[TL::WM][TL::WN], f32x16
     for (int s = 0; s < nslab; ++s) {
         slab_barrier();
         lstore();
-        if (s + 1 < nslab) film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, s + 1);
+        if (s + 1 < nslab) film_load<TL>(r, m, F6, MT, mt0, mtoff, xb, len, s + 1, rs_);
         else next();
         slab_barrier();
         const uint4* as = as0;
@@ -596,8 +597,12 @@ template <class TL, bool RES>
 __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][TL::WN], float* __restrict__ y, const float* __restrict__ res,
                                            int b, int M, int len, int mt0, int t0, float& mx, float* __restrict__ y2 = nullptr, int f2 = 0, int rlin = 0, float rscale = 0.f,
                                            int rs_ = 0, int coloff = 0) {
-    // ragged batches (ragged.h): rs_ = the tensors' row stride, coloff = first column of the tile's utterance (b = 0 then), len = its length
+    // ragged batches (ragged.h): rs_ = the tensors' row stride, coloff = first column of the tile's utterance (b = 0 then), len = its length;
+    // an interpolated residual's low-rate tensor is laid out alike: rlin = ITS row stride, the utterance's low-rate length = len / (rs / rlin)
     const int rs = rs_ ? rs_ : len;
+    // (uniform integer divisions run on the vector ALU: readfirstlane brings the quotients back where the uniform-base loads below need them)
+    const int rvalid = (rs_ && rlin > 0) ? __builtin_amdgcn_readfirstlane(len / (rs / rlin)) : rlin;         // low-rate samples of this utterance
+    const int rcol = (rs_ && rlin > 0) ? __builtin_amdgcn_readfirstlane(coloff / (rs / rlin)) : 0;           // its first low-rate column
     constexpr int WM = TL::WM, WN = TL::WN, BM = TL::BM, BN = TL::BN, OS = TL::OS, NTHR = TL::NTHR;
     // The thread index is laundered through an empty asm: everything below depends on it only, so the compiler would hoist
     // all of the store pass's index math (64-bit offsets included) out of the persistent tile loop and keep ~25 registers
@@ -621,7 +626,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
     __builtin_amdgcn_sched_barrier(0);                         // nothing of the store pass moves up into the FiLM combine (three accumulator sets live there)
     float* yb = y + ((long)b * M + mt0 * 32) * rs + coloff + t0;      // offsets inside the tile's rows fit 32 bits
     // rlin > 0: the residual is F.interpolate(res_low) of a [B][M][rlin] tensor, evaluated here instead of read back
-    const float* rb = RES ? (rlin > 0 ? res + ((long)b * M + mt0 * 32) * rlin : res + ((long)b * M + mt0 * 32) * rs + coloff + t0) : nullptr;
+    const float* rb = RES ? (rlin > 0 ? res + ((long)b * M + mt0 * 32) * rlin + rcol : res + ((long)b * M + mt0 * 32) * rs + coloff + t0) : nullptr;
     const int rows = M - mt0 * 32 < BM ? M - mt0 * 32 : BM;
     const bool vec = ((rs | coloff) & 3) == 0;              // rows start 16-byte aligned (t0 is a multiple of 32)
     // optional 1/f2-rate copy for the next Downsample block (see C3EpiBias): pick for f2 = 3 / 5, two-sample mean for f2 = 4
@@ -638,7 +643,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int t = t0 + c + u < len ? t0 + c + u : len - 1;
-                const Lerp lc = lerp_coord(t, rscale, rlin);
+                const Lerp lc = lerp_coord(t, rscale, rvalid);
                 o0[u] = 4u * (unsigned)lc.i0;
                 o1[u] = 4u * (unsigned)lc.i1;
                 lam[u] = lc.w1;
@@ -748,7 +753,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int t = t0 + c + u < len ? t0 + c + u : len - 1;
-                const Lerp lc = lerp_coord(t, rscale, rlin);
+                const Lerp lc = lerp_coord(t, rscale, rvalid);
                 w[u] = e[u] + lerp_eval(lc, rb[row * rlin + lc.i0], rb[row * rlin + lc.i1]);
             }
             if (vec && t0 + c + 3 < len) {
@@ -804,7 +809,7 @@ __device__ __forceinline__ void tile_store(float* Ot, const f32x16 (&v)[TL::WM][
 // look the column's utterance up for the block-floating-point scale only.
 template <class TL, int TAPS, bool LRELU, class Epi, bool FILM, bool SCALED = false, bool LERP = false, bool CLAMP = false, bool RAG = false>
 __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ? S_WPE_F : (Epi::kIgemm ? (TL::NW <= 8 ? S_WPE_G : 5) : S_WPE)))) void conv3s_kernel(ConvSArgs a, Epi ep) {
-    static_assert(!RAG || (!FILM && !LERP && !SCALED), "ragged batches: plain / residual-conv / GEMM launches only");
+    static_assert(!RAG || (!LERP && !SCALED && !(FILM && TL::WN > 1)), "ragged batches: plain / residual-conv / narrow FiLM / GEMM launches only");
     constexpr bool RAGT = RAG && !Epi::kIgemm;      // time-tiled ragged walk
     constexpr bool RAGG = RAG && Epi::kIgemm;       // GEMM over the whole ragged batch
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, A_U4 = TL::a_u4(TAPS);
@@ -831,16 +836,16 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         const int nt_id = v / mblocks, mb = v - nt_id * mblocks;
         mt0 = mb * MTB;
         if constexpr (RAGT) {
-            b = rag_find(a.rag.ts, a.rag.B, nt_id, b);
-            t0 = (nt_id - a.rag.ts[b]) * TL::BN;
+            b = __builtin_amdgcn_readfirstlane(rag_find(a.rag.ts, a.rag.B, __builtin_amdgcn_readfirstlane(nt_id), b));      // (v / mblocks ran on the vector ALU)
+            t0 = __builtin_amdgcn_readfirstlane((nt_id - a.rag.ts[b]) * TL::BN);
         } else {
             b = nt_id / a.tiles_per_utt;
             t0 = (nt_id - b * a.tiles_per_utt) * TL::BN;
         }
     };
     // RAGT: utterance b's length and first column at this launch's rate
-    auto ulen = [&](int b_) __attribute__((always_inline)) { return a.rag.tb[b_] * a.rag.mult; };
-    auto uoff = [&](int b_) __attribute__((always_inline)) { return a.rag.pre[b_] * a.rag.mult; };
+    auto ulen = [&](int b_) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(a.rag.tb[b_] * a.rag.mult); };
+    auto uoff = [&](int b_) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(a.rag.pre[b_] * a.rag.mult); };
     int tile, vtiles;
     tile_range(ntiles, tile, vtiles);
     SlabRegs<TL> regs;
@@ -864,7 +869,8 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     // alive: 4 sets at the peak instead of 5, which did not fit the 168 registers of a 12-wave workgroup)
     constexpr bool FILM_FIRST = FILM && TL::WN == 1;
     auto load_first = [&](int mt0_, int b_, int t0_) __attribute__((always_inline)) {
-        if constexpr (FILM_FIRST) film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0_, a.MT, a.cond + (long)b_ * a.Ccond * len, len, t0_);
+        if constexpr (FILM_FIRST && RAGT) film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0_, a.MT, a.cond + uoff(b_), ulen(b_), t0_, rs);
+        else if constexpr (FILM_FIRST) film_first_load<TL>(regs, a.sc6, 2 * a.MT, mt0_, a.MT, a.cond + (long)b_ * a.Ccond * len, len, t0_);
         else if constexpr (RAGT) first_load<TL, TAPS, LERP, CLAMP>(regs, a.A6, a.MT, mt0_, a.x + uoff(b_), a.Cin, ulen(b_), a.dil, t0_, 0, 0u, a.cmax, 0, 0.f, rs);
         else first_load<TL, TAPS, LERP, CLAMP>(regs, a.A6, a.MT, mt0_, fT ? a.x : a.x + (long)b_ * a.xstride, a.Cin, len, a.dil, t0_, fT, fstride, a.cmax, a.lin, a.lscale);
     };
@@ -987,7 +993,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         } else if constexpr (FILM) {
             // conv -> FiLM -> + residual (decoder.py:94-97,181-182): scale and shift come from one more 1x1 phase over
             // the cond tile on the same output tiles; (conv, scale, shift) combine in registers.
-            const float* cb = a.cond + (long)b * a.Ccond * len;
+            const float* cb = RAGT ? a.cond + coloff : a.cond + (long)b * a.Ccond * len;
             const int mtoff = a.MT;                                   // the stacked FiLM image has 2 * a.MT m-tiles: scale rows, then shift rows
             const Bfp sc = bfp_load(a.amax_c, b);
             f32x16 asc[WM][WN], lsc[WM][WN], ash[WM][WN], lsh[WM][WN];
@@ -996,11 +1002,11 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             clear(ash);
             clear(lsh);
             film_phase<TL>(asc, lsc, ash, lsh, regs, a.sc6, 2 * a.MT, mt0, mtoff, cb, a.Ccond, len, t0, As, Xs,
-                           [&]() __attribute__((always_inline)) { first_load<TL, TAPS, LERP, false>(regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, 0, 0u, 0, a.lin, a.lscale); }, sc.s);
+                           [&]() __attribute__((always_inline)) { first_load<TL, TAPS, LERP, false>(regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, 0, 0u, 0, a.lin, a.lscale, rs); }, sc.s, rs);
             fold(asc, lsc, Bs + 4 * TL::BM, sc.inv);            // scale and shift without their biases: frees two sets before the conv phase
             fold(ash, lsh, Bs + 5 * TL::BM, sc.inv);
             split_phase<TL, TAPS, A_U4, LRELU, S_FB_F, false, LERP, false>(hi, lo, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs, load_next_tile, sx.s, nullptr, 0, 0u, 0,
-                                                                            a.lin, a.lscale);
+                                                                            a.lin, a.lscale, 0, NoMid(), nullptr, rs);
             fold(hi, lo, Bs + 3 * TL::BM, sx.inv);
             // out = ((h + b)(sc + b_sc)) + (sh + b_sh), + residual in the store pass
             {
@@ -1014,7 +1020,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                         for (int j = 0; j < WN; ++j)
                             hi[i][j][r] = __fadd_rn(__fmul_rn(hi[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
                     }
-                tile_store<TL, true>(reinterpret_cast<float*>(smem_s), hi, ep.y, ep.res, b, ep.M, len, mt0, t0, mx_run, nullptr, 0, ep.res_lin, ep.res_scale);
+                tile_store<TL, true>(reinterpret_cast<float*>(smem_s), hi, ep.y, ep.res, RAGT ? 0 : b, ep.M, len, mt0, t0, mx_run, nullptr, 0, ep.res_lin, ep.res_scale, rs, coloff);
             }
         } else {
             float inv = sx.inv;
@@ -1180,7 +1186,7 @@ inline int conv3s_launch_t(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const 
     const int slots = ncu * bpc;        // persistent: one resident workgroup per slot walks a contiguous range of the tiles
     if (ctx->rag) {
         // ragged batch (ragged.h): the driver passed B = 1 and len = the batch's columns at this rate (= the row stride)
-        if constexpr (!FILM && !LERP && !SCALED) {
+        if constexpr (!LERP && !SCALED && !(FILM && TL::WN > 1)) {
             if (B != 1 || flat || a.len % ctx->rag->Ttot != 0) return fail(ctx, TVC_ERR_STATE, "conv3s: a ragged batch runs as one long utterance");
             static bool ready_rag[64] = {};
             bool& rr = ready_rag[ctx->device & 63];
@@ -1224,7 +1230,7 @@ inline int conv3s_launch(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const fl
         const long mb = w.MT6 / 3;
         const long tiles_w = mb * ((len + 255) / 256) * B;
         const long slots = 256 * S_BPC;
-        const bool wide = tiles_w >= slots;
+        const bool wide = tiles_w >= slots && !ctx->rag;      // (a ragged batch runs the narrow tile: its utterances are shorter than one wide tile)
         if (wide)
             return conv3s_launch_t<SplitTile<3, 1, 4, 2>, 3, LRELU, Epi, FILM, false, LERP>(ctx, s, w, x, B, Cin, len, dil, ep, wsc, wsh, cond, Ccond, 0, S_BPC, nullptr, false,
                                                                                            0, lin, lscale, bfp);

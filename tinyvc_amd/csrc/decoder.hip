@@ -303,7 +303,7 @@ static int film_conv(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const Packed
     int rc = 0;
     // The two kernels round differently (film_s2.h: one accumulator per result), so the choice may depend on nothing but the utterance's
     // own shape: an utterance converts to the same samples in every batch.  Below one 256-column tile the narrow conv3s tile wastes less.
-    if (len >= FS2::BN && film_s2_try(&rc, ctx, s, fu, h, cond, B, C, len, dil, out, res, res_lin, res_scale, bfp)) return rc;
+    if (rag_min_len(ctx, len) >= FS2::BN && film_s2_try(&rc, ctx, s, fu, h, cond, B, C, len, dil, out, res, res_lin, res_scale, bfp)) return rc;
     return conv3s_launch<true, C3EpiFilmFused, true>(ctx, s, w, h, B, C, len, dil, C3EpiFilmFused{out, w.bias, bsc, bsh, res, C, len, res_lin, res_scale}, bfp, &fw, &fw,
                                                      cond, C);
 }
@@ -316,7 +316,7 @@ static int film_conv(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const Packed
 static int conv_film_half(tvc_ctx* ctx, hipStream_t s, const PackedW& ca, const PackedW& cb, const PackedW& fw, const FilmU& fu, const float* x, int lin, float lscale,
                           int da, int db, float* h, const float* cond, int B, int C, int len, float* out, const float* bsc, const float* bsh, const float* res,
                           int res_lin, float res_scale, const float* ma_in, float* mh, const float* mcond, float* mout) {
-    const bool pre = len >= FS2::BN && fu.img && fu.C == C && fu.hb_w > 0.f && C % 96 == 0 && C <= 384 && ma_in && mcond && res && db >= 1 && db <= FS2::MAXD &&
+    const bool pre = rag_min_len(ctx, len) >= FS2::BN && fu.img && fu.C == C && fu.hb_w > 0.f && C % 96 == 0 && C <= 384 && ma_in && mcond && res && db >= 1 && db <= FS2::MAXD &&
                      (long)C * len * 4 < (1L << 32) && (res_lin <= 0 || (long)C * res_lin * 4 < (1L << 32));
     if (pre) {
         int rc = 0;

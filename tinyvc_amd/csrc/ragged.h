@@ -30,7 +30,7 @@ struct RagDev {                   // device view handed to a kernel (tb == nullp
 };
 
 struct RagHost {                  // one ragged (sub-)batch of a call; lives for the duration of the call
-    int B = 0, Ttot = 0, Tmax = 0, Tlong = 0;     // Tlong = the longest utterance's frames
+    int B = 0, Ttot = 0, Tmax = 0, Tlong = 0, Tshort = 0;     // Tlong / Tshort = the longest / shortest utterance's frames
     std::vector<int> tb, pre, row;
     const int* d_tb = nullptr;
     const int* d_pre = nullptr;
@@ -55,6 +55,10 @@ int rag_setup(tvc_ctx* ctx, hipStream_t s, bool dry, RagHost& h, const std::vect
 // the view of the context's current ragged batch for a launch at `mult` samples per frame; bn > 0: with the column-tile table of
 // bn-wide tiles (built on first use), *ntiles = its total.  Equal-length calls (no current batch) get the empty view.
 int rag_view(tvc_ctx* ctx, hipStream_t s, int mult, int bn, RagDev* out, int* ntiles);
+
+// Shape-dependent kernel choices (decoder.hip: film_s2 needs one 256-column tile per utterance) look at the SHORTEST utterance of a ragged batch:
+// a batch only holds utterances that make the same choices (api.hip ragged_split), so this is every member's own decision.
+int rag_min_len(const tvc_ctx* ctx, int len);
 
 // ---- device side -------------------------------------------------------------------------------------------------------------
 // utterance of column tile ct: ts[b] <= ct < ts[b + 1]; `hint` = the previous tile's utterance (a persistent walk only moves forward)

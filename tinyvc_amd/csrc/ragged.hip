@@ -66,9 +66,11 @@ int rag_setup(tvc_ctx* ctx, hipStream_t s, bool dry, RagHost& h, const std::vect
     h.Tmax = Tmax;
     h.pre.assign(h.B + 1, 0);
     h.Tlong = 0;
+    h.Tshort = h.B ? frames[0] : 0;
     for (int b = 0; b < h.B; ++b) {
         h.pre[b + 1] = h.pre[b] + frames[b];
         if (frames[b] > h.Tlong) h.Tlong = frames[b];
+        if (frames[b] < h.Tshort) h.Tshort = frames[b];
     }
     h.Ttot = h.pre[h.B];
     int* p = scratch;
@@ -93,6 +95,8 @@ int rag_setup(tvc_ctx* ctx, hipStream_t s, bool dry, RagHost& h, const std::vect
     hipLaunchKernelGGL(rag_prefix_kernel, dim3(1), dim3(1024), 0, s, d_tb, d_pre, d_col2b, h.B, 1, 0);
     return launch_check(ctx, "rag tables");
 }
+
+int rag_min_len(const tvc_ctx* ctx, int len) { return ctx->rag ? ctx->rag->Tshort * (len / ctx->rag->Ttot) : len; }
 
 int rag_view(tvc_ctx* ctx, hipStream_t s, int mult, int bn, RagDev* out, int* ntiles) {
     *out = RagDev{};

@@ -97,13 +97,6 @@ struct tvc_ctx {
     std::vector<hipEvent_t> event_pool;       // recycled hipEvents: no hipEventCreate on the hot path
     hipStream_t side = nullptr;               // fork/join stream: the pitch estimator runs beside the SSL chain
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // ragged batches: the equal-length groups of a call run concurrently, each on a lane with its own pitch side stream and events
-    struct Lane {
-        hipStream_t s = nullptr, side = nullptr;
-        hipEvent_t fork = nullptr, join = nullptr, done = nullptr;
-    };
-    std::vector<Lane> lanes;
-    hipEvent_t ev_ragged = nullptr;
     tvc::RagHost* rag = nullptr;              // the ragged batch the drivers are currently running for (ragged.h); nullptr = equal lengths
     bool enc_ready = false, dec_ready = false;  // which checkpoint groups tvc_finalize_weights packed
     char enc_missing[160] = {0}, dec_missing[160] = {0};

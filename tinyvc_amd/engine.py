@@ -377,7 +377,7 @@ class Engine:
 
     def convert_ragged(self, wav, lengths, prepared, N, pitch_shift, noise_angle=None):
         """wav [B, Lmax] (row b holds an utterance of lengths[b] samples, a multiple of 480, zero-padded behind it) -> [B, Lmax]:
-        every utterance converted over its OWN length (tvc_convert_ragged_f32: equal-length groups run as concurrent batches)."""
+        every utterance converted over its OWN length (tvc_convert_ragged_f32: per-utterance lengths inside the kernels)."""
         wav = _prep(wav, "wave", self.device)
         B, Lmax = wav.shape
         if Lmax % spec.HOP:
