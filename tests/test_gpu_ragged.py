@@ -228,3 +228,28 @@ def test_infer_py_bounds_its_batches_and_skips_files_it_cannot_convert(tmp_path,
             continue
         y, sr = audio_io.load(str(d / "out" / f"{name}.wav"))
         assert sr == 24000 and y.shape == (1, -(-n // 480) * 480) and torch.isfinite(y).all() and float(y.abs().max()) > 1e-3
+
+
+def test_many_utterances_and_several_batches_per_class(gen, monkeypatch):
+    """1 500 utterances in one call (more than one 1024-wide round of the table scans, lengths uploaded in two kernel-argument chunks)
+    and, with the per-batch frame cap lowered, several in-kernel batches per length class: spot rows equal their B = 1 calls."""
+    B = 1500
+    frames = [3 + (i * 7) % 23 for i in range(B)]                 # 3 ... 25 frames: two classes
+    lens = [480 * f for f in frames]
+    g = torch.Generator().manual_seed(5)
+    wf = 0.2 * torch.randn(B, max(lens), generator=g)
+    for b, n in enumerate(lens):
+        wf[b, n:] = 0
+    wf = wf.to(DEV)
+    tgt = synth.synth_index(64, seed=3).to(DEV)
+    angle = synth.synth_angle(B, max(frames), 9).to(DEV)
+    out = gen.convert(wf, tgt, 0.0, noise_angle=angle, lengths=lens)
+    rows = [0, 1, 511, 1023, 1024, 1025, 1499]
+    ones = {}
+    for b in rows:
+        ones[b] = gen.convert(wf[b:b + 1, :lens[b]], tgt, 0.0, noise_angle=angle[b:b + 1, :, :frames[b]].contiguous())[0]
+        assert torch.equal(out[b, :lens[b]], ones[b]), f"utterance {b} ({frames[b]} frames)"
+        assert not out[b, lens[b]:].any()
+    monkeypatch.setenv("TVC_RAG_MAX_FRAMES", "4000")            # ~ 5 batches per class
+    out2 = gen.convert(wf, tgt, 0.0, noise_angle=angle, lengths=lens)
+    assert torch.equal(out2, out)

@@ -3,6 +3,8 @@
 #include <functional>
 #include <mutex>
 
+#include <cstdlib>
+
 #include "tvc_common.h"
 
 using namespace tvc;
@@ -1033,6 +1035,11 @@ struct RagBatchPlan {
 };
 int ragged_split(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, std::vector<RagBatchPlan>* batches) {
     std::vector<RagBatchPlan> open(4);          // the batch being filled, per class
+    int max_frames = kRagMaxFrames;
+    if (const char* e = std::getenv("TVC_RAG_MAX_FRAMES")) {      // tests: a small cap exercises the several-batches-per-class path
+        const int v = std::atoi(e);
+        if (v > 0 && v < max_frames) max_frames = v;
+    }
     for (int b = 0; b < B; ++b) {
         if (lens[b] <= 0 || lens[b] % kHop || lens[b] > Lmax || lens[b] < kNfft / 2 + 1)
             return fail(ctx, TVC_ERR_ARG, "ragged batch: lens[%d] = %lld must be a multiple of 480 in (960, Lmax]", b, (long long)lens[b]);
@@ -1040,7 +1047,7 @@ int ragged_split(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, std::ve
         if (T > kRagMaxFrames) return fail(ctx, TVC_ERR_ARG, "ragged batch: lens[%d] = %lld is longer than a batch may be; convert it with tvc_convert_f32", b, (long long)lens[b]);
         const int cls = (T >= kRagClassBounds[0]) + (T >= kRagClassBounds[1]) + (T >= kRagClassBounds[2]);
         RagBatchPlan& p = open[cls];
-        if (p.Ttot + T > kRagMaxFrames) {
+        if (p.Ttot + T > max_frames && !p.rows.empty()) {
             batches->push_back(p);
             p = RagBatchPlan();
         }
