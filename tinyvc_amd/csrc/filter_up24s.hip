@@ -494,7 +494,9 @@ struct Down0SArgs {
 };
 
 template <bool RAG>
-static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void down0s_kernel(Down0SArgs a) {
+// (two 60 KB workgroups per CU, four waves per SIMD at <= 128 registers: this kernel waits on HBM - 1.1 GB in and out per step - more than on its
+// 15 MFMAs per tile, and the second workgroup's loads fly under the first one's arithmetic: 0.371 -> 0.339 ms same-box for the input stage, round 4)
+static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void down0s_kernel(Down0SArgs a) {
     constexpr int W = 254, XW = 256, XP = XW, NT = 512;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_d[];
     u32x4* Xs = reinterpret_cast<u32x4*>(smem_d);              // [2 buffers][2 parts][3 groups][XP]
@@ -633,7 +635,7 @@ int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float*
         if (B != 1 || len != ctx->rag->Ttot * kHop) return fail(ctx, TVC_ERR_STATE, "down0s: a ragged batch runs as one long utterance");
         TVC_CHECK(rag_view(ctx, s, kHop, 254, &a.rag, &a.ntiles));
     }
-    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    const int grid = a.ntiles < 2 * ncu ? a.ntiles : 2 * ncu;      // two persistent workgroups per CU
     if (ctx->rag) hipLaunchKernelGGL(down0s_kernel<true>, dim3(grid), dim3(512), lds, s, a);
     else hipLaunchKernelGGL(down0s_kernel<false>, dim3(grid), dim3(512), lds, s, a);
     return launch_check(ctx, "down0s");
