@@ -63,7 +63,9 @@ struct Conv48Args {
 // RES: 0 none, 1 direct, 2 interpolated.  C5: Upsample.c5 (1x1, 48 -> 24, decoder.py:171,189) applied to the finished tile
 // before it leaves the CU: the 48-channel block output is never written, only c5's 24 rows are.
 template <bool FILM, bool LERP, int RES, bool C5 = false, bool RAG = false>
-__global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void conv48s_kernel(Conv48Args a) {
+// (launches without FiLM - 73 KB of LDS, <= 128 registers - run TWO workgroups per CU: a plain 48-channel conv waits on its 0.47 GB of HBM traffic more
+// than on its 27 MFMAs per tile, and the second workgroup's loads fly under the first one's arithmetic: Upsample 3 0.80 -> 0.765 ms same-box, round 4)
+__global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 : 4))) void conv48s_kernel(Conv48Args a) {
     constexpr int C = kC48, BN = kBN48, XP = kXP48, NT = kNT48;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_q[];
     u32x4* Xs = reinterpret_cast<u32x4*>(smem_q);              // [2 parts][6 groups][XP]
@@ -410,7 +412,8 @@ int launch48(tvc_ctx* ctx, hipStream_t s, Conv48Args a, int B) {
         if (B != 1 || a.len % ctx->rag->Ttot != 0) return fail(ctx, TVC_ERR_STATE, "conv48s: a ragged batch runs as one long utterance");
         TVC_CHECK(rag_view(ctx, s, a.len / ctx->rag->Ttot, kBN48, &a.rag, &a.ntiles));
     }
-    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    const int wpc = FILM ? 1 : 2;                     // persistent workgroups per CU
+    const int grid = a.ntiles < wpc * ncu ? a.ntiles : wpc * ncu;
     if (ctx->rag) hipLaunchKernelGGL((conv48s_kernel<FILM, LERP, RES, C5, true>), dim3(grid), dim3(kNT48), lds, s, a);
     else hipLaunchKernelGGL((conv48s_kernel<FILM, LERP, RES, C5>), dim3(grid), dim3(kNT48), lds, s, a);
     return launch_check(ctx, "conv48s");
