@@ -211,6 +211,10 @@ int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* p
  * one after the other on `stream`.  Every utterance gets exactly the samples a B = 1 tvc_convert_f32 call gives it.  A single
  * utterance may be up to 80 000 frames.  Workspace: tvc_workspace_bytes_ragged. */
 int tvc_workspace_bytes_ragged(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, int64_t N, size_t* out_bytes);
+/* Which utterances of a ragged call share their kernel launches: batch_of_row[b] = the in-kernel batch (0 .. *n_batches - 1, the order they
+ * run in) that utterance b is converted in.  Pure host logic, no context, no device: the split tvc_convert_ragged_f32 makes (length classes
+ * at 11 / 43 / 128 frames, at most 80 000 frames per batch).  Returns TVC_ERR_ARG for a length the ragged call would refuse. */
+int tvc_ragged_plan(int B, int64_t Lmax, const int64_t* lens, int32_t* batch_of_row, int* n_batches);
 int tvc_convert_ragged_f32(tvc_ctx* ctx, void* stream, const float* wav, int64_t Lmax, const int64_t* lens, const float* prepared_index,
                            int64_t N, float pitch_shift, const float* noise_angle, uint64_t seed, float* wave, int B, void* ws,
                            size_t ws_bytes);

@@ -79,3 +79,35 @@ def test_host_helpers():
     x = torch.ones(2, 1000)
     y = utils.autopad_waveform(x)
     assert y.shape == (2, 1440) and float(y[:, 1000:].abs().sum()) == 0 and utils.autopad_waveform(y) is y
+
+
+def test_ragged_plan_is_host_logic(lib, monkeypatch):
+    """tvc_ragged_plan needs no context and no device: the split of a ragged call into in-kernel batches (length classes at 11 / 43 / 128
+    frames - the kernels a FilterNet level runs depend on the utterance's length there -, a frame cap per batch), and its validation."""
+    import ctypes
+
+    def plan(frames, lmax_frames=None):
+        B = len(frames)
+        lens = (ctypes.c_int64 * B)(*[480 * f for f in frames])
+        out = (ctypes.c_int32 * B)()
+        n = ctypes.c_int()
+        rc = lib.tvc_ragged_plan(B, 480 * (lmax_frames or max(frames)), lens, out, ctypes.byref(n))
+        return rc, list(out), n.value
+
+    rc, rows, n = plan([200, 5, 131, 10, 11, 42, 43, 127, 128, 3])
+    assert rc == 0 and n == 4
+    cls = lambda f: (f >= 11) + (f >= 43) + (f >= 128)
+    frames = [200, 5, 131, 10, 11, 42, 43, 127, 128, 3]
+    by_batch = {}
+    for f, r in zip(frames, rows):
+        by_batch.setdefault(r, set()).add(cls(f))
+    assert all(len(v) == 1 for v in by_batch.values()) and len(by_batch) == 4      # one class per batch
+    assert rows[0] == rows[2] == rows[8] == 0                                       # the longest class runs first
+    rc, rows, n = plan([150] * 7)
+    assert rc == 0 and n == 1 and rows == [0] * 7
+    assert plan([2, 50])[0] != 0                                                    # 960 samples: too short for the STFT's reflect padding
+    assert plan([50, 60], lmax_frames=55)[0] != 0                                   # longer than its row
+    assert plan([90000])[0] != 0                                                    # longer than a batch may be
+    monkeypatch.setenv("TVC_RAG_MAX_FRAMES", "400")
+    rc, rows, n = plan([150] * 7)
+    assert rc == 0 and n == 4 and rows == [0, 0, 1, 1, 2, 2, 3]                     # the cap cuts a class into several batches, in order

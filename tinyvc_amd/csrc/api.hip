@@ -1085,6 +1085,17 @@ int ragged_batch_bytes(tvc_ctx* ctx, const std::vector<RagBatchPlan>& batches, i
 }
 }  // namespace
 
+int tvc_ragged_plan(int B, int64_t Lmax, const int64_t* lens, int32_t* batch_of_row, int* n_batches) {
+    if (!lens || !batch_of_row || !n_batches || B <= 0 || Lmax <= 0 || Lmax % kHop != 0) return TVC_ERR_ARG;
+    std::vector<RagBatchPlan> batches;
+    const int rc = ragged_split(nullptr, B, Lmax, lens, &batches);
+    if (rc) return rc;
+    for (size_t i = 0; i < batches.size(); ++i)
+        for (int b : batches[i].rows) batch_of_row[b] = (int32_t)i;
+    *n_batches = (int)batches.size();
+    return TVC_OK;
+}
+
 int tvc_workspace_bytes_ragged(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, int64_t N, size_t* out_bytes) {
     TVC_CHECK(need_ready(ctx, NEED_NONE));
     if (!out_bytes || !lens || B <= 0 || Lmax <= 0 || Lmax % kHop != 0 || N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_workspace_bytes_ragged: need B>0, Lmax%%480==0, N>=4");
