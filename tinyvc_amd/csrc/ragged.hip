@@ -15,7 +15,7 @@ __global__ void upload_ints_kernel(IntChunk c, int* __restrict__ dst, int n) {
     if (i < n) dst[i] = c.v[i];
 }
 // one workgroup: pre = exclusive prefix of tb * mult_num / bn (bn = 0: of tb itself), pre[B] = total; col2b (optional) = utterance of every frame
-__global__ __launch_bounds__(1024) void rag_prefix_kernel(const int* __restrict__ tb, int* __restrict__ pre, int* __restrict__ col2b, int B, int mult, int bn) {
+__global__ __launch_bounds__(1024) void rag_prefix_kernel(const int* __restrict__ tb, int* pre, int* __restrict__ col2b, int B, int mult, int bn) {
     __shared__ int part[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -37,16 +37,26 @@ __global__ __launch_bounds__(1024) void rag_prefix_kernel(const int* __restrict_
         for (int w = 0; w < wave; ++w) woff += part[w];
         const int carry = carry_s;
         const int excl = carry + woff + inc - v;
-        if (b < B) {
-            pre[b] = excl;
-            if (col2b)
-                for (int t = 0; t < v; ++t) col2b[excl + t] = b;
-        }
+        if (b < B) pre[b] = excl;
         __syncthreads();
         if (tid == 1023) carry_s = carry + woff + inc;
         __syncthreads();
     }
     if (tid == 0) pre[B] = carry_s;
+    if (col2b) {      // frame -> utterance: every thread looks its frames' utterance up in the finished prefix (a 26-minute utterance must not be one thread's loop)
+        __syncthreads();
+        __threadfence_block();
+        const int total = carry_s;
+        for (int f = tid; f < total; f += 1024) {
+            int lo = 0, hi = B - 1;           // last b with pre[b] <= f
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pre[mid] <= f) lo = mid;
+                else hi = mid - 1;
+            }
+            col2b[f] = lo;
+        }
+    }
 }
 int upload_ints(tvc_ctx* ctx, hipStream_t s, const std::vector<int>& src, int* dst) {
     for (size_t o = 0; o < src.size(); o += 960) {
