@@ -253,3 +253,19 @@ def test_many_utterances_and_several_batches_per_class(gen, monkeypatch):
     monkeypatch.setenv("TVC_RAG_MAX_FRAMES", "4000")            # ~ 5 batches per class
     out2 = gen.convert(wf, tgt, 0.0, noise_angle=angle, lengths=lens)
     assert torch.equal(out2, out)
+
+
+def test_class_boundaries(gen):
+    """Frame counts on both sides of every length-class boundary (11, 43, 128 frames: where a FilterNet level changes the kernel it runs)."""
+    frames = [10, 11, 42, 43, 127, 128]
+    lens = [480 * f for f in frames]
+    wf = torch.zeros(len(frames), max(lens))
+    for b, n in enumerate(lens):
+        wf[b, :n] = synth.synth_wave(1, n, seed=300 + b)[0]
+    wf = wf.to(DEV)
+    tgt = synth.synth_index(500, seed=2).to(DEV)
+    angle = synth.synth_angle(len(frames), max(frames), 11).to(DEV)
+    out = gen.convert(wf, tgt, 1.0, noise_angle=angle, lengths=lens)
+    for b, f in enumerate(frames):
+        one = gen.convert(wf[b:b + 1, :lens[b]], tgt, 1.0, noise_angle=angle[b:b + 1, :, :f].contiguous())
+        assert torch.equal(out[b, :lens[b]], one[0]), f"{f} frames"
