@@ -27,9 +27,11 @@ def build(force=False, verbose=True):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "tinyvc_hip.h"))
     objs, jobs = [], []
+    objdir = os.environ.get("TVC_OBJ_DIR") or CSRC      # variant builds (TVC_EXTRA_FLAGS + TVC_LIB_PATH) keep their objects apart
+    os.makedirs(objdir, exist_ok=True)
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
             jobs.append([hipcc] + flags + ["-c", s, "-o", o])

@@ -1,6 +1,7 @@
 // Encoder (encoder.py:75-116) and the ConvNeXt-v2 layer shared with SourceNet (convnext.py:7-58).
 #include "conv3s.h"
 #include "gemm_s2.h"
+#include "cnx_s3.h"
 #include "small_kernels.h"
 #include "tvc_common.h"
 
@@ -184,7 +185,79 @@ int run_layernorm(tvc_ctx* ctx, hipStream_t s, float* x, const float* g, const f
     return launch_check(ctx, "layernorm");
 }
 
-int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW& w, float* x, int B, int T) {
+// The two fused launches of cnx_s3.h around grn_norm; false = the layer is outside their preconditions (run_convnext's five launches take it)
+template <int C>
+static bool cnx_try(int* rc, tvc_ctx* ctx, hipStream_t s, const ConvNeXtW& w, float* x, float* h, float* gx, int B, int T, float* amax_out) {
+    if (w.C != C || !(w.ln_bound < 32768.f) || w.c2.MT6 != 2 * C / 32 || w.c3.MT6 != C / 32 || w.c2.S6 < C / 16 || w.c3.S6 < 2 * C / 16) return false;
+    const int NB = ctx->rag ? ctx->rag->B : B, Tl = ctx->rag ? ctx->rag->Tlong : T, rs = T;      // (ragged: T = all frames = the row stride)
+    if ((long)rs * 8 * 4 >= (1L << 31)) return false;                                             // 32-bit lane offsets
+    constexpr int KP = C == 384 ? 2 : 1;
+    static int ncu_dev[64] = {};
+    int& ncu = ncu_dev[ctx->device & 63];
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, ctx->device);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cnx1_kernel<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Cnx1<C, 1>::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cnx1_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, Cnx1<C, 2>::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cnx2_kernel<C, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, Cnx2<C, KP>::LDS_BYTES);
+        if (e != hipSuccess) {
+            *rc = fail(ctx, TVC_ERR_HIP, "cnx setup: %s", hipGetErrorString(e));
+            return true;
+        }
+        ncu = prop.multiProcessorCount;
+    }
+    CnxArgs a{};
+    a.x = x;
+    a.h = h;
+    a.T = T;
+    a.rs = rs;
+    if ((*rc = rag_view(ctx, s, 1, 0, &a.rg, nullptr)) != 0) return true;
+    // rows of the weight image per workgroup: the whole image while the column tiles alone cover the chip, else split over blockIdx.z
+    auto split = [&](int MT, int tiles) {
+        int d = 1;
+        for (int c = 1; c <= MT; ++c)
+            if (MT % c == 0 && (long)tiles * c <= ncu) d = c;
+        return d;
+    };
+    {
+        a.A6 = reinterpret_cast<const uint4*>(w.c2.A6);
+        a.wsc = w.c2.wscale;
+        a.bias = w.c2.bias;
+        a.MT = w.c2.MT6;
+        a.dw_w = w.dw_w;
+        a.dw_b = w.dw_b;
+        a.ln_g = w.ln_g;
+        a.ln_b = w.ln_b;
+        a.dil = w.dilation;
+        const int nt = Tl <= 32 ? 1 : 2, tx = (Tl + 32 * nt - 1) / (32 * nt);
+        const int d = split(a.MT, tx * NB);
+        a.mt_per_wg = a.MT / d;
+        const dim3 grid((unsigned)tx, (unsigned)NB, (unsigned)d);
+        constexpr int nthr = Cnx1<C, 2>::NTHR, lds1 = Cnx1<C, 1>::LDS_BYTES, lds2 = Cnx1<C, 2>::LDS_BYTES;
+        if (nt == 1) hipLaunchKernelGGL((cnx1_kernel<C, 1>), grid, dim3(nthr), lds1, s, a);
+        else hipLaunchKernelGGL((cnx1_kernel<C, 2>), grid, dim3(nthr), lds2, s, a);
+    }
+    hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)NB * 2 * C * 64)), dim3(256), 0, s, h, gx, (long)NB * 2 * C, T, a.rg, 2 * C);
+    {
+        a.A6 = reinterpret_cast<const uint4*>(w.c3.A6);
+        a.wsc = w.c3.wscale;
+        a.bias = w.c3_bias_grn;
+        a.MT = w.c3.MT6;
+        a.gx = gx;
+        a.grn_g = w.grn_g;
+        a.amax_y = amax_out;
+        const int tx = (Tl + 63) / 64;
+        const int d = split(a.MT, tx * NB);
+        a.mt_per_wg = a.MT / d;
+        constexpr int nthr = Cnx2<C, KP>::NTHR, lds = Cnx2<C, KP>::LDS_BYTES;
+        hipLaunchKernelGGL((cnx2_kernel<C, KP>), dim3((unsigned)tx, (unsigned)NB, (unsigned)d), dim3(nthr), lds, s, a);
+    }
+    *rc = launch_check(ctx, "convnext (fused)");
+    return true;
+}
+
+// amax_out: optional per-utterance |max| slot of the layer's output (zeroed by the caller), for the contraction that reads it next
+int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW& w, float* x, int B, int T, float* amax_out) {
     const int C = w.C, C2 = 2 * w.C, ncols = B * T;
     const int NB = ctx->rag ? ctx->rag->B : B;      // utterances (a ragged batch runs as B = 1, T = all its frames: ragged.h)
     size_t mk = ws.mark();
@@ -196,6 +269,12 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     float* hmax = ws.get<float>((size_t)NB);
     ws.release(mk);
     if (dry) return 0;
+#ifndef TVC_CNX_OLD
+    {
+        int rc = 0;
+        if (C == 384 ? cnx_try<384>(&rc, ctx, s, w, x, h, gx, B, T, amax_out) : (C == 128 && cnx_try<128>(&rc, ctx, s, w, x, h, gx, B, T, amax_out))) return rc;
+    }
+#endif
     {
         TVC_CHECK(dwconv_ln_launch<true>(ctx, s, x, y, w.dw_w, w.dw_b, w.ln_g, w.ln_b, B, C, T, w.dilation));
     }
@@ -225,6 +304,7 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
             rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC, EpiBias<ACT_NONE, true>, true>(ctx, s, w.c3, h, B, C2, T, 0, ep, hmax, nx);
         TVC_CHECK(rc);
     }
+    if (amax_out) TVC_CHECK(run_amax_rows(ctx, s, x, B, C, T, amax_out));
     return launch_check(ctx, "convnext");
 }
 

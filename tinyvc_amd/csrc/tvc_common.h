@@ -275,6 +275,6 @@ int run_conv48_pair(tvc_ctx*, hipStream_t, const PackedW& wa, const PackedW& wb,
                     const float* amax_x, const float* amax_c, float* amax_y);
 
 // ConvNeXt-v2 layer on x [B, C, T] in place (convnext.py:49-58); tmp buffers from ws.
-int run_convnext(tvc_ctx*, hipStream_t, Ws&, bool dry, const ConvNeXtW& w, float* x, int B, int T);
+int run_convnext(tvc_ctx*, hipStream_t, Ws&, bool dry, const ConvNeXtW& w, float* x, int B, int T, float* amax_out = nullptr);
 
 }  // namespace tvc
