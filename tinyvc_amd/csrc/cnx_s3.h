@@ -44,17 +44,41 @@ struct CnxArgs {
     const float* gx;     // [B][2C] row norms (grn_norm_kernel)
     const float* grn_g;  // [2C]
     float* amax_y;       // optional per-utterance |max| slot of the output x (zeroed by the caller)
+#ifdef CNX_TRACE
+    unsigned long long* trace;   // diagnostic build (tools/micro/cnx_bench.hip): s_memtime stamps of two waves of workgroup CNX_TRACE
+#endif
 };
+#ifdef CNX_TRACE
+#define CNX_STAMP(id)                                                                                   \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if (a.trace && (int)(blockIdx.x + gridDim.x * blockIdx.y) == CNX_TRACE && (tid & 255) == 0 && tid < 512) {   \
+            unsigned long long t_;                                                                      \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            a.trace[(tid >> 8) * 32 + (id)] = t_;                                                       \
+        }                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    } while (0)
+#else
+#define CNX_STAMP(id) do {} while (0)
+#endif
 
 constexpr int CNX_PD = 4;      // A-fragment ring depth (K16 steps in flight)
+#ifndef CNX_ABL
+#define CNX_ABL 0                // what-if builds of tools/micro/cnx_bench.hip (timing only, wrong results)
+#endif
 typedef float f32x4s_t __attribute__((ext_vector_type(4)));
 
 // hi / lo += (A6 pieces of m-tile mt) x (the resident operand tile Ys), K16 steps [k_begin, k_begin + KSL) of the image against local
 // steps [0, KSL) of Ys.  ring = the A fragments of the next CNX_PD steps (already requested); after the last step the ring holds the
 // first steps of (mt_next, k_next) - the next item or the next K pass.
-template <int NT, int NC, int KSL>
+struct CnxNoPost {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// post(k) runs behind step k's MFMAs, inside the step's scheduling region: the previous item's epilogue rides in the matrix pipe's shadow
+template <int NT, int NC, int KSL, class Post = CnxNoPost>
 __device__ __forceinline__ void cnx_mma(f32x16 (&hi)[NT], f32x16 (&lo)[NT], u32x4 (&ring)[CNX_PD][2], const uint4* __restrict__ A6, int MT, int mt, int k_begin,
-                                        int mt_next, int k_next, const uint4* Ys, int lane) {
+                                        int mt_next, int k_next, const uint4* Ys, int lane, const Post& post = Post()) {
     static_assert(KSL % CNX_PD == 0, "ring depth divides the K walk");
     const int l31 = lane & 31, lh = lane >> 5;
     const uint4* yb = Ys + lh * NC + l31;
@@ -63,6 +87,7 @@ __device__ __forceinline__ void cnx_mma(f32x16 (&hi)[NT], f32x16 (&lo)[NT], u32x
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int p = 0; p < 2; ++p) bq[0][j][p] = *reinterpret_cast<const u32x4*>(yb + (p * 2) * NC + j * 32);
+#pragma unroll
     for (int k0 = 0; k0 < KSL; k0 += CNX_PD) {
 #pragma unroll
         for (int u = 0; u < CNX_PD; ++u) {
@@ -76,8 +101,10 @@ __device__ __forceinline__ void cnx_mma(f32x16 (&hi)[NT], f32x16 (&lo)[NT], u32x
                 kg = k_next;
             }
             const uint4* ab = A6 + ((long)(kg + kn) * MT + mtl) * kPU4;
-            ring[u][0] = ldg_so4(ab, 16u * (unsigned)lane);
-            ring[u][1] = ldg_so4(ab, 16u * (unsigned)(64 + lane));
+            if (!(CNX_ABL & 16)) {
+                ring[u][0] = ldg_so4(ab, 16u * (unsigned)lane);
+                ring[u][1] = ldg_so4(ab, 16u * (unsigned)(64 + lane));
+            }
             // next step's B fragments (the walk's last step reads step 0 again: harmless)
             const int kb = k + 1 < KSL ? k + 1 : 0;
 #pragma unroll
@@ -90,6 +117,7 @@ __device__ __forceinline__ void cnx_mma(f32x16 (&hi)[NT], f32x16 (&lo)[NT], u32x
             for (int j = 0; j < NT; ++j) hi[j] = TVC_MFMA16(a0, __builtin_bit_cast(f16x8, bq[fb][j][0]), hi[j]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) lo[j] = TVC_MFMA16(a0, __builtin_bit_cast(f16x8, bq[fb][j][1]), lo[j]);
+            post(k);
             __builtin_amdgcn_sched_barrier(0);      // the ring's loads and the next step's fragment reads stay in the step that issues them (the scheduler sank them to their uses)
         }
     }
@@ -137,7 +165,9 @@ __global__ __launch_bounds__((Cnx1<C, NT>::NTHR)) void cnx1_kernel(CnxArgs a) {
         Gl[i] = a.ln_g[i];
         Gl[C + i] = a.ln_b[i];
     }
+    CNX_STAMP(0);
     __syncthreads();
+    CNX_STAMP(1);
 
     // ---- depthwise conv + LayerNorm moments: thread = (column, channel class(es) v = c % 16), dwconv_ln_kernel's arithmetic ----
     const int col = NT == 2 ? lane : l31;
@@ -163,7 +193,7 @@ __global__ __launch_bounds__((Cnx1<C, NT>::NTHR)) void cnx1_kernel(CnxArgs a) {
             if (NT == 2) {
                 const float* xr = xb + (long)c * rs;                // wave-uniform row
 #pragma unroll
-                for (int j = 0; j < 7; ++j) acc = fmaf(wj[j], ldg_so(xr, tt[j]), acc);
+                for (int j = 0; j < 7; ++j) acc = fmaf(wj[j], (CNX_ABL & 1) ? (float)tt[j] : ldg_so(xr, tt[j]), acc);
             } else {
                 const char* xr = reinterpret_cast<const char*>(xb + (long)c * rs);
 #pragma unroll
@@ -175,7 +205,9 @@ __global__ __launch_bounds__((Cnx1<C, NT>::NTHR)) void cnx1_kernel(CnxArgs a) {
         }
         red[vw * NC + col] = sum;
     }
+    CNX_STAMP(2);
     __syncthreads();
+    CNX_STAMP(3);
     float tot = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) tot += red[w * NC + col];
@@ -198,6 +230,7 @@ __global__ __launch_bounds__((Cnx1<C, NT>::NTHR)) void cnx1_kernel(CnxArgs a) {
     for (int w = 0; w < 16; ++w) tot2 += red[w * NC + col];
     const float var = tot2 / (float)C;
     const float rstd = 1.f / sqrtf(var + 1e-5f);
+    CNX_STAMP(4);
 
     // ---- normalise, split, operand tile: wave w rewrites the 16-channel blocks w, w + 8, ... in place (a block's fp32 values and
     // its four fragment rows per column are the same 64 * NC bytes; a wave's LDS accesses execute in order) -------------------
@@ -219,7 +252,9 @@ __global__ __launch_bounds__((Cnx1<C, NT>::NTHR)) void cnx1_kernel(CnxArgs a) {
             Ys[((i * 2 + 1) * 2 + half) * NC + col] = p2;
         }
     }
+    CNX_STAMP(5);
     __syncthreads();
+    CNX_STAMP(6);
 
     // ---- c2: every wave walks its own m-tiles; no barrier from here on ----------------------------------------------------
     const int mt_lo = blockIdx.z * a.mt_per_wg;
@@ -234,7 +269,38 @@ __global__ __launch_bounds__((Cnx1<C, NT>::NTHR)) void cnx1_kernel(CnxArgs a) {
         ring[u][1] = ldg_so4(ab, 16u * (unsigned)(64 + lane));
     }
     float* hb = a.h + hoff;
-    while (true) {
+    // A wave's epilogue (GELU, 32 stores) is as long as its MFMA walk, and a wave that stores and then waits for its next A
+    // fragments waits for the stores too (one in-order counter).  So the epilogue of item i is software-pipelined into the walk of
+    // item i + 1: finished values wait in `pend` and leave a few per K16 step, behind that step's MFMAs.
+    constexpr int NPEND = NT * 16, EPS = ((NPEND + KS - 1) / KS + 1) / 2 * 2;      // values leaving per K16 step (pairs)
+    float pend[NPEND];
+    int pmt = mt;
+    // Columns past the tile's end hold copies of its last column (the prologue clamps), so their lanes compute that column's values bit
+    // for bit and may store them to ITS address: every lane stores, no exec-masked block sits between the MFMAs and the epilogue
+    // arithmetic, and the wait counters stay exact (a conditional store made every later fragment wait drain the stores).
+    unsigned oo[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + l31;
+        oo[j] = 4u * (unsigned)(4 * lh * rs + t0 + (n < tw ? n : tw - 1));
+    }
+    auto finish2 = [&](int e) __attribute__((always_inline)) {      // values e, e + 1 (same n-tile: e is even)
+        const int j = e >> 4;
+        f32x2e v = {pend[e], pend[e + 1]};
+        asm volatile("" : "+v"(v));       // pins the arithmetic to the step that stores it (free-floating, all 32 GELUs were hoisted to the top of the walk and spilled)
+        const f32x2e o = (CNX_ABL & 4) ? v : gelu_pair(v);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (e + i) & 15;
+            if (!((CNX_ABL & 8) && o[i] != 1.2345f)) stg_so(hb + (long)(pmt * 32 + (r & 3) + 8 * (r >> 2)) * rs, oo[j], o[i]);
+        }
+    };
+    auto post = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = EPS * k; e < EPS * k + EPS; e += 2)
+            if (e < NPEND) finish2(e);
+    };
+    auto walk = [&](auto& poster) __attribute__((always_inline)) {
         const int mtn = mt + WAVES < mt_hi ? mt + WAVES : mt;       // (the last item's ring refills re-read its own first steps: harmless)
         float bv[16];
 #pragma unroll
@@ -244,24 +310,29 @@ __global__ __launch_bounds__((Cnx1<C, NT>::NTHR)) void cnx1_kernel(CnxArgs a) {
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hi[j][r] = lo[j][r] = 0.f;
-        cnx_mma<NT, NC, KS>(hi, lo, ring, a.A6, a.MT, mt, 0, mtn, 0, Ys, lane);
+        if (!(CNX_ABL & 2)) cnx_mma<NT, NC, KS>(hi, lo, ring, a.A6, a.MT, mt, 0, mtn, 0, Ys, lane, poster);
         const float cw = a.wsc[mt] * 1.f, cl = cw * kLoInv;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = j * 32 + l31;
-            const bool live = n < tw;
-            const unsigned oo = 4u * (unsigned)(4 * lh * rs + t0 + n);
-            float o[16];
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = act_apply(comb(hi[j][r], lo[j][r], cw, cl) + bv[r], ACT_GELU);
-            if (live) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) stg_so(hb + (long)(mt * 32 + (r & 3) + 8 * (r >> 2)) * rs, oo, o[r]);
-            }
-        }
-        if (mt + WAVES >= mt_hi) break;
-        mt += WAVES;
+            for (int r = 0; r < 16; ++r) pend[j * 16 + r] = comb(hi[j][r], lo[j][r], cw, cl) + bv[r];
+        pmt = mt;
+    };
+    int stamp = 7;
+    {
+        CnxNoPost none;
+        walk(none);
     }
+    CNX_STAMP(stamp);
+    while (mt + WAVES < mt_hi) {
+        mt += WAVES;
+        walk(post);
+        ++stamp;
+        CNX_STAMP(stamp);
+    }
+#pragma unroll
+    for (int e = 0; e < NPEND; e += 2) finish2(e);
+    CNX_STAMP(12);
 }
 
 template <int C, int KPASS>
@@ -336,7 +407,7 @@ __global__ __launch_bounds__((Cnx2<C, KPASS>::NTHR)) void cnx2_kernel(CnxArgs a)
         for (int i = 0; i < XPER; ++i) {
             const int gg = pass * CF::GPP + wave + i * WAVES;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xr[i][q] = ldg_so(hb + (long)(8 * gg + q) * rs, so);
+            for (int q = 0; q < 8; ++q) xr[i][q] = (CNX_ABL & 32) ? (float)(gg + q) : ldg_so(hb + (long)(8 * gg + q) * rs, so);
         }
     };
     auto deposit = [&](int pass) __attribute__((always_inline)) {
@@ -382,14 +453,14 @@ __global__ __launch_bounds__((Cnx2<C, KPASS>::NTHR)) void cnx2_kernel(CnxArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hi[j][r] = lo[j][r] = 0.f;
         if (KPASS == 1) {
-            cnx_mma<NT, NC, KSL>(hi, lo, ring, a.A6, a.MT, mt, 0, mtn, 0, Ys, lane);
+            if (!(CNX_ABL & 2)) cnx_mma<NT, NC, KSL>(hi, lo, ring, a.A6, a.MT, mt, 0, mtn, 0, Ys, lane);
         } else {
-            if (has) cnx_mma<NT, NC, KSL>(hi, lo, ring, a.A6, a.MT, mt, 0, mt, KSL, Ys, lane);
+            if (has && !(CNX_ABL & 2)) cnx_mma<NT, NC, KSL>(hi, lo, ring, a.A6, a.MT, mt, 0, mt, KSL, Ys, lane);
             slab_barrier();                                         // every wave is done with the first K half
             deposit(1);
             slab_barrier();
             if (!has) break;
-            cnx_mma<NT, NC, KSL>(hi, lo, ring, a.A6, a.MT, mt, KSL, mt, KSL, Ys, lane);
+            if (!(CNX_ABL & 2)) cnx_mma<NT, NC, KSL>(hi, lo, ring, a.A6, a.MT, mt, KSL, mt, KSL, Ys, lane);
         }
         // epilogue: EpiBias<ACT_NONE, true> (bias' = c3.bias + c3.weight . grn.beta), residual = the layer's input, in place
         const float cw = a.wsc[mt] * sx.inv, cl = cw * kLoInv;
@@ -399,8 +470,7 @@ __global__ __launch_bounds__((Cnx2<C, KPASS>::NTHR)) void cnx2_kernel(CnxArgs a)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = j * 32 + l31;
-            const bool live = n < tw;
-            const unsigned oo = 4u * (unsigned)(4 * lh * rs + t0 + (live ? n : tw - 1));
+            const unsigned oo = 4u * (unsigned)(4 * lh * rs + t0 + (n < tw ? n : tw - 1));     // (columns past the end: copies of the last one, stored to its address)
             float res[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) res[r] = ldg_so(xb + (long)(mt * 32 + (r & 3) + 8 * (r >> 2)) * rs, oo);
@@ -412,7 +482,8 @@ __global__ __launch_bounds__((Cnx2<C, KPASS>::NTHR)) void cnx2_kernel(CnxArgs a)
                 res[r] = o;
                 mx = fmaxf(mx, fabsf(o));
             }
-            if (live) {
+            // (in place: only the column's own lane stores - a clamped lane of the second n-tile would re-read a column the first n-tile has already updated)
+            if (n < tw && !((CNX_ABL & 8) && res[0] != 1.2345f)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stg_so(xb + (long)(mt * 32 + (r & 3) + 8 * (r >> 2)) * rs, oo, res[r]);
                 mx_out = fmaxf(mx_out, mx);

@@ -218,10 +218,9 @@ static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
         if (!gemm_s2_try(&rc, ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep, cmax)) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep, cmax);
         TVC_CHECK(rc);
     }
-    for (int i = 0; i < 3; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->src_mid[i], x, B, T));
+    if (!dry) TVC_HIP(ctx, hipMemsetAsync(xmax, 0, (size_t)NB * sizeof(float), s));
+    for (int i = 0; i < 3; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->src_mid[i], x, B, T, i == 2 ? xmax : nullptr));     // the last layer publishes the |max| slot of its output
     if (dry) return 0;
-    TVC_HIP(ctx, hipMemsetAsync(xmax, 0, (size_t)NB * sizeof(float), s));
-    TVC_CHECK(run_amax_rows(ctx, s, x, B, kSrcCh, T, xmax));
     // to_amps (128 -> 15 rows: one 32-row m-tile)
     EpiBias<ACT_ELU1, false> ea{amps, ctx->src_to_amps.bias, nullptr, kHarm, T, ncols, (long)kHarm * T, 0};
     TVC_CHECK((gemm_s_launch<1, 4, 2>(ctx, s, ctx->src_to_amps, x, B, kSrcCh, T, 0, ea, xmax)));

@@ -431,9 +431,8 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
         TVC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
         sp = ctx->side;
     }
-    for (int i = 0; i < 4; ++i) TVC_CHECK(run_convnext(ctx, sp, ws, dry, ctx->pit_mid[i], xp, B, T));
+    for (int i = 0; i < 4; ++i) TVC_CHECK(run_convnext(ctx, sp, ws, dry, ctx->pit_mid[i], xp, B, T, i == 3 ? xp_max : nullptr));      // the last layer publishes the |max| slot of its output
     if (!dry) {
-        TVC_CHECK(run_amax_rows(ctx, sp, xp, B, kPitchCh, T, xp_max));
         EpiBias<ACT_NONE, false> ep{lg, ctx->pit_out.bias, nullptr, kPitchClasses, T, ncols, (long)kPitchClasses * T, 0};
         int rc = 0;
         if (!gemm_s2_try(&rc, ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep, xp_max)) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep, xp_max);
@@ -441,11 +440,10 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
         hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(kPdWaves * 64), 0, sp, lg, ctx->pitch_freq, f0, B, T);
     }
     if (fork) TVC_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
-    for (int i = 0; i < 6; ++i) TVC_CHECK(run_convnext(ctx, s, wssl, dry, ctx->ssl_mid[i], xs, B, T));
+    for (int i = 0; i < 6; ++i) TVC_CHECK(run_convnext(ctx, s, wssl, dry, ctx->ssl_mid[i], xs, B, T, i == 5 ? xs_max : nullptr));
     if (!wssl.ok()) return fail(ctx, TVC_ERR_WORKSPACE, "encoder: SSL scratch block too small");
     if (dry) return 0;
     {
-        TVC_CHECK(run_amax_rows(ctx, s, xs, B, kSslCh, T, xs_max));
         EpiBias<ACT_NONE, false> ep{ssl, ctx->ssl_out.bias, nullptr, kSslDim, T, ncols, (long)kSslDim * T, 0};
         int rc = 0;
         if (!gemm_s2_try(&rc, ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep, xs_max)) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->ssl_out, xs, B, kSslCh, T, 0, ep, xs_max);
