@@ -9,6 +9,9 @@
 
 using namespace tvc;
 
+#ifndef TVC_SIDE_PRIO_EXPR
+#define TVC_SIDE_PRIO_EXPR prio_least
+#endif
 namespace {
 
 struct ArenaBuilder {
@@ -568,7 +571,11 @@ int tvc_ctx_create(int hip_device, tvc_ctx** out) {
         }
         for (auto& f : pk.fix) *f.slot = c->const_arena + f.off;
     }
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+    // the side stream carries the pitch estimator beside the SSL trunk (encoder.hip): lowest priority, so that its workgroups take the
+    // slots the trunk's launches leave free instead of competing with them (the pitch chain has ~150 us of slack)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, TVC_SIDE_PRIO_EXPR) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         tvc_ctx_destroy(c);

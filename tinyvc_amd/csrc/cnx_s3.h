@@ -372,36 +372,24 @@ __global__ __launch_bounds__((Cnx2<C, KPASS>::NTHR)) void cnx2_kernel(CnxArgs a)
     const int rs = a.rs;
 
     // ---- GRN factors: grn_finalize_kernel's arithmetic and order (256 threads) --------------------------------------------
+    // (their inputs are requested first and the first operand half right behind them, so that it flies under the reductions:
+    // one in-order counter - waiting for a load waits for every older one)
     const float* g = a.gx + (long)b * K;
+    constexpr int GPT = K / 256;
+    float gv[GPT], gm[GPT];
     if (tid < 256) {
-        float s = 0.f;
-        for (int c = tid; c < K; c += 256) s += g[c];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) red[wave] = s;
-    }
-    __syncthreads();
-    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)K;
-    const float den = mean + 1e-6f;
-    if (tid < 256) {
-        float mx = 0.f;
-        for (int c = tid; c < K; c += 256) {
-            const float f = fmaf(a.grn_g[c], g[c] / den, 1.f);
-            Fl[c] = f;
-            mx = fmaxf(mx, g[c] * fabsf(f));
+        for (int i = 0; i < GPT; ++i) {
+            gv[i] = g[tid + 256 * i];
+            gm[i] = a.grn_g[tid + 256 * i];
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        if (lane == 0) red[4 + wave] = mx;
     }
-    __syncthreads();
-    const Bfp sx = bfp_from_amax(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));      // |h * factor| <= max_c gx[c] |f[c]|
-
     // ---- operand staging: an item = 8 channels of one column (gemm_s2's SCALED staging arithmetic) ---------------------------
     const float* hb = a.h + hoff;
     const int scol = lane;                                          // NC = 64: a wave = one 8-channel group x 64 columns
     const unsigned so = 4u * (unsigned)(t0 + (scol < tw ? scol : tw - 1));
     float xr[XPER][8];
+    Bfp sx{1.f, 1.f};
     auto fetch = [&](int pass) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
@@ -426,6 +414,31 @@ __global__ __launch_bounds__((Cnx2<C, KPASS>::NTHR)) void cnx2_kernel(CnxArgs a)
         }
     };
     fetch(0);
+    if (tid < 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) s += gv[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) red[wave] = s;
+    }
+    slab_barrier();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)K;
+    const float den = mean + 1e-6f;
+    if (tid < 256) {
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const float f = fmaf(gm[i], gv[i] / den, 1.f);
+            Fl[tid + 256 * i] = f;
+            mx = fmaxf(mx, gv[i] * fabsf(f));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) red[4 + wave] = mx;
+    }
+    slab_barrier();
+    sx = bfp_from_amax(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));      // |h * factor| <= max_c gx[c] |f[c]|
     deposit(0);
     if (KPASS == 2) fetch(1);                                       // lands under the first pass's MFMAs
     slab_barrier();
