@@ -208,13 +208,21 @@ int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* p
  * `lens` is a HOST array (lengths are launch geometry; they travel to the device as kernel arguments, asynchronously on `stream`).
  * The utterances share every kernel launch - the kernels take per-utterance lengths (csrc/ragged.h) -, in at most four batches per
  * call by length class (frames < 11, < 43, < 128, the rest: the kernels a FilterNet level runs depend on the utterance's length there),
- * one after the other on `stream`.  Every utterance gets exactly the samples a B = 1 tvc_convert_f32 call gives it.  A single
+ * one after the other on `stream`.  Every utterance gets exactly the samples a B = 1 tvc_convert_f32 call gives it for the same noise
+ * phases.  With noise_angle = NULL the library draws them itself: the phase of (row b, bin, frame) is a hash of `seed` and of those three
+ * numbers alone - independent of the other utterances, of their lengths and of the split into batches -, so row b of a ragged call equals row
+ * b of an equal-length call with the same seed over its own frames, and row 0 the B = 1 call.  A single
  * utterance may be up to 80 000 frames.  Workspace: tvc_workspace_bytes_ragged. */
 int tvc_workspace_bytes_ragged(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, int64_t N, size_t* out_bytes);
 /* Which utterances of a ragged call share their kernel launches: batch_of_row[b] = the in-kernel batch (0 .. *n_batches - 1, the order they
  * run in) that utterance b is converted in.  Pure host logic, no context, no device: the split tvc_convert_ragged_f32 makes (length classes
  * at 11 / 43 / 128 frames, at most 80 000 frames per batch).  Returns TVC_ERR_ARG for a length the ragged call would refuse. */
 int tvc_ragged_plan(int B, int64_t Lmax, const int64_t* lens, int32_t* batch_of_row, int* n_batches);
+/* Frames per in-kernel batch of the ragged calls (process-wide; 0 or anything above 80 000 = the default, 80 000): a smaller cap cuts a
+ * length class into several batches, one after the other.  Results do not depend on it (every utterance equals its B = 1 conversion); the
+ * plan, the workspace size and the conversion all follow the value set at the time of THEIR call, so set it between calls, not during one.
+ * (The tests use it to reach the several-batches-per-class path with small inputs; there is no environment variable behind it.) */
+int tvc_set_ragged_batch_frames(int max_frames);
 int tvc_convert_ragged_f32(tvc_ctx* ctx, void* stream, const float* wav, int64_t Lmax, const int64_t* lens, const float* prepared_index,
                            int64_t N, float pitch_shift, const float* noise_angle, uint64_t seed, float* wave, int B, void* ws,
                            size_t ws_bytes);

@@ -81,7 +81,7 @@ def test_host_helpers():
     assert y.shape == (2, 1440) and float(y[:, 1000:].abs().sum()) == 0 and utils.autopad_waveform(y) is y
 
 
-def test_ragged_plan_is_host_logic(lib, monkeypatch):
+def test_ragged_plan_is_host_logic(lib):
     """tvc_ragged_plan needs no context and no device: the split of a ragged call into in-kernel batches (length classes at 11 / 43 / 128
     frames - the kernels a FilterNet level runs depend on the utterance's length there -, a frame cap per batch), and its validation."""
     import ctypes
@@ -108,6 +108,9 @@ def test_ragged_plan_is_host_logic(lib, monkeypatch):
     assert plan([2, 50])[0] != 0                                                    # 960 samples: too short for the STFT's reflect padding
     assert plan([50, 60], lmax_frames=55)[0] != 0                                   # longer than its row
     assert plan([90000])[0] != 0                                                    # longer than a batch may be
-    monkeypatch.setenv("TVC_RAG_MAX_FRAMES", "400")
-    rc, rows, n = plan([150] * 7)
+    assert lib.tvc_set_ragged_batch_frames(400) == 0
+    try:
+        rc, rows, n = plan([150] * 7)
+    finally:
+        assert lib.tvc_set_ragged_batch_frames(0) == 0
     assert rc == 0 and n == 4 and rows == [0, 0, 1, 1, 2, 2, 3]                     # the cap cuts a class into several batches, in order

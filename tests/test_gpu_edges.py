@@ -74,7 +74,7 @@ def test_long_utterance_large_index(gen):
     full = gen.convert(w, tgt.to(DEV), 0.0, noise_angle=angle.to(DEV))
     d2 = rms(full.cpu() - st["wave"])
     print(f"[edge] 20 s end to end: rms diff {d2:.3e}")
-    assert d2 <= 2e-3      # no discrete failure (phase slip, flipped neighbour); the arithmetic claim at this length is test_gpu_truth.py (T = 1000)
+    assert d2 <= 5e-4      # measured 1.8e-4; no discrete failure (phase slip, flipped neighbour); the arithmetic claim at this length is test_gpu_truth.py (T = 1000)
 
 
 def test_full_bench_size_properties(gen):

@@ -251,4 +251,4 @@ def test_ten_seconds_against_the_host_cpu_spread(models):
     assert dec_only <= 1e-6
     # end to end: logged only - the claim that does not depend on this host's thread count is test_gpu_truth.py (GPU and reference
     # arithmetic both measured against the fp64 evaluation of the path); here only that nothing discrete went wrong
-    assert d <= 1e-3
+    assert d <= 3e-4       # measured 9.8e-5 (the host's own 1-vs-128-thread spread: 1.7e-4)

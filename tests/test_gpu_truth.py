@@ -50,7 +50,7 @@ def test_gpu_is_as_close_to_the_fp64_truth_as_the_reference_arithmetic(gen, T):
     """Two claims, measured on NB utterances of T frames each.
     (1) f0 - the quantity whose error the oscillator integrates into phase - is as accurate on the GPU as in the reference's
         fp32 arithmetic: pooled relative error vs the fp64 truth <= 1.25 x the reference's.  T x NB frames: a tight statistic.
-    (2) the waveform: pooled rms(GPU - truth) <= 2 x pooled rms(reference fp32 - truth).  Per utterance the ratio scatters
+    (2) the waveform: pooled rms(GPU - truth) <= 1.5 x pooled rms(reference fp32 - truth) (measured 0.75 / 0.91 / 1.07).  Per utterance the ratio scatters
         between ~0.4 and ~2 in BOTH directions (it is the end point of a random walk: T = 200 measured 0.44, T = 500 1.9 on single
         utterances with the same f0 accuracy), hence the pooling and the factor; every per-utterance figure is logged."""
     from oracle import ref_cpu as R
@@ -80,6 +80,6 @@ def test_gpu_is_as_close_to_the_fp64_truth_as_the_reference_arithmetic(gen, T):
          f"waveform rms vs truth: GPU {e_gpu:.3e}, reference {e_ref:.3e} (ratio {e_gpu / e_ref:.2f}); GPU vs reference {mutual:.3e}; "
          "per utterance GPU/reference: " + ", ".join(f"{a:.2e}/{b:.2e}" for a, b in per))
     assert f_gpu <= 1.25 * f_ref, f"T={T}: f0 is {f_gpu:.2e} from the fp64 truth on the GPU, {f_ref:.2e} in the reference's fp32 arithmetic"
-    assert e_gpu <= 2.0 * e_ref, f"T={T}: GPU waveform is {e_gpu:.3e} from the fp64 truth, the reference's own fp32 arithmetic {e_ref:.3e}"
+    assert e_gpu <= 1.5 * e_ref, f"T={T}: GPU waveform is {e_gpu:.3e} from the fp64 truth, the reference's own fp32 arithmetic {e_ref:.3e}"
     # the triangle inequality bounds the mutual difference: nothing else (a flipped neighbour, a phase slip) is hiding in it
     assert mutual <= e_gpu + e_ref + 1e-7

@@ -35,6 +35,7 @@ SIGNATURES = {
     "tvc_knn_prepare_index_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "tvc_knn_forget": (c_int, [c_void_p, c_void_p]),
     "tvc_ragged_plan": (c_int, [c_int, c_int64, POINTER(c_int64), POINTER(c_int32), POINTER(c_int)]),
+    "tvc_set_ragged_batch_frames": (c_int, [c_int]),
     "tvc_knn_prepare_index_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "tvc_knn_match_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_knn_topk_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),

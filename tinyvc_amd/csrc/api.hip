@@ -1,4 +1,5 @@
 // libtinyvc_hip.so — context, checkpoint packing, workspace sizing and the extern "C" surface.
+#include <atomic>
 #include <cmath>
 #include <functional>
 #include <mutex>
@@ -1035,6 +1036,7 @@ namespace {
 // 2 T, 6 T, 24 T >= 256, decoder.hip film_conv), so the frame counts split into four classes at 11, 43 and 128 frames; inside a class every
 // utterance takes exactly the path its own B = 1 call takes and the result is bit-identical to it.
 constexpr int kRagClassBounds[3] = {11, 43, 128};
+std::atomic<int> g_rag_batch_frames{0};
 constexpr int kRagMaxFrames = 80000;       // frames per in-kernel batch: 24 rows x 480 x 4 B x frames stays below the 32-bit byte offsets of the 24-channel kernels
 struct RagBatchPlan {
     std::vector<int> rows, frames;
@@ -1042,11 +1044,8 @@ struct RagBatchPlan {
 };
 int ragged_split(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, std::vector<RagBatchPlan>* batches) {
     std::vector<RagBatchPlan> open(4);          // the batch being filled, per class
-    int max_frames = kRagMaxFrames;
-    if (const char* e = std::getenv("TVC_RAG_MAX_FRAMES")) {      // tests: a small cap exercises the several-batches-per-class path
-        const int v = std::atoi(e);
-        if (v > 0 && v < max_frames) max_frames = v;
-    }
+    const int cap = g_rag_batch_frames.load(std::memory_order_relaxed);      // tvc_set_ragged_batch_frames: 0 = the default
+    const int max_frames = cap > 0 && cap < kRagMaxFrames ? cap : kRagMaxFrames;
     for (int b = 0; b < B; ++b) {
         if (lens[b] <= 0 || lens[b] % kHop || lens[b] > Lmax || lens[b] < kNfft / 2 + 1)
             return fail(ctx, TVC_ERR_ARG, "ragged batch: lens[%d] = %lld must be a multiple of 480 in (960, Lmax]", b, (long long)lens[b]);
@@ -1073,16 +1072,18 @@ int ragged_batch(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const RagBatchPl
     RagHost h;
     TVC_CHECK(rag_setup(ctx, s, dry, h, p.frames, p.rows, (int)(Lmax / kHop), scratch));
     ctx->rag = &h;
-    const int rc = convert_impl(ctx, s, ws, dry, wav, prepared, N, pitch_shift, angle, seed + (uint64_t)p.rows[0] * 0x9E3779B97F4A7C15ull, wave, 1, (int64_t)p.Ttot * kHop);
+    const int rc = convert_impl(ctx, s, ws, dry, wav, prepared, N, pitch_shift, angle, seed, wave, 1, (int64_t)p.Ttot * kHop);
     ctx->rag = nullptr;
     return rc;
 }
 // the batches of a call run one after the other on the caller's stream and share one workspace region.  Sized for a call with AND without
 // caller-supplied noise phases (the library's own draw needs a buffer the injected phases do not).
-int ragged_batch_bytes(tvc_ctx* ctx, const std::vector<RagBatchPlan>& batches, int64_t Lmax, int64_t N, size_t* bytes) {
+// angle_mode: 0 / 1 = a call without / with caller-supplied phases (what a conversion needs), -1 = the larger of the two (what
+// tvc_workspace_bytes_ragged promises: it does not know which call will follow)
+int ragged_batch_bytes(tvc_ctx* ctx, const std::vector<RagBatchPlan>& batches, int64_t Lmax, int64_t N, size_t* bytes, int angle_mode) {
     *bytes = 0;
     for (auto& p : batches)
-        for (int with_angle = 0; with_angle < 2; ++with_angle) {
+        for (int with_angle = angle_mode < 0 ? 0 : angle_mode; with_angle <= (angle_mode < 0 ? 1 : angle_mode); ++with_angle) {
             Ws ws(nullptr, 0, true);
             TVC_CHECK(ragged_batch(ctx, nullptr, ws, true, p, nullptr, Lmax, nullptr, N, 0.f, with_angle ? (const float*)256 : nullptr, 0, nullptr));
             const size_t need = (ws.peak + 4095) & ~size_t(4095);
@@ -1092,6 +1093,11 @@ int ragged_batch_bytes(tvc_ctx* ctx, const std::vector<RagBatchPlan>& batches, i
 }
 }  // namespace
 
+int tvc_set_ragged_batch_frames(int max_frames) {
+    if (max_frames < 0) return TVC_ERR_ARG;
+    g_rag_batch_frames.store(max_frames, std::memory_order_relaxed);
+    return TVC_OK;
+}
 int tvc_ragged_plan(int B, int64_t Lmax, const int64_t* lens, int32_t* batch_of_row, int* n_batches) {
     if (!lens || !batch_of_row || !n_batches || B <= 0 || Lmax <= 0 || Lmax % kHop != 0) return TVC_ERR_ARG;
     std::vector<RagBatchPlan> batches;
@@ -1109,7 +1115,7 @@ int tvc_workspace_bytes_ragged(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t*
     std::vector<RagBatchPlan> batches;
     TVC_CHECK(ragged_split(ctx, B, Lmax, lens, &batches));
     size_t bytes = 0;
-    TVC_CHECK(ragged_batch_bytes(ctx, batches, Lmax, N, &bytes));
+    TVC_CHECK(ragged_batch_bytes(ctx, batches, Lmax, N, &bytes, -1));
     *out_bytes = bytes + 4096;
     return TVC_OK;
 }
@@ -1125,7 +1131,7 @@ int tvc_convert_ragged_f32(tvc_ctx* ctx, void* stream, const float* wav, int64_t
     std::vector<RagBatchPlan> batches;
     TVC_CHECK(ragged_split(ctx, B, Lmax, lens, &batches));
     size_t bytes = 0;
-    TVC_CHECK(ragged_batch_bytes(ctx, batches, Lmax, N, &bytes));
+    TVC_CHECK(ragged_batch_bytes(ctx, batches, Lmax, N, &bytes, noise_angle ? 1 : 0));      // one dry walk per batch: host time on the launch path
     if (bytes > ws_bytes) return fail(ctx, TVC_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", bytes, ws_bytes);
     // the whole padded output is cleared once: every kernel writes its utterance's own samples only
     TVC_HIP(ctx, hipMemsetAsync(wave, 0, (size_t)B * Lmax * sizeof(float), s));

@@ -283,7 +283,9 @@ class Engine:
 
     def _angle(self, noise_angle, B, T):
         if noise_angle is None:
-            return None, self.next_seed()
+            # the library draws the phases itself (tvc_* with noise_angle = NULL: a counter-based hash of (seed, row, bin, frame)); the
+            # seed comes from torch's CPU generator, so torch.manual_seed makes a run repeatable - a host-side draw, no device launch
+            return None, int(torch.randint(0, 2 ** 62, (1,)).item())
         a = _prep(noise_angle, "noise_angle", self.device)
         if tuple(a.shape) != (B, spec.FFT_BIN, T):
             raise ValueError(f"noise_angle must be [{B}, {spec.FFT_BIN}, {T}], got {tuple(a.shape)}")

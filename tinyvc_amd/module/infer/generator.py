@@ -32,7 +32,7 @@ class Generator(HipModule):
         """generator.py:26-34: wf [B, L], tgt [1 or B, 768, N] -> converted waveform [B, L'] (L' = L
         padded to a multiple of 480).  `f0_estimation` / `device` are accepted and ignored exactly as
         in the reference.  `noise_angle` [B,961,T] (extension) injects the decoder's noise phases;
-        by default they are drawn with torch.rand on the device, as the reference does.
+        by default the library draws them itself (seeded from torch's generator: Decoder.draw_noise_angle).
         `lengths` (extension): a RAGGED batch - row b of wf holds an utterance of lengths[b] samples, zero-padded behind it.
         Every utterance is converted over its own length (padded to a multiple of 480), exactly as if it were converted
         alone (the reference's loop, infer.py:60-66; GRN and the oscillator's phase run over the whole time axis, so padding
@@ -41,9 +41,7 @@ class Generator(HipModule):
         tgt = self._input_device(tgt)
         eng = self.engine(wf.device)
         B, L = wf.shape
-        if noise_angle is None:
-            noise_angle = Decoder.draw_noise_angle(B, L // 480, wf.device)
-        else:
+        if noise_angle is not None:
             noise_angle = self._input_device(noise_angle)
         if lengths is not None:
             lens = [-(-int(n) // 480) * 480 for n in lengths]

@@ -49,6 +49,11 @@ class BatchedStreamInfer:
         # torch.roll + slice assignment of the reference (stream.py:69-70), in place on a fixed buffer
         self.input_wav.copy_(torch.roll(self.input_wav, -self.block_size, dims=1))
         self.input_wav[:, -self.block_size:] = blocks
+        if noise_angle is None and self.use_graph:
+            # a captured step bakes kernel arguments in: the library's seeded draw would replay ONE seed for every block.  torch's
+            # generator is graph-safe (its offset advances per replay), so the graph path keeps the reference's torch.rand draw
+            from ..tinyvc import Decoder
+            noise_angle = Decoder.draw_noise_angle(self.n_streams, self.input_size // 480, self.device)
         y = self.generator.convert(self.input_wav, self.target, self.pitch_shift, device=self.device,
                                    f0_estimation=self.f0_estimation, noise_angle=noise_angle)
         eng = self.generator.engine(self.device)

@@ -99,8 +99,12 @@ class Decoder(HipModule):
 
     @staticmethod
     def draw_noise_angle(batch, frames, device):
-        """The uniform phases the reference draws inside oscillate_noise on every call
-        (decoder.py:78), from torch's generator for `device` (honours torch.manual_seed)."""
+        """The uniform phases the reference draws inside oscillate_noise on every call (decoder.py:78), from torch's generator for
+        `device`: pass the result as `noise_angle` to get torch's own draw.  By default (`noise_angle=None`) the library draws the
+        phases inside its noise kernel's launch sequence instead (one launch less per call, no [B, 961, T] tensor through torch): a
+        counter-based hash of (seed, utterance row, bin, frame), the seed taken from torch's CPU generator - repeatable under
+        torch.manual_seed, like the reference's draw, and like it not reproducible across devices (a CUDA and a CPU torch.rand with
+        the same seed differ too)."""
         u = torch.rand(batch, S.FFT_BIN, frames, device=device)
         if u.is_cuda:       # the three tensor ops of the reference's expression as one in-place launch with the same roundings
             from ...engine import default_engine
@@ -112,15 +116,12 @@ class Decoder(HipModule):
         """decoder.py:253-257 -> [B, L].  `noise_angle` [B,961,T] (extension) injects the noise
         phases, e.g. a seeded CPU draw for parity with the reference's CPU path."""
         content = self._input_device(content)
-        if noise_angle is None:
-            noise_angle = self.draw_noise_angle(content.shape[0], content.shape[2], content.device)
         return self.engine(content.device).decoder(content, self._input_device(f0), self._input_device(energy),
-                                                   self._input_device(noise_angle))
+                                                   None if noise_angle is None else self._input_device(noise_angle))
 
     @torch.no_grad()
     def dsp(self, f0, amps, kernel, noise_angle=None):
         """decoder.py:259-266 -> source [B, 16, L]."""
         f0 = self._input_device(f0)
-        if noise_angle is None:
-            noise_angle = self.draw_noise_angle(f0.shape[0], f0.shape[2], f0.device)
-        return self.engine(f0.device).dsp(f0, self._input_device(amps), self._input_device(kernel), self._input_device(noise_angle))
+        return self.engine(f0.device).dsp(f0, self._input_device(amps), self._input_device(kernel),
+                                          None if noise_angle is None else self._input_device(noise_angle))
