@@ -283,9 +283,15 @@ class Engine:
 
     def _angle(self, noise_angle, B, T):
         if noise_angle is None:
-            # the library draws the phases itself (tvc_* with noise_angle = NULL: a counter-based hash of (seed, row, bin, frame)); the
-            # seed comes from torch's CPU generator, so torch.manual_seed makes a run repeatable - a host-side draw, no device launch
-            return None, int(torch.randint(0, 2 ** 62, (1,)).item())
+            # the library draws the phases itself (tvc_* with noise_angle = NULL: a counter-based hash of (seed, row, bin, frame)).  Its
+            # seed comes from THIS DEVICE's torch generator - the one the reference's torch.rand(device=...) draws from -: (seed, philox
+            # offset) read on the host, the offset advanced as a draw would advance it.  No device launch, repeatable under
+            # torch.manual_seed, untouched by CPU-side draws (module construction) in between.
+            g = torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()]
+            off = g.get_offset()
+            g.set_offset(off + 4)
+            z = (g.initial_seed() * 0x9E3779B97F4A7C15 + off * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+            return None, z
         a = _prep(noise_angle, "noise_angle", self.device)
         if tuple(a.shape) != (B, spec.FFT_BIN, T):
             raise ValueError(f"noise_angle must be [{B}, {spec.FFT_BIN}, {T}], got {tuple(a.shape)}")

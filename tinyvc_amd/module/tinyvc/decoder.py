@@ -102,7 +102,8 @@ class Decoder(HipModule):
         """The uniform phases the reference draws inside oscillate_noise on every call (decoder.py:78), from torch's generator for
         `device`: pass the result as `noise_angle` to get torch's own draw.  By default (`noise_angle=None`) the library draws the
         phases inside its noise kernel's launch sequence instead (one launch less per call, no [B, 961, T] tensor through torch): a
-        counter-based hash of (seed, utterance row, bin, frame), the seed taken from torch's CPU generator - repeatable under
+        counter-based hash of (seed, utterance row, bin, frame), the seed taken from the device's torch generator (seed and offset, read
+        and advanced on the host) - repeatable under
         torch.manual_seed, like the reference's draw, and like it not reproducible across devices (a CUDA and a CPU torch.rand with
         the same seed differ too)."""
         u = torch.rand(batch, S.FFT_BIN, frames, device=device)
