@@ -669,6 +669,33 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
     pk.conv({"filter_net.content_in"}, &ctx->flt_content_in, kSslDim, 1);
     pk.raw("filter_net.f0_in.weight", &ctx->flt_f_w, ch[0]);
     pk.raw("filter_net.f0_in.bias", &ctx->flt_f_b, ch[0]);
+    // analytic |max| bounds of 1x1 outputs (a hair above max_m sum_k |w_mk| and max |b|): the slot of a tensor an epilogue functor finishes
+    // comes from its input's slot instead of a pass over the tensor
+    auto bound_1x1 = [&](const std::string& name, int cout, int cin, float* bw, float* bb) {
+        const HostTensor* w = pk.find(name + ".weight");
+        const HostTensor* b = pk.find(name + ".bias");
+        if (!w || !b || w->data.size() != (size_t)cout * cin || b->data.size() != (size_t)cout) return;
+        double wl1 = 0.0, bm = 0.0;
+        for (int m = 0; m < cout; ++m) {
+            double sum = 0.0;
+            for (int k = 0; k < cin; ++k) sum += std::fabs((double)w->data[(size_t)m * cin + k]);
+            wl1 = std::max(wl1, sum);
+            bm = std::max(bm, std::fabs((double)b->data[m]));
+        }
+        *bw = (float)(wl1 * 1.0001);
+        *bb = (float)(bm * 1.0001);
+    };
+    {
+        bound_1x1("filter_net.content_in", ch[0], kSslDim, &ctx->flt_in_bw, &ctx->flt_in_bb);
+        const HostTensor* fw = pk.find("filter_net.f0_in.weight");
+        const HostTensor* fb = pk.find("filter_net.f0_in.bias");
+        if (fw && fb) {      // + f0_in(log(relu(f0) + 1e-6)): |log| < 89 for every finite fp32 f0
+            double wm = 0.0, bm = 0.0;
+            for (float v : fw->data) wm = std::max(wm, std::fabs((double)v));
+            for (float v : fb->data) bm = std::max(bm, std::fabs((double)v));
+            ctx->flt_in_bb += (float)((wm * 89.0 + bm) * 1.0001);
+        }
+    }
     pk.down0s(&ctx->flt_down0s, "filter_net.downs.0", &ctx->down0_bw, &ctx->down0_bb);
     for (int i = 1; i <= 4; ++i) {
         DownW& d = ctx->downs[i - 1];
@@ -722,6 +749,7 @@ int tvc_finalize_weights(tvc_ctx* ctx) {
         pk.conv({p + ".c3"}, &u.c3, u.cin, 3);
         pk.conv({p + ".c4"}, &u.c4, u.cin, 3);
         pk.conv({p + ".c5"}, &u.c5, u.cin, 1);
+        bound_1x1(p + ".c5", u.cout, u.cin, &u.c5_bw, &u.c5_bb);
         pk.conv({p + ".film1.to_scale", p + ".film1.to_shift"}, &u.film1, u.cin, 1);
         pk.conv({p + ".film2.to_scale", p + ".film2.to_shift"}, &u.film2, u.cin, 1);
         if (u.cin >= 96) {
@@ -775,6 +803,12 @@ static int convert_impl(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const flo
     float* matched = ws.get<float>((size_t)B * kSslDim * T);
     float* f0 = ws.get<float>((size_t)B * T);
     float* f0s = ws.get<float>((size_t)B * T);
+    // |max| slots the path can bound without a pass over the tensors (block-floating-point guard of the fp16 split, conv3s.h; equal-length
+    // batches): emax = max |wav| per utterance (the energy stage's pooled maxima, 1 500 values each) bounds the energy envelope - a linear
+    // interpolation of them - and, times the Hann window's sum (960), every |STFT| bin; `matched` is a mean of index rows.
+    float* emax = ws.get<float>((size_t)2 * B);
+    float* spec_bound = emax + B;
+    const bool bounds = !ctx->rag;
     size_t m = ws.mark();
     {
         ProfScope ps(ctx, s, dry, "stft");
@@ -783,12 +817,13 @@ static int convert_impl(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const flo
     ws.release(m);
     {
         ProfScope ps(ctx, s, dry, "energy");
-        TVC_CHECK(run_energy(ctx, s, ws, dry, wav, energy, B, L));
+        TVC_CHECK(run_energy(ctx, s, ws, dry, wav, energy, B, L, bounds ? emax : nullptr));
+        if (!dry && bounds) TVC_CHECK(run_slot_affine(ctx, s, spec_bound, emax, 1, 960.5f, 0.f, B));
     }
     ws.release(m);
     {
         ProfScope ps(ctx, s, dry, "encoder");
-        TVC_CHECK(run_encoder(ctx, s, ws, dry, spec, ssl, f0, nullptr, B, T));
+        TVC_CHECK(run_encoder(ctx, s, ws, dry, spec, ssl, f0, nullptr, B, T, bounds ? spec_bound : nullptr));
     }
     ws.release(m);
     {
@@ -797,7 +832,8 @@ static int convert_impl(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const flo
     }
     ws.release(m);
     if (!dry) TVC_CHECK(run_shift(ctx, s, f0, f0s, (int64_t)B * T, pitch_shift));
-    TVC_CHECK(run_decoder(ctx, s, ws, dry, matched, f0s, energy, angle, seed, wave, nullptr, nullptr, nullptr, B, T));
+    TVC_CHECK(run_decoder(ctx, s, ws, dry, matched, f0s, energy, angle, seed, wave, nullptr, nullptr, nullptr, B, T, dry ? nullptr : knn_index_amax(prepared),
+                          bounds ? emax : nullptr));
     ws.release(m);
     return 0;
 }

@@ -387,7 +387,8 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
         int rc = 0;
         if (!gemm_s2_try(&rc, ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax)) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax);
         TVC_CHECK(rc);
-        TVC_CHECK(run_amax_rows(ctx, s, x, B, ch[0], T, slot(S_X)));
+        // x0's |max| slot: the functor finishes the elements, so the slot is the bound bw |content|max + bb instead of a pass over x0
+        TVC_CHECK(run_slot_affine(ctx, s, slot(S_X), cmax, 1, ctx->flt_in_bw, ctx->flt_in_bb, NB));
         // skips[0] is read as FiLM cond only (ups[4]): it is written as the two halves' ready operand; the fp32 tensor exists for the parity tap alone
         TVC_CHECK(run_down0_split(ctx, s, ctx->flt_down0s, source, energy, skip[0], taps ? taps->skips[0] : nullptr, xi_pre[1], B, (int)L, smax, slot(S_SKIP0)));
     }
@@ -478,11 +479,11 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
                     TVC_CHECK(conv_film_half(ctx, s, ca, cb, fw, u.fu2, x1, 0, 0.f, da, db, h, cond, B, C, lo, xout, bsc, bsh, x1, 0, 0.f, ma_in, mh, mcond, mout));
                 }
             }
-            if (C != 48) {   // c5 (1x1, C -> C/2) as a split-precision GEMM launch; its output's |max| in one pass (the functor finishes the elements)
+            if (C != 48) {   // c5 (1x1, C -> C/2) as a split-precision GEMM launch; its output's |max| slot = the bound c5_bw |xu|max + c5_bb (the functor finishes the elements)
                 EpiBias<ACT_NONE, false> ep{xlev[i], u.c5.bias, nullptr, u.cout, lo, nc, (long)u.cout * lo, 0};
                 if (u.c5.MT6 % 3 == 0) TVC_CHECK((gemm_s_launch<3, 4, 1>(ctx, s, u.c5, xu, B, C, lo, 0, ep, slot(S_UXU + i))));
                 else TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, u.c5, xu, B, C, lo, 0, ep, slot(S_UXU + i))));
-                TVC_CHECK(run_amax_rows(ctx, s, xlev[i], B, u.cout, lo, slot(S_LEV + i)));
+                TVC_CHECK(run_slot_affine(ctx, s, slot(S_LEV + i), slot(S_UXU + i), 1, u.c5_bw, u.c5_bb, NB));      // bound of the 1x1's output from its input's slot
             }
         }
         ws.release(mk);
@@ -505,7 +506,7 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
 
 int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
                 const float* energy, const float* angle, uint64_t seed, float* wave, float* amps_out,
-                float* kernel_out, float* source_out, int B, int T) {
+                float* kernel_out, float* source_out, int B, int T, const float* content_bound, const float* energy_bound) {
     const long L = (long)T * kHop;
     float* amps = amps_out ? amps_out : ws.get<float>((size_t)B * kHarm * T);
     float* kern = kernel_out ? kernel_out : ws.get<float>((size_t)B * kBins * T);
@@ -515,9 +516,11 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
     float* cmax = ws.get<float>((size_t)2 * NB);
     float* smax = cmax + NB;
     if (!dry) {
-        TVC_HIP(ctx, hipMemsetAsync(cmax, 0, (size_t)2 * NB * sizeof(float), s));
-        TVC_CHECK(run_amax_rows(ctx, s, content, B, kSslDim, T, cmax));
-        TVC_CHECK(run_amax_rows(ctx, s, energy, B, 1, L, smax));
+        if (!content_bound || !energy_bound) TVC_HIP(ctx, hipMemsetAsync(cmax, 0, (size_t)2 * NB * sizeof(float), s));
+        if (content_bound) TVC_CHECK(run_slot_affine(ctx, s, cmax, content_bound, 0, 1.f, 0.f, NB));
+        else TVC_CHECK(run_amax_rows(ctx, s, content, B, kSslDim, T, cmax));
+        if (energy_bound) TVC_CHECK(run_slot_affine(ctx, s, smax, energy_bound, 1, 1.f, 0.f, NB));      // (the dsp kernels raise it to cat[source, energy]'s)
+        else TVC_CHECK(run_amax_rows(ctx, s, energy, B, 1, L, smax));
     }
     size_t mk = ws.mark();
     {

@@ -398,7 +398,7 @@ int run_pitch_decode(tvc_ctx* ctx, hipStream_t s, const float* logits, float* f0
 }
 
 int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec, float* ssl, float* f0,
-                float* logits, int B, int T) {
+                float* logits, int B, int T, const float* spec_bound) {
     const int ncols = B * T;
     float* xs = ws.get<float>((size_t)B * kSslCh * T);
     float* xp = ws.get<float>((size_t)B * kPitchCh * T);
@@ -410,7 +410,8 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     float *spec_max = slots, *xs_max = slots + NB, *xp_max = slots + 2 * NB;
     if (!dry) {
         TVC_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)3 * NB * sizeof(float), s));
-        TVC_CHECK(run_amax_rows(ctx, s, spec, B, kBins, T, spec_max));
+        if (spec_bound) TVC_CHECK(run_slot_affine(ctx, s, spec_max, spec_bound, 1, 1.f, 0.f, NB));      // the caller's bound instead of a pass over the 961 x T tensor
+        else TVC_CHECK(run_amax_rows(ctx, s, spec, B, kBins, T, spec_max));
         EpiSplit ep{xs, xp, ctx->enc_in.bias, kSslCh, kPitchCh, T, ncols};
         // 961 input rows: the last slab is clamped to row 960 (zero weights beyond)
         TVC_CHECK((gemm_s_launch_ragged<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, s, ctx->enc_in, spec, B, kBins, T, (long)kBins * T, ep, spec_max)));

@@ -66,7 +66,26 @@ static __global__ __launch_bounds__(256) void energy_rag_kernel(const float* __r
     }
 }
 
-int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, float* energy, int B, int64_t L) {
+// out[b] = a * in[b * in_stride] + c: the |max| slot of a tensor from the slot of the tensor it is a bounded function of (in_stride = 0:
+// one value for every utterance).  One 64-thread workgroup; NaN / Inf carry through (bfp_from_amax ignores them).
+static __global__ void slot_affine_kernel(float* __restrict__ out, const float* __restrict__ in, int in_stride, float a, float c, int n) {
+    for (int b = threadIdx.x; b < n; b += blockDim.x) out[b] = fmaf(a, in[(long)b * in_stride], c);
+}
+int run_slot_affine(tvc_ctx* ctx, hipStream_t s, float* out, const float* in, int in_stride, float a, float c, int n) {
+    hipLaunchKernelGGL(slot_affine_kernel, dim3(1), dim3(64), 0, s, out, in, in_stride, a, c, n);
+    return launch_check(ctx, "slot_affine");
+}
+// emax[b] = max_j e[b][j] (one wavefront per utterance: 1 500 values)
+static __global__ void pooled_max_kernel(const float* __restrict__ e, int ne, float* __restrict__ emax) {
+    const float* p = e + (long)blockIdx.x * ne;
+    float m = 0.f;
+    for (int j = threadIdx.x; j < ne; j += 64) m = fmaxf(m, p[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (threadIdx.x == 0) emax[blockIdx.x] = m;
+}
+
+int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, float* energy, int B, int64_t L, float* emax) {
     const int ne = (int)((L + 2 * 32 - 128) / 64 + 1);
     float* e = ws.get<float>((size_t)B * ne + 8);
     if (dry) return 0;
@@ -79,6 +98,7 @@ int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, 
         return launch_check(ctx, "energy (ragged)");
     }
     hipLaunchKernelGGL(energy_pool_kernel, dim3(grid_for((long)B * ne * 64)), dim3(256), 0, s, wav, e, B, (int)L, ne);
+    if (emax) hipLaunchKernelGGL(pooled_max_kernel, dim3(B), dim3(64), 0, s, e, ne, emax);
     // F.interpolate(e, L): `size` given -> scale = float(in) / float(out)
     float scale = (float)ne / (float)L;
     {

@@ -27,7 +27,7 @@ namespace tvc {
 
 constexpr int KD = kSslDim;        // 768
 constexpr int STEPS = KD / 16;     // 48 K16 steps per index tile
-constexpr int HDR = 64;            // blob header, floats: [0] magic, [1] kind, [2] N (low 32 bits), [3] N (high)
+constexpr int HDR = 64;            // blob header, floats: [0] magic, [1] kind, [2] N (low 32 bits), [3] N (high), [4] |max| of the raw vectors (a float)
 constexpr int KIND_F32 = 0, KIND_F16 = 1;
 constexpr int BLOB_MAGIC = 0x54564B4E;
 // fp32 kind:  header | rows fp32 [N][768] | bf16x3 image of v / den [Npad*768*3 bf16] | inv = 1 / den [Npad] | fp16 image of v / den [Npad*768]
@@ -128,6 +128,24 @@ static __global__ __launch_bounds__(256) void index_prepare_f16_kernel(const __h
     if (lane == 0) inv[n] = n < N ? 1.f / (sqrtf(s) + 1e-6f) : 0.f;
 }
 
+// header[4] = the largest |value| of the index: `matched` (the mean of four of its rows) is bounded by it, so the conversion takes the
+// |max| slot of the decoder's content input from here instead of a pass over the tensor (block-floating-point guard, conv3s.h)
+template <class T>
+static __global__ __launch_bounds__(256) void index_amax_kernel(const T* __restrict__ p, long n, float* __restrict__ slot) {
+    __shared__ float red[4];
+    float mx = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) mx = fmaxf(mx, fabsf((float)p[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));      // non-negative floats order like their bits; NaN never enters
+    }
+}
+const float* knn_index_amax(const float* prepared) { return prepared + 4; }
+
 int run_prepare_index(tvc_ctx* ctx, hipStream_t s, const float* index, float* prepared, int64_t N) {
     const long Npad = npad128(N);
     hipLaunchKernelGGL(blob_header_kernel, dim3(1), dim3(64), 0, s, prepared, KIND_F32, (long)N);
@@ -136,6 +154,7 @@ int run_prepare_index(tvc_ctx* ctx, hipStream_t s, const float* index, float* pr
     float* inv = const_cast<float*>(blob_inv(prepared, KIND_F32, N, Npad));
     __half* img16 = reinterpret_cast<__half*>(const_cast<uint4*>(blob_img16(prepared, KIND_F32, N, Npad)));
     hipLaunchKernelGGL(index_prepare_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, s, index, rows, img, inv, img16, (long)N, Npad);
+    hipLaunchKernelGGL(index_amax_kernel<float>, dim3(64), dim3(256), 0, s, index, (long)N * KD, prepared + 4);
     return launch_check(ctx, "knn_prepare_index");
 }
 
@@ -155,6 +174,7 @@ int run_prepare_index_f16(tvc_ctx* ctx, hipStream_t s, const void* rows16, float
     hipLaunchKernelGGL(index_prepare_f16_kernel, dim3((unsigned)((Npad * 64 + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const __half*>(rows16), inv, img, (long)N, Npad);
     hipLaunchKernelGGL(index_invmax_kernel, dim3((unsigned)((Npad / 128 + 255) / 256)), dim3(256), 0, s, inv, const_cast<float*>(blob_invmax(prepared, Npad)), Npad / 128);
+    hipLaunchKernelGGL(index_amax_kernel<__half>, dim3(64), dim3(256), 0, s, reinterpret_cast<const __half*>(rows16), (long)N * KD, prepared + 4);
     return launch_check(ctx, "knn_prepare_index_f16");
 }
 

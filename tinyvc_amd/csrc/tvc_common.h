@@ -75,6 +75,7 @@ struct UpW {
     FilmU fu1, fu2;                            // (c2, film1) and (c4, film2) for the single-accumulator pipelined kernel
     const float* s24a = nullptr;               // cin == 24: weight blobs of the two halves of the split-precision fused block (filter_up24s.hip)
     const float* s24b = nullptr;
+    float c5_bw = 0.f, c5_bb = 0.f;            // |c5 output| <= c5_bw |its input|max + c5_bb (max_m sum_k |w|, max |b|): the level output's |max| slot without a pass over it
     int cin = 0, cout = 0, factor = 1;
 };
 
@@ -132,6 +133,7 @@ struct tvc_ctx {
     tvc::PackedW flt_content_in;
     const float* flt_down0s = nullptr;   // downs.0 weight blob of the split-precision kernel (filter_up24s.hip)
     float down0_bw = 0.f, down0_bb = 0.f; // |downs.0 output| <= down0_bw |input|max + down0_bb: the scale skips[0] is written / read with
+    float flt_in_bw = 0.f, flt_in_bb = 0.f;   // |content_in(content) + f0_in(log f0)| <= flt_in_bw |content|max + flt_in_bb: FilterNet's x0 slot without a pass over x0
     const float* flt_f_w = nullptr;
     const float* flt_f_b = nullptr;
     tvc::DownW downs[4];
@@ -222,9 +224,14 @@ inline int launch_check(tvc_ctx* ctx, const char* what) {
 int run_stft(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* spec, int B, int64_t L);
 int run_stft_fft(tvc_ctx*, hipStream_t, const float* wav, float* spec, int B, int64_t L);
 int run_noise_ifft(tvc_ctx*, hipStream_t, const float* kern, const float* angle, float* frames, int B, int T, bool angle_padded = false);
-int run_energy(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* energy, int B, int64_t L);
+// emax (optional, equal-length batches only): per-utterance max of the pooled |x| = max |wav| of the utterance, written (not accumulated)
+int run_energy(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* energy, int B, int64_t L, float* emax = nullptr);
+const float* knn_index_amax(const float* prepared);
+// out[b] = a * in[b * in_stride] + c for b < n: a |max| slot from the slot of the tensor it is a bounded function of (frontend.hip)
+int run_slot_affine(tvc_ctx*, hipStream_t, float* out, const float* in, int in_stride, float a, float c, int n);      // device pointer to the prepared index's |max| (one float)
+// spec_bound (optional): per-utterance upper bounds of |spec| (the slot of the input contraction); nullptr = one pass over spec measures it
 int run_encoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* spec, float* ssl, float* f0,
-                float* logits, int B, int T);
+                float* logits, int B, int T, const float* spec_bound = nullptr);
 int run_pitch_decode(tvc_ctx*, hipStream_t, const float* logits, float* f0, int B, int T);
 int run_knn(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* src, const float* prepared, int64_t N,
             float* out, int64_t* idx_out, int B, int T);
@@ -234,9 +241,11 @@ int run_knn_slots(tvc_ctx*, hipStream_t, const float* prepared, int64_t N, const
 int run_knn_finish(tvc_ctx*, hipStream_t, const float* slots, float* out, int B, int T);
 int run_shift(tvc_ctx*, hipStream_t, const float* f0, float* out, int64_t n, float semitones);
 int run_uniform_to_angle(tvc_ctx*, hipStream_t, float* u, int64_t n);
+// content_bound (optional): ONE float, an upper bound of |content| (the prepared index's |max| when content came out of the kNN match);
+// energy_bound (optional): per-utterance upper bounds of |energy|.  nullptr = measured by a pass over the tensor.
 int run_decoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* content, const float* f0,
                 const float* energy, const float* angle, uint64_t seed, float* wave, float* amps_out,
-                float* kernel_out, float* source_out, int B, int T);
+                float* kernel_out, float* source_out, int B, int T, const float* content_bound = nullptr, const float* energy_bound = nullptr);
 struct FilterTaps {   // optional copies of FilterNet's block outputs (tvc_filter_net_f32)
     float* skips[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float* ups[4] = {nullptr, nullptr, nullptr, nullptr};
