@@ -98,7 +98,11 @@ __device__ __forceinline__ void conv24_phase(f32x16& hi, f32x16& lo, const u32x4
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             bf[fb][p] = __builtin_bit_cast(f16x8, src[p * 3 * P + row[s]]);
+#ifdef U24_ABL_A
+            if (s == 0) af[0][p] = af[1][p] = __builtin_bit_cast(f16x8, wt[(s * 2 + p) * 64 + lane]);      // what-if: A fragments read once per phase
+#else
             af[fb][p] = __builtin_bit_cast(f16x8, wt[(s * 2 + p) * 64 + lane]);
+#endif
         }
     };
     frags(0, 0);

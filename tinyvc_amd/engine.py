@@ -282,6 +282,10 @@ class Engine:
         return u
 
     def _angle(self, noise_angle, B, T):
+        if noise_angle is None and torch.cuda.is_current_stream_capturing():
+            # inside a graph capture a kernel argument is baked in - one seed would replay for every launch of the graph -; torch's
+            # generator is graph-safe (its offset advances per replay), so a captured call keeps the reference's torch.rand draw
+            return self.noise_angle_from_uniform(torch.rand(B, spec.FFT_BIN, T, device=self.device)), 0
         if noise_angle is None:
             # the library draws the phases itself (tvc_* with noise_angle = NULL: a counter-based hash of (seed, row, bin, frame)).  Its
             # seed comes from THIS DEVICE's torch generator - the one the reference's torch.rand(device=...) draws from -: (seed, philox

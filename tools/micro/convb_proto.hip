@@ -2,6 +2,9 @@
 // A fragments straight from the packed image, no barrier after staging), against conv_s2's 97-103 us at C = 384 x 25 600 columns.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -Itinyvc_amd/csrc tools/micro/convb_proto.hip -o tools/micro/convb_proto_bin
 #include "cnx_s3.h"
+#ifndef PD
+#define PD 4
+#endif
 #include <cstdio>
 #include <vector>
 using namespace tvc;
@@ -50,9 +53,9 @@ __global__ __launch_bounds__((CB<C, D>::NTHR)) void convb_kernel(const float* x,
     }
     __syncthreads();
     for (int mt = wave; mt < MT; mt += WAVES) {
-        u32x4 ring[CNX_PD][2];
+        u32x4 ring[PD][2];
 #pragma unroll
-        for (int u = 0; u < CNX_PD; ++u) {
+        for (int u = 0; u < PD; ++u) {
             const uint4* ab = A6 + ((long)u * MT + mt) * kPU4;
             ring[u][0] = ldg_so4(ab, 16u * (unsigned)lane);
             ring[u][1] = ldg_so4(ab, 16u * (unsigned)(64 + lane));
@@ -73,12 +76,12 @@ __global__ __launch_bounds__((CB<C, D>::NTHR)) void convb_kernel(const float* x,
         };
         bread(0, 0);
 #pragma unroll 1
-        for (int k0 = 0; k0 < KS; k0 += 12) {
+        for (int k0 = 0; k0 < KS; k0 += 24) {
 #pragma unroll
-            for (int u = 0; u < 12; ++u) {
-                const int k = k0 + u, fb = u & 1, ru = u & 3;
+            for (int u = 0; u < 24; ++u) {
+                const int k = k0 + u, fb = u & 1, ru = u % PD;
                 const f16x8 a0 = __builtin_bit_cast(f16x8, ring[ru][0]), a1 = __builtin_bit_cast(f16x8, ring[ru][1]);
-                int kn = k + CNX_PD;
+                int kn = k + PD;
                 kn = kn < KS ? kn : KS - 1;
                 const uint4* ab = A6 + ((long)kn * MT + mt) * kPU4;
                 ring[ru][0] = ldg_so4(ab, 16u * (unsigned)lane);
