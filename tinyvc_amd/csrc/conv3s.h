@@ -184,6 +184,13 @@ __device__ __forceinline__ void stg_so(float* base, unsigned byte_off, float v) 
     asm("" : "+s"(p));
     *reinterpret_cast<gf32>(reinterpret_cast<__attribute__((address_space(1))) char*>(p) + byte_off) = v;
 }
+__device__ __forceinline__ void stg_so4(float* base, unsigned byte_off, const float (&v)[4]) {
+    typedef float f32x4g __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) f32x4g* gf4;
+    gf32 p = (gf32)base;
+    asm("" : "+s"(p));
+    *reinterpret_cast<gf4>(reinterpret_cast<__attribute__((address_space(1))) char*>(p) + byte_off) = f32x4g{v[0], v[1], v[2], v[3]};
+}
 __device__ __forceinline__ u32x4 ldg_so4(const uint4* base, unsigned byte_off) {
     typedef const __attribute__((address_space(1))) u32x4* gcu4;
     gcu4 p = (gcu4)base;

@@ -44,7 +44,7 @@ struct Conv48Args {
     const u32x4* F6;       // stacked FiLM image, 24 pieces
     const u32x4* W5;       // C5: c5's image (1 m-tile, 3 K16 steps: 6 pieces) and bias [32]
     const float* b5;
-    float* out5;           // C5: [B][24][len]
+    float* out5;           // C5: the 24-channel output in the G8 layout [B][3 groups][len][8 channels] (filter_up24s.hip's input)
     const float* bias;     // [>= 48]
     const float* bsc;      // FiLM to_scale / to_shift biases [48]
     const float* bsh;
@@ -364,18 +364,19 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
                 }
                 float m5 = 0.f;
                 if (t < len) {
-                    float* o5 = RAG ? a.out5 + rt.off : a.out5 + (long)b * 24 * rs;
-                    const unsigned o5o = 4u * (unsigned)(4 * lh * rs + t);
+                    float* o5 = RAG ? a.out5 + 8L * rt.off : a.out5 + (long)b * 24 * rs;
+                    const unsigned o5o = 32u * (unsigned)t + 16u * (unsigned)lh;      // this lane's four channels of group g: 16 bytes
                     const float c = cw5 * s5.inv, cl = c * kLoInv;
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
                         const f32x4s_t b5v = *reinterpret_cast<const f32x4s_t*>(Bi + 192 + 8 * g + 4 * lh);
+                        float v4[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float v = comb(a5[4 * g + q], l5[4 * g + q], c, cl) + b5v[q];
-                            stg_so(o5 + (long)(8 * g + q) * rs, o5o, v);
-                            m5 = fmaxf(m5, fabsf(v));
+                            v4[q] = comb(a5[4 * g + q], l5[4 * g + q], c, cl) + b5v[q];
+                            m5 = fmaxf(m5, fabsf(v4[q]));
                         }
+                        stg_so4(o5 + (long)g * 8 * rs, o5o, v4);
                     }
                 }
                 mx_run = fmaxf(mx_run, m5);

@@ -348,6 +348,15 @@ static int conv_film_half(tvc_ctx* ctx, hipStream_t s, const PackedW& ca, const 
     return film_conv(ctx, s, cb, fw, fu, h, cond, B, C, len, db, out, bsc, bsh, res, res_lin, res_scale, BfpSlots{mh, mcond, mout});
 }
 
+// [B][3][l][8] (G8) -> [B][24][l]
+static __global__ void g8_to_planar_kernel(const float* __restrict__ x, float* __restrict__ y, long B, long l) {
+    const long n = B * 24 * l;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long t = i % l, bc = i / l, c = bc % 24, b = bc / 24;
+        y[i] = x[((b * 3 + c / 8) * l + t) * 8 + (c & 7)];
+    }
+}
+
 // cmax / smax (nullable): |max| slots of `content` / of cat[source, energy] if the caller already has them
 int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
                const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps, const float* cmax, const float* smax) {
@@ -497,7 +506,9 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
         long l = T;
         for (int i = 0; i < 4; ++i) {
             l *= ctx->ups[i].factor;
-            if (taps->ups[i])
+            if (taps->ups[i] && ctx->ups[i].cout == 24)      // the 24-channel level travels in the fused ups.4 kernels' G8 layout [B][3][l][8]: back to [B][24][l] for the tap
+                hipLaunchKernelGGL(g8_to_planar_kernel, dim3(grid_for((long)B * 24 * l)), dim3(256), 0, s, xlev[i], taps->ups[i], (long)B, l);
+            else if (taps->ups[i])
                 TVC_HIP(ctx, hipMemcpyAsync(taps->ups[i], xlev[i], (size_t)B * ctx->ups[i].cout * l * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
     }

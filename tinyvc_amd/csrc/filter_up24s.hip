@@ -51,11 +51,12 @@ struct U24S {
 };
 
 struct Up24SArgs {
-    const float* x;      // half A: low-rate input [B][24][len/xf]; half B: x1 [B][24][len]
+    const float* x;      // half A: low-rate input; half B: x1.  Both in the G8 layout [B][3 groups][columns][8 channels] fp32 (a staged item - 8 channels of one
+                         // position - is 32 contiguous bytes: two 16-byte loads instead of eight strided 4-byte ones; the producers store 16 bytes per lane and group)
     const uint4* cond;   // skips[0] as down0s_kernel writes it: the FiLM 1x1s' READY B operand, two fp16 planes [B][part][3 groups][len][8 fp16] of
                          // cond * 2^k, k from the bound cbw |max of downs.0's input| + cbb >= |cond| (amax_c = that input's slot; both kernels evaluate it alike)
     float cbw, cbb;
-    float* out;          // half A: x1 [B][24][len]; half B: waveform [B][len]
+    float* out;          // half A: x1 (G8 layout); half B: waveform [B][len]
     const u32x4* img;    // weight blob (api.hip up24s_half)
     int len, xf, tiles_per_utt, ntiles;
     float interp_scale;
@@ -118,6 +119,23 @@ __device__ __forceinline__ void conv24_phase(f32x16& hi, f32x16& lo, const u32x4
     }
 }
 
+#ifdef U24_TRACE
+// diagnostic build only (tools/micro/u24_trace.py): s_memtime stamps of waves 0, 1, 4, 7 of workgroup U24_TRACE over its first tiles, [half][wave slot][64]
+static __device__ unsigned long long g_u24_trace[2 * 4 * 64];
+#define U24_STAMP(id)                                                                                  \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (tr_on && tr_n < 60) {                                                                      \
+            unsigned long long t_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+            g_u24_trace[((CF::SECOND ? 1 : 0) * 4 + tr_slot) * 64 + 1 + tr_n++] = (t_ << 8) | (unsigned)(id); \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+#else
+#define U24_STAMP(id) do {} while (0)
+#endif
+
 template <class CF, bool RAG>
 __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE))) void up24s_kernel(Up24SArgs a) {
     constexpr int C = CF::C, W = CF::W, D1 = CF::D1, D2 = CF::D2, H = CF::H, E = CF::E, NT = CF::NT;
@@ -130,6 +148,11 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     float* R = Fl + CF::FL;                                       // [24][PS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
+#ifdef U24_TRACE
+    const int tr_slot = wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 4 ? 2 : 3));
+    const bool tr_on = (int)blockIdx.x == U24_TRACE && lane == 0 && (wave == 0 || wave == 1 || wave == 4 || wave == 7);
+    int tr_n = 0;
+#endif
     const int rs = a.len;                                  // row stride of cond / x1 (= every utterance's length unless RAG)
     const int rsl = CF::SECOND ? rs : rs / a.xf;           // row stride of the input x
     int bh = 0;                                            // RAG: utterance hint of the table walk
@@ -156,24 +179,38 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
         const int len = rt.len, lin = CF::SECOND ? len : len / a.xf;         // this utterance's extents (output rate / input rate)
         const int px0 = rt.tin * W - E - H;
-        const float* xb = RAG ? a.x + (CF::SECOND ? rt.off : rt.off / a.xf) : a.x + (long)rt.b * C * rsl;
+        const uint4* xb = reinterpret_cast<const uint4*>(RAG ? a.x + 8L * (CF::SECOND ? rt.off : rt.off / a.xf) : a.x + (long)rt.b * C * rsl);      // G8: group g, column p at 32 (g rsl + p) bytes
+        auto ld8 = [&](float (&dst)[8], unsigned o) __attribute__((always_inline)) {
+#ifdef U24_ABL_FETCH
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[j] = (float)(o + j);      // what-if: no input loads
+#else
+            // (element by element: indexing an ext_vector with the induction variable of an unrolled loop is folded wrongly by this compiler -
+            // elements 2 and 3 came out dead, their registers were handed to the next load; gemm_s2.h met the same)
+            const f32x4s q0 = __builtin_bit_cast(f32x4s, ldg_so4(xb, o)), q1 = __builtin_bit_cast(f32x4s, ldg_so4(xb, o + 16u));
+            dst[0] = q0.x; dst[1] = q0.y; dst[2] = q0.z; dst[3] = q0.w;
+            dst[4] = q1.x; dst[5] = q1.y; dst[6] = q1.z; dst[7] = q1.w;
+#endif
+        };
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
             int p = px0 + ic[i];
             p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
+            const int g = ig8[i] >> 3;
             if (CF::SECOND) {
+#ifdef X1_PLANAR
+                const float* xp = RAG ? a.x + rt.off : a.x + (long)rt.b * C * rsl;
                 const unsigned o = 4u * (unsigned)(ig8[i] * rsl + p);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xb + (long)j * rsl, o);
+                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xp + (long)j * rsl, o);
+#else
+                ld8(xr0[i], 32u * (unsigned)(g * rsl + p));
+#endif
             } else {
                 const Lerp lc = lerp_coord(p, a.interp_scale, lin);
                 lam[i] = lc.w1;
-                const unsigned o0 = 4u * (unsigned)(ig8[i] * rsl + lc.i0), o1 = 4u * (unsigned)(ig8[i] * rsl + lc.i1);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    xr0[i][j] = ldg_so(xb + (long)j * rsl, o0);
-                    xr1[i][j] = ldg_so(xb + (long)j * rsl, o1);
-                }
+                ld8(xr0[i], 32u * (unsigned)(g * rsl + lc.i0));
+                ld8(xr1[i], 32u * (unsigned)(g * rsl + lc.i1));
             }
         }
     };
@@ -220,6 +257,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     int mx_b = bh;
 
     for (; tile < tend; ++tile) {
+        U24_STAMP(0);
         const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
         const int b = rt.b, len = rt.len;
         bh = b;
@@ -253,6 +291,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
             }
         }
         if (next < tend) fetch(next);   // lands in registers during the whole tile
+        U24_STAMP(1);
 
         // ---- S1: Hs = split(lrelu(conv_a(lrelu(x)) + ba)) ---------------------------------------------
         for (int nt = wave; nt < CF::NT1; nt += CF::NWAVES) {
@@ -283,7 +322,9 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 *reinterpret_cast<u32x4*>(Hs + (3 * lh + g) * HP + h) = row;
             }
         }
+        U24_STAMP(2);
         slab_barrier();
+        U24_STAMP(3);
 
         // ---- S2: (conv_b(Hs) + bb) * scale + shift + res ------------------------------------------------
         if (wave < CF::NT2) {
@@ -332,11 +373,12 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 lsc = TVC_MFMA16(fa[0][0], cf[s][1], lsc);
                 lsh = TVC_MFMA16(fa[1][0], cf[s][1], lsh);
             }
-            float* ob = CF::SECOND ? nullptr : (RAG ? a.out + rt.off : a.out + (long)b * C * rs);
-            const unsigned oo = 4u * (unsigned)(4 * lh * rs + t);
+            float* ob = CF::SECOND ? nullptr : (RAG ? a.out + 8L * rt.off : a.out + (long)b * C * rs);      // x1 in the G8 layout: this lane's four channels of group g = 16 bytes
+            const unsigned oo = 32u * (unsigned)t + 16u * (unsigned)lh;
             float mx = 0.f;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
+                float v4[4];
                 const f32x4s bs = *reinterpret_cast<const f32x4s*>(Fl + 64 + 8 * g + 4 * lh);
                 const f32x4s bh = *reinterpret_cast<const f32x4s*>(Fl + 96 + 8 * g + 4 * lh);
 #pragma unroll
@@ -347,18 +389,26 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                     const float shv = comb(ash[4 * g + q], lsh[4 * g + q], c2, c2l) + bh[q];
                     const float res = R[m * PS + n];
                     const float v = __fadd_rn(__fadd_rn(__fmul_rn(hval, scv), shv), res);
-                    if (CF::SECOND)
-                        R[m * PS + n] = v;                                     // x2 stays on chip
-                    else if (n < W && t < len) {
-                        stg_so(ob + (long)(8 * g + q) * rs, oo, v);            // x1 (uniform row base + lane offset)
-                        mx = fmaxf(mx, fabsf(v));
-                    }
+                    v4[q] = v;
+                    if (CF::SECOND) R[m * PS + n] = v;                         // x2 stays on chip
+                }
+                if (!CF::SECOND && n < W && t < len) {
+#ifdef X1_PLANAR
+                    float* obp = RAG ? a.out + rt.off : a.out + (long)b * C * rs;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) stg_so(obp + (long)(8 * g + q) * rs, 4u * (unsigned)(4 * lh * rs + t), v4[q]);
+#else
+                    stg_so4(ob + (long)g * 8 * rs, oo, v4);                    // x1 (uniform group base + lane offset)
+#endif
+                    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v4[0]), fabsf(v4[1])), fmaxf(fabsf(v4[2]), fabsf(v4[3]))));
                 }
             }
             mx_run = fmaxf(mx_run, mx);
         }
+        U24_STAMP(4);
         if (CF::SECOND) {
             slab_barrier();
+            U24_STAMP(5);
             // ---- S4: c5 and output_layer folded into one Conv1d(24 -> 1, k7, replicate) on the parked x2 tile ----
             // 8 lanes per group of 4 consecutive outputs, 3 channels each: per channel 10 activations and 7
             // (broadcast) weights feed 28 FMAs; the 8 partial sums meet through three shuffles.
@@ -410,10 +460,16 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
             }
         }
         // ---- next tile's input: registers -> LDS ----------------------------------------------------------
+        U24_STAMP(6);
         slab_barrier();                                   // every wave is done with Xs, Hs and R
+        U24_STAMP(7);
         if (next < tend) deposit(bfp_load(a.amax_x, utt(next)).s);
+        U24_STAMP(8);
         slab_barrier();
     }
+#ifdef U24_TRACE
+    if (tr_on) g_u24_trace[((CF::SECOND ? 1 : 0) * 4 + tr_slot) * 64] = (unsigned long long)tr_n;
+#endif
     if (!CF::SECOND && a.amax_y && tend > (int)((long)a.ntiles * blockIdx.x / gridDim.x)) amax_flush_wg(a.amax_y + mx_b, mx_run, Fl + 304);
 }
 
@@ -444,10 +500,18 @@ static int launch_up24s(tvc_ctx* ctx, hipStream_t s, Up24SArgs a, int B) {
     return launch_check(ctx, "up24s");
 }
 
+#ifdef U24_TRACE
+}  // namespace tvc
+extern "C" int tvc_debug_trace_u24(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(tvc::g_u24_trace), sizeof(tvc::g_u24_trace)) == hipSuccess ? 0 : -1;
+}
+namespace tvc {
+#endif
+
 constexpr int U24S_WA = 250, U24S_WB = 250;     // output samples per tile of the two halves (196 / 218 for the second half - one round of first-conv tiles instead of two - measured 8 % slower: the halo dominates)
 
 // Upsample block with cin == 24 followed by FilterNet.output_layer:
-// x [B][24][len/f], cond [B][24][len] -> wave [B][len]; x1 is scratch [B][24][len].
+// x [B][3][len/f][8] (G8 layout, see Up24SArgs), cond planes -> wave [B][len]; x1 is scratch of B * 24 * len floats (G8 layout).
 // amax_x / amax_c: per-utterance |max| slots of x / cond; amax_x1: scratch slot [B] (zeroed) for the block's intermediate x1.
 int run_up24_split(tvc_ctx* ctx, hipStream_t s, const UpW& u, const float* x, const float* cond_planes, float cbw, float cbb, float* x1, float* wave, int B, int len,
                    const float* amax_x, const float* amax_c, float* amax_x1) {
