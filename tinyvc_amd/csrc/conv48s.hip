@@ -35,11 +35,26 @@ __device__ __forceinline__ void split4_48(const float (&v)[4], u32x2_t& p1, u32x
     }
 }
 
+// 8 consecutive channels of one column of a G8 tensor ([groups][columns][8 channels] fp32: 32 contiguous bytes) as two 16-byte loads.
+// (element by element: an ext_vector indexed by the induction variable of an unrolled loop is folded wrongly by this compiler)
+__device__ __forceinline__ void ld8_g8(float (&dst)[8], const float* base, unsigned byte_off) {
+    const uint4* b4 = reinterpret_cast<const uint4*>(base);
+    const f32x4s_t q0 = __builtin_bit_cast(f32x4s_t, ldg_so4(b4, byte_off)), q1 = __builtin_bit_cast(f32x4s_t, ldg_so4(b4, byte_off + 16u));
+    dst[0] = q0.x; dst[1] = q0.y; dst[2] = q0.z; dst[3] = q0.w;
+    dst[4] = q1.x; dst[5] = q1.y; dst[6] = q1.z; dst[7] = q1.w;
+}
+__device__ __forceinline__ void ld4_g8(float (&dst)[4], const float* base, unsigned byte_off) {
+    const f32x4s_t q0 = __builtin_bit_cast(f32x4s_t, ldg_so4(reinterpret_cast<const uint4*>(base), byte_off));
+    dst[0] = q0.x; dst[1] = q0.y; dst[2] = q0.z; dst[3] = q0.w;
+}
+
 struct Conv48Args {
-    const float* x;        // [B][48][len], or (LERP) the low-rate tensor [B][48][lin]
-    const float* cond;     // FILM: [B][48][len]
-    const float* res;      // RES 1: [B][48][len]; RES 2: low-rate [B][48][rlin], interpolated here
-    float* out;            // [B][48][len]
+    // The level's own tensors - x1, h, the skip tensor cond - travel in the G8 layout [B][6 groups][len][8 channels] (a staged item, a cond
+    // fragment or a lane's four output channels are 32 / 32 / 16 contiguous bytes: 16-byte accesses instead of strided 4-byte ones)
+    const float* x;        // G8 [B][6][len][8]; LERP: the low-rate tensor, planar [B][48][lin]
+    const float* cond;     // FILM: G8
+    const float* res;      // RES 1: G8; RES 2: low-rate planar [B][48][rlin], interpolated here
+    float* out;            // G8
     const u32x4* A6;       // conv image, 36 pieces
     const u32x4* F6;       // stacked FiLM image, 24 pieces
     const u32x4* W5;       // C5: c5's image (1 m-tile, 3 K16 steps: 6 pieces) and bias [32]
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
         const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
         const int len = rt.len, lin = LERP ? len / xf : len;
         const int px0 = rt.tin * BN - dil;
-        const float* xb = RAG ? a.x + (LERP ? rt.off / xf : rt.off) : a.x + (long)rt.b * C * rsl;
+        const float* xb = RAG ? a.x + (LERP ? rt.off / xf : 8L * rt.off) : a.x + (long)rt.b * C * rsl;
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
             const int g = ig[i] > 5 ? 5 : ig[i];
@@ -133,9 +148,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
                     xr1[i][j] = ldg_so(xb + (long)j * rsl, o1);
                 }
             } else {
-                const unsigned o = 4u * (unsigned)(8 * g * rsl + p);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xr0[i][j] = ldg_so(xb + (long)j * rsl, o);
+                ld8_g8(xr0[i], xb, 32u * (unsigned)(g * rsl + p));
             }
         }
     };
@@ -184,26 +197,29 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
         const int n = nt * 32 + l31;
         const int t = t0 + n;
         const int tc = t < len ? t : len - 1;
-        const unsigned oo = 4u * (unsigned)((32 * mt + 4 * lh) * rs + tc);   // rows 32 mt + 8 g + 4 lh + q, sample t (the wave's m-tile lives in the lane offset: bases stay uniform)
 
         // cond fragments of this wave's columns: K16 step s -> channels 16 s + 8 lh + j
         float cr[FILM ? 3 : 1][8];
         if (FILM) {
-            const float* cb = RAG ? a.cond + rt.off : a.cond + (long)b * C * rs;
-            const unsigned oc = 4u * (unsigned)(8 * lh * rs + tc);
+            const float* cb = RAG ? a.cond + 8L * rt.off : a.cond + (long)b * C * rs;
+            const unsigned oc = 32u * (unsigned)(lh * rs + tc);                     // group 2 s + lh, column tc
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) cr[s][j] = ldg_so(cb + (long)(16 * s + j) * rs, oc);
+            for (int s = 0; s < 3; ++s) ld8_g8(cr[s], cb + (long)s * 16 * rs, oc);
         }
         // residual values of this lane's 16 rows
         float rv[RES ? 4 : 1][4];
         if (RES == 1) {
-            const float* rb = RAG ? a.res + rt.off : a.res + (long)b * C * rs;
+            const float* rb = RAG ? a.res + 8L * rt.off : a.res + (long)b * C * rs;
+            const unsigned og = 32u * (unsigned)(4 * mt * rs + tc) + 16u * (unsigned)lh;      // group 4 mt + g, column tc, channels 4 lh ..
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g) {
+                if (32 * mt + 8 * g < C) {
+                    ld4_g8(rv[g], rb + (long)g * 8 * rs, og);
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rv[g][q] = 32 * mt + 8 * g < C ? ldg_so(rb + (long)(8 * g + q) * rs, oo) : 0.f;   // rows past 48 do not exist
+                    for (int q = 0; q < 4; ++q) rv[g][q] = 0.f;                      // rows past 48 do not exist
+                }
+            }
         } else if (RES == 2) {
             const float* rb = RAG ? a.res + rt.off / rf : a.res + (long)b * C * a.rlin;
             const Lerp lc = lerp_coord(tc, a.rscale, RAG ? len / rf : a.rlin);
@@ -291,10 +307,12 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
         float xv[C5 ? 4 : 1][4];
         float mx = 0.f;                   // |max| of what this lane stores (C5: of its part of the finished tile)
         {
-            float* ob = C5 ? nullptr : (RAG ? a.out + rt.off : a.out + (long)b * C * rs);
+            float* ob = C5 ? nullptr : (RAG ? a.out + 8L * rt.off : a.out + (long)b * C * rs);
+            const unsigned og = 32u * (unsigned)(4 * mt * rs + tc) + 16u * (unsigned)lh;      // G8: group 4 mt + g, column, this lane's four channels
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (32 * mt + 8 * g >= C) continue;                                // uniform per wave
+                float v4[4];
                 const f32x4s_t bv = *reinterpret_cast<const f32x4s_t*>(Bi + 32 * mt + 8 * g + 4 * lh);
                 f32x4s_t bs, bh;
                 if (FILM) {
@@ -306,13 +324,15 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
                     float v = acc[4 * g + q] + bv[q];
                     if (FILM) v = __fadd_rn(__fmul_rn(v, asc[4 * g + q] + bs[q]), ash[4 * g + q] + bh[q]);
                     if (RES) v = __fadd_rn(v, rv[g][q]);
+                    v4[q] = v;
                     if (C5) {
                         xv[g][q] = v;
                         mx = fmaxf(mx, fabsf(v));
-                    } else if (t < len) {
-                        stg_so(ob + (long)(8 * g + q) * rs, oo, v);
-                        mx = fmaxf(mx, fabsf(v));
                     }
+                }
+                if (!C5 && t < len) {
+                    stg_so4(ob + (long)g * 8 * rs, og, v4);
+                    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v4[0]), fabsf(v4[1])), fmaxf(fabsf(v4[2]), fabsf(v4[3]))));
                 }
             }
         }
@@ -429,10 +449,10 @@ int launch48(tvc_ctx* ctx, hipStream_t s, Conv48Args a, int B) {
 // the first conv's epilogue with an exact per-tile power-of-two pre-scale (the tile's |max| meets in LDS behind the barrier
 // between the two convs); replicate padding of h at the utterance ends = a column clamp when the second conv reads it.
 struct Conv48PArgs {
-    const float* x;        // [B][48][len], or (LERP) the low-rate tensor [B][48][lin]
-    const float* cond;     // FILM: [B][48][len]
-    const float* res;      // RES 2: low-rate [B][48][rlin], interpolated here
-    float* out;            // [B][48][len]
+    const float* x;        // planar [B][48][len], or (LERP) the low-rate tensor [B][48][lin]
+    const float* cond;     // FILM: G8 [B][6][len][8] (Conv48Args)
+    const float* res;      // RES 2: low-rate planar [B][48][rlin], interpolated here
+    float* out;            // FILM: G8 (Upsample 3's x1); else planar [B][48][len]
     const u32x4* Aa;       // first / second conv image, 36 pieces each
     const u32x4* Ab;
     const u32x4* F6;       // stacked FiLM image, 24 pieces
@@ -571,12 +591,10 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
 
         float cr[FILM ? 3 : 1][8];
         if (FILM) {
-            const float* cb = RAG ? a.cond + rt.off : a.cond + (long)b * C * rs;
-            const unsigned oc = 4u * (unsigned)(8 * lh * rs + tc);
+            const float* cb = RAG ? a.cond + 8L * rt.off : a.cond + (long)b * C * rs;      // G8 (Conv48Args)
+            const unsigned oc = 32u * (unsigned)(lh * rs + tc);                     // group 2 s + lh, column tc
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) cr[s][j] = ldg_so(cb + (long)(16 * s + j) * rs, oc);
+            for (int s = 0; s < 3; ++s) ld8_g8(cr[s], cb + (long)s * 16 * rs, oc);
         }
         float rv[RES ? 4 : 1][4];
         if (RES == 2) {
@@ -733,10 +751,13 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         // ---- epilogue ---------------------------------------------------------------------------------------------------
         {
             float mx = 0.f;
-            float* ob = RAG ? a.out + rt.off : a.out + (long)b * C * rs;
+            // the FiLM launch's output is Upsample 3's x1: G8 (conv48s_kernel reads it); the plain launch's (Downsample 2's h2) stays planar for conv3s
+            float* ob = RAG ? a.out + (FILM ? 8L : 1L) * rt.off : a.out + (long)b * C * rs;
+            const unsigned og = 32u * (unsigned)(4 * mt * rs + tc) + 16u * (unsigned)lh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (32 * mt + 8 * g >= C) continue;                                // uniform per wave
+                float v4[4];
                 const f32x4s_t bv = *reinterpret_cast<const f32x4s_t*>(Bi + 64 + 32 * mt + 8 * g + 4 * lh);
                 f32x4s_t bs, bh;
                 if (FILM) {
@@ -748,10 +769,12 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
                     float v = acc[4 * g + q] + bv[q];
                     if (FILM) v = __fadd_rn(__fmul_rn(v, asc[4 * g + q] + bs[q]), ash[4 * g + q] + bh[q]);
                     if (RES) v = __fadd_rn(v, rv[g][q]);
-                    if (live) {
-                        stg_so(ob + (long)(8 * g + q) * rs, oo, v);
-                        mx = fmaxf(mx, fabsf(v));
-                    }
+                    v4[q] = v;
+                    if (!FILM && live) stg_so(ob + (long)(8 * g + q) * rs, oo, v);
+                }
+                if (live) {
+                    if (FILM) stg_so4(ob + (long)g * 8 * rs, og, v4);
+                    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v4[0]), fabsf(v4[1])), fmaxf(fabsf(v4[2]), fabsf(v4[3]))));
                 }
             }
             mx_run = fmaxf(mx_run, mx);

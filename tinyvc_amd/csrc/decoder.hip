@@ -348,12 +348,12 @@ static int conv_film_half(tvc_ctx* ctx, hipStream_t s, const PackedW& ca, const 
     return film_conv(ctx, s, cb, fw, fu, h, cond, B, C, len, db, out, bsc, bsh, res, res_lin, res_scale, BfpSlots{mh, mcond, mout});
 }
 
-// [B][3][l][8] (G8) -> [B][24][l]
-static __global__ void g8_to_planar_kernel(const float* __restrict__ x, float* __restrict__ y, long B, long l) {
-    const long n = B * 24 * l;
+// [B][C / 8][l][8] (G8) -> [B][C][l]
+static __global__ void g8_to_planar_kernel(const float* __restrict__ x, float* __restrict__ y, long B, long l, int C) {
+    const long n = B * C * l;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const long t = i % l, bc = i / l, c = bc % 24, b = bc / 24;
-        y[i] = x[((b * 3 + c / 8) * l + t) * 8 + (c & 7)];
+        const long t = i % l, bc = i / l, c = bc % C, b = bc / C;
+        y[i] = x[((b * (C / 8) + c / 8) * l + t) * 8 + (c & 7)];
     }
 }
 
@@ -501,13 +501,15 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
     }
     if (!dry && taps) {   // parity taps: the block outputs are still live in the workspace
         for (int i = 1; i < 5; ++i)      // (skips[0] was written into the tap by its producer)
-            if (taps->skips[i])
+            if (taps->skips[i] && i == 1)      // the 48-channel skip travels in the G8 layout (down24f_kernel -> conv48s.hip's FiLM cond)
+                hipLaunchKernelGGL(g8_to_planar_kernel, dim3(grid_for((long)B * 48 * len_dn[1])), dim3(256), 0, s, skip[1], taps->skips[1], (long)B, len_dn[1], 48);
+            else if (taps->skips[i])
                 TVC_HIP(ctx, hipMemcpyAsync(taps->skips[i], skip[i], (size_t)B * ch[4 - i] * len_dn[i] * sizeof(float), hipMemcpyDeviceToDevice, s));
         long l = T;
         for (int i = 0; i < 4; ++i) {
             l *= ctx->ups[i].factor;
             if (taps->ups[i] && ctx->ups[i].cout == 24)      // the 24-channel level travels in the fused ups.4 kernels' G8 layout [B][3][l][8]: back to [B][24][l] for the tap
-                hipLaunchKernelGGL(g8_to_planar_kernel, dim3(grid_for((long)B * 24 * l)), dim3(256), 0, s, xlev[i], taps->ups[i], (long)B, l);
+                hipLaunchKernelGGL(g8_to_planar_kernel, dim3(grid_for((long)B * 24 * l)), dim3(256), 0, s, xlev[i], taps->ups[i], (long)B, l, 24);
             else if (taps->ups[i])
                 TVC_HIP(ctx, hipMemcpyAsync(taps->ups[i], xlev[i], (size_t)B * ctx->ups[i].cout * l * sizeof(float), hipMemcpyDeviceToDevice, s));
         }

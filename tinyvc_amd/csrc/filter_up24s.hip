@@ -721,7 +721,7 @@ int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float*
 // analytic bound (max_m sum|w1|) |xi|max + max|b1|, h2 by the bound of that bound, c3 and down_res share one scale as they share accumulators.
 struct Down24FArgs {
     const float* x;        // xi [B][24][len]
-    float* out;            // [B][48][len]
+    float* out;            // [B][6][len][8]: the block's output in the G8 layout (conv48s.hip: 16-byte stores here, 16-byte fragment loads there)
     float* y2;             // optional [B][48][len / 4]: mean of samples 4 d + 1, 4 d + 2 (the next block's 1/4-rate input)
     const u32x4* img1;     // the three convs' blobs (api.hip Packer::conv24s): c1 (10 pieces + 64 floats), c2, c3 (20 pieces, bias = c3 + down_res, joint scales)
     const u32x4* img2;
@@ -961,9 +961,9 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
         }
         float mx = 0.f;
         {
-            float* ob = RAG ? a.out + rt.off : a.out + (long)b * 48 * rs;
+            float* ob = RAG ? a.out + 8L * rt.off : a.out + (long)b * 48 * rs;      // skips[1] in the G8 layout [6 groups][len][8] (conv48s.hip reads it as FiLM cond)
             float* y2b = a.y2 ? (RAG ? a.y2 + (rt.off >> 2) : a.y2 + (long)b * 48 * len2) : nullptr;
-            const unsigned oo = 4u * (unsigned)(4 * lh * rs + tc);
+            const unsigned oo = 32u * (unsigned)tc + 16u * (unsigned)lh;
             const bool pair = a.y2 != nullptr && (t & 3) == 1 && t + 1 < len;      // 1/4-rate copy: mean of samples 4 d + 1, 4 d + 2
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -972,17 +972,19 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
                 for (int g = 0; g < 4; ++g) {
                     if (32 * mt + 8 * g >= 48) continue;
                     const f32x4s bv = *reinterpret_cast<const f32x4s*>(Bi + 128 + 32 * mt + 8 * g + 4 * lh);
+                    float v4[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float v = comb(acc[mt][4 * g + q], alo[mt][4 * g + q], c, cl) + bv[q];
                         const float vn = __shfl_down(v, 1);                        // sample t + 1 (same tile: W % 4 == 0)
                         const int m = 32 * mt + 8 * g + 4 * lh + q;
+                        v4[q] = v;
                         if (live) {
-                            stg_so(ob + (long)(32 * mt + 8 * g + q) * rs, oo, v);
                             mx = fmaxf(mx, fabsf(v));
                             if (pair) y2b[(long)m * len2 + (t >> 2)] = fmaf(0.5f, v, __fmul_rn(0.5f, vn));
                         }
                     }
+                    if (live) stg_so4(ob + (long)(4 * mt + g) * 8 * rs, oo, v4);
                 }
             }
         }
