@@ -79,6 +79,15 @@ __device__ __forceinline__ void split4(const float (&v)[4], u32x2& p1, u32x2& p2
     }
 }
 
+// 8 consecutive channels of one column of a G8 tensor ([groups][columns][8 channels] fp32: 32 contiguous bytes) as two 16-byte loads.
+// (element by element: an ext_vector indexed by the induction variable of an unrolled loop is folded wrongly by this compiler)
+__device__ __forceinline__ void ld8_g8(float (&dst)[8], const float* base, unsigned byte_off) {
+    const uint4* b4 = reinterpret_cast<const uint4*>(base);
+    const f32x4s q0 = __builtin_bit_cast(f32x4s, ldg_so4(b4, byte_off)), q1 = __builtin_bit_cast(f32x4s, ldg_so4(b4, byte_off + 16u));
+    dst[0] = q0.x; dst[1] = q0.y; dst[2] = q0.z; dst[3] = q0.w;
+    dst[4] = q1.x; dst[5] = q1.y; dst[6] = q1.z; dst[7] = q1.w;
+}
+
 // (hi, lo) += W (.) src over the 9 (tap, group) units of a 24-channel k3 conv for this wave's 32 columns.
 // src = Xs / Hs ([part][group][P rows]), wt = the conv's 10 pieces, col = this lane's column of tap 0, clamped to [lo_c, hi_c].
 template <int P, int DIL>
@@ -553,7 +562,7 @@ struct Down0SArgs {
     float* out;            // optional (parity taps) [B][24][L] fp32
     uint4* planes;         // the output as the FiLM 1x1s' ready B operand (up24s_kernel): two fp16 planes [B][part][3 groups][L][8 fp16] of out * 2^k,
                            // k from the analytic bound Bi[29] |x|max + Bi[30] >= |out| (amax_x non-null)
-    float* y2;             // optional [B][24][L / 5]: F.interpolate(out, scale_factor = 1/5) = the sample at 5 d + 2
+    float* y2;             // optional, G8 layout [B][3][L / 5][8]: F.interpolate(out, scale_factor = 1/5) = the sample at 5 d + 2
     const u32x4* img;      // 10 weight pieces + 32 floats: bias, [31] = the image's scale (api.hip down0s)
     int len, tiles_per_utt, ntiles;
     const float* amax_x;   // per-utterance |max| of cat[source, energy] (block-floating-point guard, conv3s.h), nullable
@@ -649,7 +658,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
             const int tc = t < len ? t : len - 1;
             float* ob = a.out ? (RAG ? a.out + rt.off : a.out + (long)b * 24 * rs) : nullptr;
             uint4* pb = RAG ? a.planes + rt.off : a.planes + (long)b * 6 * rs;
-            float* y2b = a.y2 ? (RAG ? a.y2 + rt.off / 5 : a.y2 + (long)b * 24 * len2) : nullptr;
+            float* y2b = a.y2 ? (RAG ? a.y2 + 8L * (rt.off / 5) : a.y2 + (long)b * 24 * len2) : nullptr;      // G8 layout [3][len2][8] (down24f_kernel's input)
             const unsigned oo = 4u * (unsigned)(4 * lh * rs + tc);
             const int q5 = tc / 5;
             const bool pick = live && a.y2 != nullptr && tc - 5 * q5 == 2;
@@ -663,8 +672,11 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
                     if (live) {
                         if (ob) stg_so(ob + (long)(8 * gg + q) * rs, oo, v[q] * pinv);
                         mx = fmaxf(mx, fabsf(v[q]));
-                        if (pick) y2b[(long)(8 * gg + 4 * lh + q) * len2 + q5] = v[q] * pinv;
                     }
+                }
+                if (pick) {
+                    const float p4[4] = {v[0] * pinv, v[1] * pinv, v[2] * pinv, v[3] * pinv};
+                    stg_so4(y2b + (long)gg * 8 * len2, 32u * (unsigned)q5 + 16u * (unsigned)lh, p4);
                 }
                 // a position's 16-byte operand row = [lanes 0-31's four channels | lanes 32-63's four]: v_permlane32_swap hands the lower half of
                 // the wave both halves of the part-1 row and the upper half those of part 2 (every lane takes part: no branch around it)
@@ -720,7 +732,7 @@ int run_down0_split(tvc_ctx* ctx, hipStream_t s, const float* blob, const float*
 // result is bit-identical to theirs (measured before they were removed).  The intermediates have no |max| slot (they never leave the CU): h1 is scaled by the
 // analytic bound (max_m sum|w1|) |xi|max + max|b1|, h2 by the bound of that bound, c3 and down_res share one scale as they share accumulators.
 struct Down24FArgs {
-    const float* x;        // xi [B][24][len]
+    const float* x;        // xi, G8 layout [B][3][len][8] (down0s_kernel's 1/5-rate copy)
     float* out;            // [B][6][len][8]: the block's output in the G8 layout (conv48s.hip: 16-byte stores here, 16-byte fragment loads there)
     float* y2;             // optional [B][48][len / 4]: mean of samples 4 d + 1, 4 d + 2 (the next block's 1/4-rate input)
     const u32x4* img1;     // the three convs' blobs (api.hip Packer::conv24s): c1 (10 pieces + 64 floats), c2, c3 (20 pieces, bias = c3 + down_res, joint scales)
@@ -774,7 +786,7 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
         const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
         const int len = rt.len;
         const int px0 = rt.tin * W - 7;
-        const float* xb = RAG ? a.x + rt.off : a.x + (long)rt.b * 24 * rs;
+        const float* xb = RAG ? a.x + 8L * rt.off : a.x + (long)rt.b * 24 * rs;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * NT;
@@ -783,9 +795,7 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
             g = g > 2 ? 2 : g;                                 // idle items load a valid address
             int p = px0 + c;
             p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
-            const unsigned o = 4u * (unsigned)(8 * g * rs + p);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xa[i][j] = ldg_so(xb + (long)j * rs, o);
+            ld8_g8(xa[i], xb, 32u * (unsigned)(g * rs + p));
         }
     };
     auto deposit = [&](int buf, float xs) __attribute__((always_inline)) {
@@ -873,13 +883,9 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
         // down_res's B fragments (xi at the output position, raw), requested before the first multiply
         float xq0[8], xq1[8];
         {
-            const float* xb2 = RAG ? a.x + rt.off : a.x + (long)b * 24 * rs;
-            const unsigned o0 = 4u * (unsigned)(8 * lh * rs + tc), o1 = 4u * (unsigned)tc;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                xq0[j] = ldg_so(xb2 + (long)j * rs, o0);                // K16 step 0: channels 8 lh + j
-                xq1[j] = ldg_so(xb2 + (long)(16 + j) * rs, o1);         // step 1: channels 16 + j on lh = 0, the zero unit on lh = 1
-            }
+            const float* xb2 = RAG ? a.x + 8L * rt.off : a.x + (long)b * 24 * rs;
+            ld8_g8(xq0, xb2, 32u * (unsigned)(lh * rs + tc));          // K16 step 0: channels 8 lh + j = group lh
+            ld8_g8(xq1, xb2, 32u * (unsigned)(2 * rs + tc));           // step 1: channels 16 + j = group 2 on lh = 0, the zero unit on lh = 1
         }
         // ---- c1: Xs -> H1 (position t0 - 6 + n needs xi at t0 - 7 + n + tap) ---------------------------------------------------
         {
