@@ -449,9 +449,9 @@ int launch48(tvc_ctx* ctx, hipStream_t s, Conv48Args a, int B) {
 // the first conv's epilogue with an exact per-tile power-of-two pre-scale (the tile's |max| meets in LDS behind the barrier
 // between the two convs); replicate padding of h at the utterance ends = a column clamp when the second conv reads it.
 struct Conv48PArgs {
-    const float* x;        // planar [B][48][len], or (LERP) the low-rate tensor [B][48][lin]
+    const float* x;        // planar [B][48][len], or (LERP) the low-rate level output in the G8 layout [B][6][lin][8]
     const float* cond;     // FILM: G8 [B][6][len][8] (Conv48Args)
-    const float* res;      // RES 2: low-rate planar [B][48][rlin], interpolated here
+    const float* res;      // RES 2: the low-rate level output again (G8), interpolated here
     float* out;            // FILM: G8 (Upsample 3's x1); else planar [B][48][len]
     const u32x4* Aa;       // first / second conv image, 36 pieces each
     const u32x4* Ab;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
         const int len = rt.len, lin = LERP ? len / xf : len;
         const int px0 = rt.tin * BNO - db - da;
-        const float* xb = RAG ? a.x + (LERP ? rt.off / xf : rt.off) : a.x + (long)rt.b * C * rsl;
+        const float* xb = RAG ? a.x + (LERP ? 8L * (rt.off / xf) : rt.off) : a.x + (long)rt.b * C * rsl;      // LERP: the low-rate level output, G8 (EpiBiasG8)
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
             const int g = ig[i] > 5 ? 5 : ig[i];
@@ -530,12 +530,8 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
             if (LERP) {
                 const Lerp lc = lerp_coord(p, a.lscale, lin);
                 lam[i] = lc.w1;
-                const unsigned o0 = 4u * (unsigned)(8 * g * rsl + lc.i0), o1 = 4u * (unsigned)(8 * g * rsl + lc.i1);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    xr0[i][j] = ldg_so(xb + (long)j * rsl, o0);
-                    xr1[i][j] = ldg_so(xb + (long)j * rsl, o1);
-                }
+                ld8_g8(xr0[i], xb, 32u * (unsigned)(g * rsl + lc.i0));
+                ld8_g8(xr1[i], xb, 32u * (unsigned)(g * rsl + lc.i1));
             } else {
                 const unsigned o = 4u * (unsigned)(8 * g * rsl + p);
 #pragma unroll
@@ -597,21 +593,20 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
             for (int s = 0; s < 3; ++s) ld8_g8(cr[s], cb + (long)s * 16 * rs, oc);
         }
         float rv[RES ? 4 : 1][4];
-        if (RES == 2) {
-            const float* rb = RAG ? a.res + rt.off / rf : a.res + (long)b * C * a.rlin;
+        if (RES == 2) {      // the interpolated residual: the low-rate level output again (G8)
+            const float* rb = RAG ? a.res + 8L * (rt.off / rf) : a.res + (long)b * C * a.rlin;
             const Lerp lc = lerp_coord(tc, a.rscale, RAG ? len / rf : a.rlin);
-            const unsigned o0 = 4u * (unsigned)((32 * mt + 4 * lh) * a.rlin + lc.i0), o1 = 4u * (unsigned)((32 * mt + 4 * lh) * a.rlin + lc.i1);
+            const unsigned o0 = 32u * (unsigned)(4 * mt * a.rlin + lc.i0) + 16u * (unsigned)lh, o1 = 32u * (unsigned)(4 * mt * a.rlin + lc.i1) + 16u * (unsigned)lh;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float x0 = 0.f, x1 = 0.f;
-                    if (32 * mt + 8 * g < C) {
-                        x0 = ldg_so(rb + (long)(8 * g + q) * a.rlin, o0);
-                        x1 = ldg_so(rb + (long)(8 * g + q) * a.rlin, o1);
-                    }
-                    rv[g][q] = fmaf(lc.w0, x0, __fmul_rn(lc.w1, x1));      // = lerp_eval
+            for (int g = 0; g < 4; ++g) {
+                float x0[4] = {0.f, 0.f, 0.f, 0.f}, x1[4] = {0.f, 0.f, 0.f, 0.f};
+                if (32 * mt + 8 * g < C) {
+                    ld4_g8(x0, rb + (long)g * 8 * a.rlin, o0);
+                    ld4_g8(x1, rb + (long)g * 8 * a.rlin, o1);
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rv[g][q] = fmaf(lc.w0, x0[q], __fmul_rn(lc.w1, x1[q]));      // = lerp_eval
+            }
         }
 
         // ---- first conv: h column n (position t0 - db + n) from Xs columns n + tap * da -------------------------------------
@@ -838,10 +833,9 @@ int run_conv48s(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, i
     a.fsc = film ? film->wscale : nullptr;
     a.amax_x = amax_x; a.amax_c = amax_c; a.amax_y = amax_y;
     a.len = len; a.dil = dil; a.lin = lin; a.rlin = rlin; a.lscale = lscale; a.rscale = rscale;
-    if (lin > 0) {
-        if (film || res) return fail(ctx, TVC_ERR_ARG, "conv48s: the interpolating variant is a plain conv");
-        return launch48<false, true, 0>(ctx, s, a, B);
-    }
+    // (the level's tensors are in the G8 layout; the interpolating input / residual variants of this kernel read planar low-rate tensors and
+    // are not launched any more: the first half of Upsample 3 is run_conv48_pair)
+    if (lin > 0 || rlin > 0) return fail(ctx, TVC_ERR_ARG, "conv48s: interpolated inputs / residuals go through run_conv48_pair");
     if (film) {
         if (!res) return fail(ctx, TVC_ERR_ARG, "conv48s: the FiLM variants carry a residual");
         if (c5) {   // FiLM2 + residual + c5: only c5's 24 rows leave the CU
@@ -853,7 +847,7 @@ int run_conv48s(tvc_ctx* ctx, hipStream_t s, const PackedW& w, const float* x, i
             a.out5 = out5;
             return launch48<true, false, 1, true>(ctx, s, a, B);
         }
-        return rlin > 0 ? launch48<true, false, 2>(ctx, s, a, B) : launch48<true, false, 1>(ctx, s, a, B);
+        return launch48<true, false, 1>(ctx, s, a, B);
     }
     if (res) return fail(ctx, TVC_ERR_ARG, "conv48s: plain convs carry no residual");
     return launch48<false, false, 0>(ctx, s, a, B);

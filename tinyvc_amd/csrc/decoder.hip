@@ -490,7 +490,10 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
             }
             if (C != 48) {   // c5 (1x1, C -> C/2) as a split-precision GEMM launch; its output's |max| slot = the bound c5_bw |xu|max + c5_bb (the functor finishes the elements)
                 EpiBias<ACT_NONE, false> ep{xlev[i], u.c5.bias, nullptr, u.cout, lo, nc, (long)u.cout * lo, 0};
-                if (u.c5.MT6 % 3 == 0) TVC_CHECK((gemm_s_launch<3, 4, 1>(ctx, s, u.c5, xu, B, C, lo, 0, ep, slot(S_UXU + i))));
+                if (u.cout == 48) {   // the 48-channel level output: G8 layout (conv48s.hip's interpolating launch reads 16-byte rows)
+                    EpiBiasG8 eg{xlev[i], u.c5.bias, u.cout, lo, nc};
+                    TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, u.c5, xu, B, C, lo, 0, eg, slot(S_UXU + i))));
+                } else if (u.c5.MT6 % 3 == 0) TVC_CHECK((gemm_s_launch<3, 4, 1>(ctx, s, u.c5, xu, B, C, lo, 0, ep, slot(S_UXU + i))));
                 else TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, u.c5, xu, B, C, lo, 0, ep, slot(S_UXU + i))));
                 TVC_CHECK(run_slot_affine(ctx, s, slot(S_LEV + i), slot(S_UXU + i), 1, u.c5_bw, u.c5_bb, NB));      // bound of the 1x1's output from its input's slot
             }
@@ -508,8 +511,8 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
         long l = T;
         for (int i = 0; i < 4; ++i) {
             l *= ctx->ups[i].factor;
-            if (taps->ups[i] && ctx->ups[i].cout == 24)      // the 24-channel level travels in the fused ups.4 kernels' G8 layout [B][3][l][8]: back to [B][24][l] for the tap
-                hipLaunchKernelGGL(g8_to_planar_kernel, dim3(grid_for((long)B * 24 * l)), dim3(256), 0, s, xlev[i], taps->ups[i], (long)B, l, 24);
+            if (taps->ups[i] && ctx->ups[i].cout <= 48)      // the 48- and 24-channel levels travel in the fused kernels' G8 layout [B][C / 8][l][8]: back to [B][C][l] for the tap
+                hipLaunchKernelGGL(g8_to_planar_kernel, dim3(grid_for((long)B * ctx->ups[i].cout * l)), dim3(256), 0, s, xlev[i], taps->ups[i], (long)B, l, ctx->ups[i].cout);
             else if (taps->ups[i])
                 TVC_HIP(ctx, hipMemcpyAsync(taps->ups[i], xlev[i], (size_t)B * ctx->ups[i].cout * l * sizeof(float), hipMemcpyDeviceToDevice, s));
         }

@@ -92,6 +92,22 @@ struct EpiBias {
     }
 };
 
+// y = acc + bias in the G8 layout [B][M / 8][T][8 channels] (the 48-channel level output conv48s.hip interpolates from: four consecutive
+// rows of one column are 16 contiguous bytes, one store).  m is a multiple of 4; M a multiple of 8.
+struct EpiBiasG8 {
+    static constexpr bool kIgemm = true;
+    float* y;
+    const float* bias;
+    int M, T, ncols;
+    __device__ __forceinline__ void store(int n, int m, const float v[4]) const {
+        if (n >= ncols || m >= M) return;
+        const int b = n / T, t = n - b * T;
+        typedef float f32x4e __attribute__((ext_vector_type(4)));
+        const f32x4e o = {v[0] + bias[m], v[1] + bias[m + 1], v[2] + bias[m + 2], v[3] + bias[m + 3]};
+        *reinterpret_cast<f32x4e*>(y + (((long)b * (M >> 3) + (m >> 3)) * T + t) * 8 + (m & 7)) = o;
+    }
+};
+
 // content_in(content) + energy_in(e) + f0_in(log(relu(f0)+1e-6))   (decoder.py:128, :223)
 // e / lf0 are per-(b,t) scalars feeding 1->M 1x1 convs; `e` may be null (FilterNet has no energy).
 struct EpiSumCond {
