@@ -138,6 +138,17 @@ __device__ __forceinline__ Bfp bfp_from_amax(float amax) {
     return r;
 }
 __device__ __forceinline__ Bfp bfp_load(const float* amax, int b) { return amax ? bfp_from_amax(amax[b]) : Bfp{1.f, 1.f}; }
+// A slot read through the SCALAR cache (the address must be wave-uniform).  The persistent fused kernels read their utterance's slots at
+// the top of every tile; as a vector load (the compiler cannot prove a global store does not alias them) each read was followed by
+// `s_waitcnt vmcnt(0)` - i.e. every tile began by waiting for ALL of the previous tile's stores to be acknowledged (cycle stamps,
+// tools/micro/u24_trace.py: 2-3 k of a 13 k-cycle tile).  Slots are written by EARLIER launches (caches are invalidated at launch boundaries),
+// so the scalar path is coherent; it counts on lgkmcnt and leaves the store queue alone.
+__device__ __forceinline__ float sload_f32(const float* p) {
+    float v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ Bfp bfp_load_u(const float* amax, int b) { return amax ? bfp_from_amax(sload_f32(amax + b)) : Bfp{1.f, 1.f}; }
 // the smaller of two scales (two tensors accumulated into one tile share it)
 __device__ __forceinline__ Bfp bfp_min(const Bfp& a, const Bfp& b) { return a.s < b.s ? a : b; }
 // Publishing a |max| slot.  Same-address device-scope atomics complete at ~3 per microsecond on this part (measured: one

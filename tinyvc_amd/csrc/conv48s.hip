@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
     if (tile >= tend) return;
     bh = utt(tile);
     fetch(tile);
-    deposit(bfp_load(a.amax_x, bh).s);
+    deposit(bfp_load_u(a.amax_x, bh).s);
     if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
     float mx_run = 0.f;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
             mx_run = 0.f;
             mx_b = b;
         }
-        const Bfp sx = bfp_load(a.amax_x, b), sc = FILM ? bfp_load(a.amax_c, b) : Bfp{1.f, 1.f};
+        const Bfp sx = bfp_load_u(a.amax_x, b), sc = FILM ? bfp_load_u(a.amax_c, b) : Bfp{1.f, 1.f};
         const int t0 = rt.tin * BN;
         const int next = tile + 1;
         const int n = nt * 32 + l31;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
         // ---- next tile's input: registers -> LDS, then request the one after --------------------------------
         slab_barrier();                                   // every wave is done reading Xs
         if (next < tend) {
-            deposit(bfp_load(a.amax_x, utt(next)).s);
+            deposit(bfp_load_u(a.amax_x, utt(next)).s);
             if (next + 1 < tend) fetch(next + 1);
         }
         slab_barrier();
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
     if (tile >= tend) return;
     bh = utt(tile);
     fetch(tile);
-    deposit(bfp_load(a.amax_x, bh).s);
+    deposit(bfp_load_u(a.amax_x, bh).s);
     if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
     float mx_run = 0.f;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
             mx_run = 0.f;
             mx_b = b;
         }
-        const Bfp sx = bfp_load(a.amax_x, b), sc = FILM ? bfp_load(a.amax_c, b) : Bfp{1.f, 1.f};
+        const Bfp sx = bfp_load_u(a.amax_x, b), sc = FILM ? bfp_load_u(a.amax_c, b) : Bfp{1.f, 1.f};
         const int t0 = rt.tin * BNO;
         const int next = tile + 1;
         const int n = nt * 32 + l31;                       // this lane's column: of h in the first conv, of the output in the second
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         // ---- next tile's input: registers -> LDS, then request the one after ------------------------------------------------
         slab_barrier();                                   // every wave is done reading Xs and Hs
         if (next < tend) {
-            deposit(bfp_load(a.amax_x, utt(next)).s);
+            deposit(bfp_load_u(a.amax_x, utt(next)).s);
             if (next + 1 < tend) fetch(next + 1);
         }
         slab_barrier();

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     if (tile < tend) {
         bh = utt(tile);
         fetch(tile);
-        deposit(bfp_load(a.amax_x, bh).s);
+        deposit(bfp_load_u(a.amax_x, bh).s);
     }
     slab_barrier();
     const float wsa = Fl[297], wsb = Fl[298], wssc = Fl[299], wssh = Fl[300], wl1 = Fl[301], bamax = Fl[302];
@@ -277,9 +277,9 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         }
         // block-floating-point scales: input (per-utterance |max| slot), cond, and the on-chip intermediate h = lrelu(conv_a + b_a),
         // bounded by sum|w_a| * amax_x + max|b_a| (never measured: it does not leave the CU)
-        const Bfp sx = bfp_load(a.amax_x, b);
-        const Bfp sc = a.amax_c ? norm_from_amax(fmaf(a.cbw, a.amax_c[b], a.cbb)) : Bfp{1.f, 1.f};      // the scale down0s_kernel wrote the planes with
-        const Bfp sh_ = a.amax_x ? bfp_from_amax(fmaf(wl1, a.amax_x[b], bamax)) : Bfp{1.f, 1.f};
+        const Bfp sx = bfp_load_u(a.amax_x, b);
+        const Bfp sc = a.amax_c ? norm_from_amax(fmaf(a.cbw, sload_f32(a.amax_c + b), a.cbb)) : Bfp{1.f, 1.f};      // the scale down0s_kernel wrote the planes with
+        const Bfp sh_ = a.amax_x ? bfp_from_amax(fmaf(wl1, sload_f32(a.amax_x + b), bamax)) : Bfp{1.f, 1.f};
         const int t0 = rt.tin * W;
         const int ph0 = t0 - E - D2;      // position of Hs column 0
         const int p20 = t0 - E;           // position of second-conv column 0
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         U24_STAMP(6);
         slab_barrier();                                   // every wave is done with Xs, Hs and R
         U24_STAMP(7);
-        if (next < tend) deposit(bfp_load(a.amax_x, utt(next)).s);
+        if (next < tend) deposit(bfp_load_u(a.amax_x, utt(next)).s);
         U24_STAMP(8);
         slab_barrier();
     }
@@ -621,7 +621,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
     if (tile >= tend) return;
     bh = utt(tile);
     fetch(tile);
-    deposit(0, bfp_load(a.amax_x, bh).s);
+    deposit(0, bfp_load_u(a.amax_x, bh).s);
     if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
     const int len2 = rs / 5;             // row stride of the 1/5-rate copy
@@ -639,7 +639,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
         }
         const int t0 = rt.tin * W;
         const int next = tile + 1, next2 = next + 1;
-        if (next < tend) deposit(cur ^ 1, bfp_load(a.amax_x, utt(next)).s);            // tile i + 1 (requested one tile ago) -> the other buffer
+        if (next < tend) deposit(cur ^ 1, bfp_load_u(a.amax_x, utt(next)).s);            // tile i + 1 (requested one tile ago) -> the other buffer
         if (next2 < tend) fetch(next2);               // tile i + 2 flies across this tile
         f32x16 acc, alo;
 #pragma unroll
@@ -648,9 +648,9 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
         conv24_phase<XP, 1>(acc, alo, Xs + cur * 6 * XP, Wt, n, 0, XW - 1, lane);
         // the planes' scale 2^k (up24s_kernel undoes it) rides in the epilogue's constants: (acc c + lo cl + bias) 2^k is formed as
         // acc (c 2^k) + lo (cl 2^k) + bias 2^k - powers of two, the same bits - and the fp32 values the tap / the 1/5-rate copy / the |max| want are vs 2^-k
-        const Bfp pn = a.amax_x ? norm_from_amax(fmaf(Bi[29], a.amax_x[b], Bi[30])) : Bfp{1.f, 1.f};
+        const Bfp pn = a.amax_x ? norm_from_amax(fmaf(Bi[29], sload_f32(a.amax_x + b), Bi[30])) : Bfp{1.f, 1.f};
         const float ps = pn.s, pinv = pn.inv;
-        const float cc = cw * bfp_load(a.amax_x, b).inv * ps, ccl = cc * kLoInv;
+        const float cc = cw * bfp_load_u(a.amax_x, b).inv * ps, ccl = cc * kLoInv;
         const int t = t0 + n;
         float mx = 0.f;
         {
@@ -820,9 +820,9 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
     };
     auto scales = [&](int b) __attribute__((always_inline)) -> Sc {
         Sc r;
-        r.x = bfp_load(a.amax_x, b);
+        r.x = bfp_load_u(a.amax_x, b);
         if (a.amax_x) {
-            const float bound1 = fmaf(a.b1_w, a.amax_x[b], a.b1_b);
+            const float bound1 = fmaf(a.b1_w, sload_f32(a.amax_x + b), a.b1_b);
             r.h1 = bfp_from_amax(bound1);
             r.hj = bfp_min(bfp_from_amax(fmaf(a.b2_w, bound1, a.b2_b)), r.x);
         } else {
@@ -856,7 +856,7 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
     if (tile >= tend) return;
     bh = utt(tile);
     fetch(tile);
-    deposit(0, bfp_load(a.amax_x, bh).s);
+    deposit(0, bfp_load_u(a.amax_x, bh).s);
     if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
     const int len2 = rs >> 2;            // row stride of the 1/4-rate copy
@@ -873,7 +873,7 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
         }
         const int t0 = rt.tin * W;
         const int next = tile + 1, next2 = next + 1;
-        if (next < tend) deposit(cur ^ 1, bfp_load(a.amax_x, utt(next)).s);   // tile i + 1 (requested one tile ago) -> the other buffer
+        if (next < tend) deposit(cur ^ 1, bfp_load_u(a.amax_x, utt(next)).s);   // tile i + 1 (requested one tile ago) -> the other buffer
         if (next2 < tend) fetch(next2);                        // tile i + 2 flies across this tile
         const Sc sc = scales(b);
         const int n = wave * 32 + l31;                         // this lane's column of every conv's tile
