@@ -941,7 +941,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         }
         const int rl = wm * WM * 32 + 4 * lh;                     // local row of accumulator register r of m-tile i: rl + 32 i + (r & 3) + 8 (r >> 2)
         // block-floating-point scales of this tile's inputs (identity unless an utterance's |max| leaves the fp16 window)
-        const Bfp sx = (fT || RAGG) ? Bfp{1.f, 1.f} : bfp_load(a.amax_x, b);      // flat GEMM tiles: per column (make_map / the epilogue below)
+        const Bfp sx = (fT || RAGG) ? Bfp{1.f, 1.f} : bfp_load_u(a.amax_x, b);      // flat GEMM tiles: per column (make_map / the epilogue below)
         f32x16 hi[WM][WN], lo[WM][WN];
         auto clear = [&](f32x16 (&u)[WM][WN]) __attribute__((always_inline)) {
 #pragma unroll
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             // tile is staged twice; in exchange the conv phase (3/5 of the MFMAs) runs on the 96 x 256 tile of the plain convs.
             const float* cb = a.cond + (long)b * a.Ccond * len;
             const int mtoff = a.MT;
-            const Bfp sc = bfp_load(a.amax_c, b);
+            const Bfp sc = bfp_load_u(a.amax_c, b);
             split_phase<TL, TAPS, A_U4, LRELU, S_FB_FW, false, LERP, false>(      // only one accumulator pair is live here: two fragment sets fit
                 hi, lo, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,
                 [&]() __attribute__((always_inline)) { first_load<TL, 1>(regs, a.sc6, 2 * a.MT, mt0, cb, a.Ccond, len, 0, t0); }, sx.s, nullptr, 0, 0u, 0, a.lin, a.lscale);
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
             // the cond tile on the same output tiles; (conv, scale, shift) combine in registers.
             const float* cb = RAGT ? a.cond + coloff : a.cond + (long)b * a.Ccond * len;
             const int mtoff = a.MT;                                   // the stacked FiLM image has 2 * a.MT m-tiles: scale rows, then shift rows
-            const Bfp sc = bfp_load(a.amax_c, b);
+            const Bfp sc = bfp_load_u(a.amax_c, b);
             f32x16 asc[WM][WN], lsc[WM][WN], ash[WM][WN], lsh[WM][WN];
             clear(asc);
             clear(lsc);
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
                 // One accumulator pair, one unit: the two images are packed with JOINT per-m-tile scales (api.hip) and the two
                 // inputs share the smaller of their block-floating-point scales.
                 const float* cb = RAGT ? a.cond + coloff : a.cond + (long)b * a.Ccond * len;
-                const Bfp s2 = bfp_min(sx, bfp_load(a.amax_c, b));
+                const Bfp s2 = bfp_min(sx, bfp_load_u(a.amax_c, b));
                 inv = s2.inv;
                 split_phase<TL, TAPS, A_U4, LRELU, S_FB, false, false, false>(
                     hi, lo, regs, a.A6, a.MT, mt0, xb, a.Cin, len, a.dil, t0, As, Xs,

@@ -36,7 +36,7 @@ struct ConvS2Args {
 };
 // |conv + bias| <= (max_m sum_k |w|) |x|max + max |b|: the bound the producer normalises its pre-split output by and the consumer undoes
 // (amax = the per-utterance |max| slot of the producer's INPUT; non-null for these launches)
-__device__ __forceinline__ float presplit_bound(float pre_w, float pre_b, const float* amax, int b) { return fmaf(pre_w, amax[b], pre_b); }
+__device__ __forceinline__ float presplit_bound(float pre_w, float pre_b, const float* amax, int b) { return fmaf(pre_w, sload_f32(amax + b), pre_b); }      // (b wave-uniform: scalar cache, conv3s.h)
 // power of two that brings |max| into [2^14, 2^15) (1 for zero, Inf, NaN: they carry no information)
 __device__ __forceinline__ Bfp norm_from_amax(float amax) {
     const unsigned u = __builtin_bit_cast(unsigned, amax);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
         } else {
             xo = (unsigned)(cbase + p);
         }
-        xsc = bfp_load(a.amax_x, lb).s;
+        xsc = bfp_load_u(a.amax_x, lb).s;
     };
     tile_offsets();
     auto issue_load = [&]() __attribute__((always_inline)) {     // global -> registers only; the values are not touched here
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(CS2::NTHR) __attribute__((amdgpu_waves_per_eu(3))) 
         advance_load();           // (behind the MFMAs: the slab body above is one basic block)
         if (++cs == nslab) {
             // epilogue straight from the accumulators: bias, store, running |max|
-            const Bfp sx = bfp_load(a.amax_x, cb);
+            const Bfp sx = bfp_load_u(a.amax_x, cb);
             const int row0 = (cmt0 + wm) * 32;
             float* yb = RAG ? a.y + (long)row0 * rs + coff : a.y + ((long)cb * a.M + row0) * rs;
             const float ps = PRE ? norm_from_amax(presplit_bound(a.pre_w, a.pre_b, a.amax_x, cb)).s : 1.f;

@@ -136,8 +136,8 @@ __global__ __launch_bounds__(FS2T<NWV_>::NTHR) __attribute__((amdgpu_waves_per_e
         int pc = lt0 + cc;
         pc = pc > llen - 1 ? llen - 1 : pc;
         co = (unsigned)(8 * cg * rs + ub + pc);
-        xs = XPRE ? 1.f : norm_from_amax(a.amax_x[lb]).s;
-        cs_ = norm_from_amax(a.amax_c[lb]).s;
+        xs = XPRE ? 1.f : norm_from_amax(sload_f32(a.amax_x + lb)).s;
+        cs_ = norm_from_amax(sload_f32(a.amax_c + lb)).s;
     };
     tile_offsets();
     auto issue_load = [&]() __attribute__((always_inline)) {
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(FS2T<NWV_>::NTHR) __attribute__((amdgpu_waves_per_e
             int el = lane;
             asm volatile("" : "+v"(el));
             const int e31 = el & 31, eh = el >> 5;
-            const float ix = norm_from_amax(XPRE ? presplit_bound(a.pre_w, a.pre_b, a.amax_x, cb) : a.amax_x[cb]).inv, ic_ = norm_from_amax(a.amax_c[cb]).inv;
+            const float ix = norm_from_amax(XPRE ? presplit_bound(a.pre_w, a.pre_b, a.amax_x, cb) : sload_f32(a.amax_x + cb)).inv, ic_ = norm_from_amax(sload_f32(a.amax_c + cb)).inv;
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
             const int row0 = (cmb * MTB + wm * WM + i) * 32;
