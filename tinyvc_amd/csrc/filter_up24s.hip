@@ -264,6 +264,8 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     const float wsa = Fl[297], wsb = Fl[298], wssc = Fl[299], wssh = Fl[300], wl1 = Fl[301], bamax = Fl[302];
     float mx_run = 0.f;
     int mx_b = bh;
+    int slot_b = -1;
+    float slot_x = 0.f, slot_c = 0.f;
 
     for (; tile < tend; ++tile) {
         U24_STAMP(0);
@@ -277,9 +279,14 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         }
         // block-floating-point scales: input (per-utterance |max| slot), cond, and the on-chip intermediate h = lrelu(conv_a + b_a),
         // bounded by sum|w_a| * amax_x + max|b_a| (never measured: it does not leave the CU)
-        const Bfp sx = bfp_load_u(a.amax_x, b);
-        const Bfp sc = a.amax_c ? norm_from_amax(fmaf(a.cbw, sload_f32(a.amax_c + b), a.cbb)) : Bfp{1.f, 1.f};      // the scale down0s_kernel wrote the planes with
-        const Bfp sh_ = a.amax_x ? bfp_from_amax(fmaf(wl1, sload_f32(a.amax_x + b), bamax)) : Bfp{1.f, 1.f};
+        if (b != slot_b) {      // the utterance's slots: read when the walk enters it (one or two utterances per workgroup), not per tile
+            slot_b = b;
+            slot_x = a.amax_x ? sload_f32(a.amax_x + b) : 0.f;
+            slot_c = a.amax_c ? sload_f32(a.amax_c + b) : 0.f;
+        }
+        const Bfp sx = a.amax_x ? bfp_from_amax(slot_x) : Bfp{1.f, 1.f};
+        const Bfp sc = a.amax_c ? norm_from_amax(fmaf(a.cbw, slot_c, a.cbb)) : Bfp{1.f, 1.f};      // the scale down0s_kernel wrote the planes with
+        const Bfp sh_ = a.amax_x ? bfp_from_amax(fmaf(wl1, slot_x, bamax)) : Bfp{1.f, 1.f};
         const int t0 = rt.tin * W;
         const int ph0 = t0 - E - D2;      // position of Hs column 0
         const int p20 = t0 - E;           // position of second-conv column 0
@@ -472,7 +479,10 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         U24_STAMP(6);
         slab_barrier();                                   // every wave is done with Xs, Hs and R
         U24_STAMP(7);
-        if (next < tend) deposit(bfp_load_u(a.amax_x, utt(next)).s);
+        if (next < tend) {
+            const int bn = utt(next);
+            deposit(bn == slot_b ? sx.s : bfp_load_u(a.amax_x, bn).s);
+        }
         U24_STAMP(8);
         slab_barrier();
     }
