@@ -294,6 +294,14 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
 
         // FiLM cond of this wave's second-conv tile: the producer left it split, scaled and in B-fragment order - K16 step 0 = channel
         // group lh, step 1 = group 2 for lh = 0 (the other half is the zero unit): four 16-byte loads, no arithmetic
+        // The tile's global stores are issued BEHIND the next tile's deposit: the deposit waits for its fetched registers with vmcnt(0) (its stores
+        // sit in exec-masked blocks, the counter cannot be exact), and stores issued before it made every tile wait for their acknowledgement.
+        float keep[3][4];
+        bool keep_live = false;
+        unsigned keep_oo = 0;
+        float wv_out = 0.f;
+        bool wv_live = false;
+        int wv_off = 0;
         u32x4 cq[2][2];
         if (wave < CF::NT2) {
             const uint4* cb = RAG ? a.cond + rt.off : a.cond + (long)b * 6 * rs;
@@ -389,8 +397,6 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 lsc = TVC_MFMA16(fa[0][0], cf[s][1], lsc);
                 lsh = TVC_MFMA16(fa[1][0], cf[s][1], lsh);
             }
-            float* ob = CF::SECOND ? nullptr : (RAG ? a.out + 8L * rt.off : a.out + (long)b * C * rs);      // x1 in the G8 layout: this lane's four channels of group g = 16 bytes
-            const unsigned oo = 32u * (unsigned)t + 16u * (unsigned)lh;
             float mx = 0.f;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
@@ -408,18 +414,15 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                     v4[q] = v;
                     if (CF::SECOND) R[m * PS + n] = v;                         // x2 stays on chip
                 }
-                if (!CF::SECOND && n < W && t < len) {
-#ifdef X1_PLANAR
-                    float* obp = RAG ? a.out + rt.off : a.out + (long)b * C * rs;
+                if (!CF::SECOND) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) stg_so(obp + (long)(8 * g + q) * rs, 4u * (unsigned)(4 * lh * rs + t), v4[q]);
-#else
-                    stg_so4(ob + (long)g * 8 * rs, oo, v4);                    // x1 (uniform group base + lane offset)
-#endif
-                    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v4[0]), fabsf(v4[1])), fmaxf(fabsf(v4[2]), fabsf(v4[3]))));
+                    for (int q = 0; q < 4; ++q) keep[g][q] = v4[q];           // x1 leaves behind the deposit (below)
+                    if (n < W && t < len) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v4[0]), fabsf(v4[1])), fmaxf(fabsf(v4[2]), fabsf(v4[3]))));
                 }
             }
             mx_run = fmaxf(mx_run, mx);
+            keep_live = !CF::SECOND && n < W && t < len;
+            keep_oo = 32u * (unsigned)t + 16u * (unsigned)lh;
         }
         U24_STAMP(4);
         if (CF::SECOND) {
@@ -471,8 +474,10 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 }
                 const int o = 4 * g + part;                  // lanes 0..3 of a group store outputs 4g..4g+3
                 const float v = part == 0 ? o4[0] : (part == 1 ? o4[1] : (part == 2 ? o4[2] : o4[3]));
-                float* wrow = RAG ? a.out + (long)a.rag.row[b] * a.rag.Tmax * kHop : a.out + (long)b * rs;
-                if (part < 4 && o < W && t0 + o < len) wrow[t0 + o] = v + W7[168];
+                static_assert((W + 3) / 4 <= NT / 8, "one output per thread: it waits in a register until the deposit is through");
+                wv_out = v + W7[168];
+                wv_live = part < 4 && o < W && t0 + o < len;
+                wv_off = t0 + o;
             }
         }
         // ---- next tile's input: registers -> LDS ----------------------------------------------------------
@@ -482,6 +487,14 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         if (next < tend) {
             const int bn = utt(next);
             deposit(bn == slot_b ? sx.s : bfp_load_u(a.amax_x, bn).s);
+        }
+        if (CF::SECOND) {
+            float* wrow = RAG ? a.out + (long)a.rag.row[b] * a.rag.Tmax * kHop : a.out + (long)b * rs;
+            if (wv_live) wrow[wv_off] = wv_out;
+        } else if (keep_live) {
+            float* ob = RAG ? a.out + 8L * rt.off : a.out + (long)b * C * rs;      // x1 in the G8 layout: this lane's four channels of group g = 16 bytes
+#pragma unroll
+            for (int g = 0; g < 3; ++g) stg_so4(ob + (long)g * 8 * rs, keep_oo, keep[g]);
         }
         U24_STAMP(8);
         slab_barrier();
