@@ -157,31 +157,6 @@ static __global__ __launch_bounds__(256) void harm_synth_kernel(const float* __r
 // window iSTFT (n_fft 1920, hop 480).  The per-frame c2r transform is a wave-level inverse FFT (fft.hip:
 // run_noise_ifft); overlap-add divides by the frame-count envelope and trims 960 samples per side.
 // =================================================================================================
-// counter-based uniform phases when the caller gives no `noise_angle`: the phase of (utterance row, bin, frame) is a hash of the call's
-// seed and of those three numbers alone - whatever else is in the batch and however a ragged call is cut into in-kernel batches.
-// Layout = the kernel tensor's: [B][961][T], or (ragged batch, ragged.h) [961][T] over the whole batch.
-static __global__ void angle_fill_kernel(float* __restrict__ angle, int B, int T, uint64_t seed, RagDev rg) {
-    const long n = (long)B * kBins * T;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int t = (int)(i % T);
-        const long bk = i / T;
-        int k = (int)(bk % kBins), row = (int)(bk / kBins), tl = t;
-        if (rg.tb) {
-            const int b = rg.col2b[t];
-            row = rg.row[b];
-            tl = t - rg.pre[b];
-        }
-        uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)row + 1);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z += 0x9E3779B97F4A7C15ull * (((uint64_t)k << 32) + (uint64_t)tl + 1);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z ^= z >> 31;
-        float u = (float)(z >> 40) * (1.0f / 16777216.0f);  // [0, 1)
-        angle[i] = u * 6.2831854820251465f - 3.1415927410125732f;
-    }
-}
-
 // grid (x, B): blockIdx.y = utterance; smax[b] = per-utterance |max| slot of `source` (block-floating-point guard of
 // FilterNet's first conv, conv3s.h): one atomic per workgroup
 static __global__ __launch_bounds__(256) void noise_ola_kernel(const float* __restrict__ frames, float* __restrict__ source, int B, int T, float* __restrict__ smax, RagDev rg) {
@@ -250,7 +225,6 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
     const long L = (long)T * kHop;
     double* csum = ws.get<double>((size_t)B * kHarm * T);
     float* frames = ws.get<float>((size_t)B * T * kNfft);
-    float* ang = angle ? nullptr : ws.get<float>((size_t)B * kBins * T);
     const int NB = ctx->rag ? ctx->rag->B : B;
     const int Tg = ctx->rag ? ctx->rag->Tlong : T;      // frames of the longest utterance: the per-utterance grids' extent
     float* smax_own = smax ? nullptr : ws.get<float>((size_t)NB);
@@ -270,13 +244,9 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
     // the 15 harmonic rows are sin(.) * voiced gate * interpolated amps: bounded by the amplitudes' own |max| (3 000 values per utterance)
     TVC_CHECK(run_amax_rows(ctx, s, amps, B, kHarm, T, smax));
     // noise -> source[:, 15]: kernel * exp(i angle) -> inverse 1920-point FFT per frame (fft.hip) -> overlap-add
-    if (!angle) {
-        RagDev rga;
-        TVC_CHECK(rag_view(ctx, s, 1, 0, &rga, nullptr));
-        hipLaunchKernelGGL(angle_fill_kernel, dim3(grid_for((long)B * kBins * T)), dim3(256), 0, s, ang, B, T, seed, rga);
-        angle = ang;
-    }
-    TVC_CHECK(run_noise_ifft(ctx, s, kern, angle, frames, B, T, ctx->rag && angle != ang));
+    // (angle == nullptr: the kernel draws the phases itself while it stages the tile - small_kernels.h noise_phase_hash(seed, row, bin, frame) -,
+    // no [B][961][T] phase tensor is written or read)
+    TVC_CHECK(run_noise_ifft(ctx, s, kern, angle, seed, frames, B, T, ctx->rag && angle));
     hipLaunchKernelGGL(noise_ola_kernel, dim3(grid_for((long)Tg * kHop / 4, 256, NB >= 32 ? 16 : 512 / NB), NB), dim3(256), 0, s, frames, source, B, T, smax, rg);
     return launch_check(ctx, "dsp");
 }

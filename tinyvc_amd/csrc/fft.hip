@@ -185,8 +185,11 @@ __global__ __launch_bounds__(kFW * 64) void stft_fft_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------------------------------
 // frames[(b T + t)][n] = irfft_1920(kernel[b][:, t] * exp(i angle[b][:, t]))[n]  (torch.fft.irfft semantics: 1/N, the
 // imaginary parts of bins 0 and 960 do not enter)
+// angle == nullptr: the phases are the library's own draw, noise_phase_hash(seed, utterance row, bin, frame) (small_kernels.h), evaluated here
+template <bool DRAW>
 __global__ __launch_bounds__(kFW * 64) void noise_ifft_kernel(const float* __restrict__ kern, const float* __restrict__ angle, float* __restrict__ frames,
-                                                              const float2* __restrict__ tw960, const float2* __restrict__ tw1920, int T, RagDev rg) {
+                                                              const float2* __restrict__ tw960, const float2* __restrict__ tw1920, int T, RagDev rg,
+                                                              unsigned long long seed, const int* __restrict__ rowmap) {
     extern __shared__ __attribute__((aligned(16))) float2 smem_f[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int YS = kBins + 1;                                      // row stride (962 float2: rows stay 16-byte aligned)
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(kFW * 64) void noise_ifft_kernel(const float* __res
             const int k = i / kFW;
             int f = i - k * kFW;
             f = f < nf ? f : nf - 1;
-            av[j] = ab[(long)k * as + f];
+            av[j] = DRAW ? noise_phase_hash(seed, rowmap ? rowmap[b] : b, k, t0 + f) : ab[(long)k * as + f];
             kv[j] = kb[(long)k * rs + f];
         }
 #pragma unroll
@@ -294,23 +297,28 @@ int run_stft_fft(tvc_ctx* ctx, hipStream_t s, const float* wav, float* spec, int
 }
 
 // angle_padded (ragged batches only): `angle` is the caller's padded [rows][961][Tmax] tensor, not the batch-wide [961][T] layout
-int run_noise_ifft(tvc_ctx* ctx, hipStream_t s, const float* kern, const float* angle, float* frames, int B, int T, bool angle_padded) {
+int run_noise_ifft(tvc_ctx* ctx, hipStream_t s, const float* kern, const float* angle, uint64_t seed, float* frames, int B, int T, bool angle_padded) {
     if (!ctx->fft_tw960 || !ctx->fft_tw1920) return fail(ctx, TVC_ERR_STATE, "fft tables missing");
     static bool ready_dev[64] = {};
     bool& ready = ready_dev[ctx->device & 63];
     constexpr int lds = kFW * (kBins + 1) * 8;
     if (!ready) {
-        hipError_t e = hipFuncSetAttribute((const void*)noise_ifft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)noise_ifft_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)noise_ifft_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "noise_ifft setup: %s", hipGetErrorString(e));
         ready = true;
     }
     RagDev rg;
     TVC_CHECK(rag_view(ctx, s, 1, 0, &rg, nullptr));
+    const int* rowmap = rg.row;                    // ragged batch: utterance -> row of the call (the hash's row index)
     if (!angle_padded) rg.row = nullptr;
     const int groups = ((ctx->rag ? ctx->rag->Tlong : T) + kFW - 1) / kFW;
     if (ctx->rag) B = ctx->rag->B;
-    hipLaunchKernelGGL(noise_ifft_kernel, dim3((unsigned)(B * groups)), dim3(kFW * 64), lds, s, kern, angle, frames,
-                       reinterpret_cast<const float2*>(ctx->fft_tw960), reinterpret_cast<const float2*>(ctx->fft_tw1920), T, rg);
+    const dim3 grid((unsigned)(B * groups)), blk(kFW * 64);
+    const float2* t960 = reinterpret_cast<const float2*>(ctx->fft_tw960);
+    const float2* t1920 = reinterpret_cast<const float2*>(ctx->fft_tw1920);
+    if (angle) hipLaunchKernelGGL(noise_ifft_kernel<false>, grid, blk, lds, s, kern, angle, frames, t960, t1920, T, rg, 0ull, rowmap);
+    else hipLaunchKernelGGL(noise_ifft_kernel<true>, grid, blk, lds, s, kern, kern, frames, t960, t1920, T, rg, (unsigned long long)seed, rowmap);
     return launch_check(ctx, "noise_ifft");
 }
 

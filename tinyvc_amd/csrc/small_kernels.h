@@ -48,6 +48,19 @@ __device__ __forceinline__ float2 sincos_small(float a) {
     return make_float2((q & 2) ? -vs : vs, ((q + 1) & 2) ? -vc : vc);
 }
 
+// The library's own noise phases (noise_angle = NULL): the phase of (utterance row, bin, frame) is a counter-based hash of the call's seed and
+// of those three numbers alone - whatever else is in the batch and however a ragged call is cut into in-kernel batches -, uniform in [-pi, pi).
+__device__ __forceinline__ float noise_phase_hash(unsigned long long seed, int row, int k, int t) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)row + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z += 0x9E3779B97F4A7C15ull * (((unsigned long long)k << 32) + (unsigned long long)t + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);  // [0, 1)
+    return u * 6.2831854820251465f - 3.1415927410125732f;
+}
+
 // y[row][d] = lerp(x[row][:]) — F.interpolate(mode='linear') on `rows` independent rows.
 // A thread owns 4 consecutive outputs: their source coordinates depend on d only, so they are computed once and
 // reused for every row the thread walks (blockIdx.y strides the rows); outputs leave as one 16-byte store.

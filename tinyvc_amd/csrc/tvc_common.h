@@ -223,7 +223,7 @@ inline int launch_check(tvc_ctx* ctx, const char* what) {
 // ---- stage drivers (each enqueues kernels on `s`; `dry` = measure workspace only) ----------
 int run_stft(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* spec, int B, int64_t L);
 int run_stft_fft(tvc_ctx*, hipStream_t, const float* wav, float* spec, int B, int64_t L);
-int run_noise_ifft(tvc_ctx*, hipStream_t, const float* kern, const float* angle, float* frames, int B, int T, bool angle_padded = false);
+int run_noise_ifft(tvc_ctx*, hipStream_t, const float* kern, const float* angle, uint64_t seed, float* frames, int B, int T, bool angle_padded = false);      // angle == nullptr: phases drawn in the kernel from `seed`
 // emax (optional, equal-length batches only): per-utterance max of the pooled |x| = max |wav| of the utterance, written (not accumulated)
 int run_energy(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* energy, int B, int64_t L, float* emax = nullptr);
 const float* knn_index_amax(const float* prepared);

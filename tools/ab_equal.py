@@ -46,6 +46,8 @@ def dump(path):
         angle = synth.synth_angle(B, T, 31).to(dev)
         y = gen.convert(wf, tgt, 1.0, noise_angle=angle)
         out["wave_B%d_T%d" % (B, T)] = y[:: max(1, B // 8)].cpu().numpy()
+    torch.manual_seed(4321)                      # the library's own phase draw (noise_angle = None): same seed, same hash, same samples
+    out["wave_default_draw"] = gen.convert(synth.synth_wave(3, 480 * 40, seed=9).to(dev), tgt, 0.0).cpu().numpy()
     frames = [33, 7, 50, 200, 3, 129, 21, 64, 12, 250, 65]
     lens = [480 * f - (17 if i % 2 else 0) for i, f in enumerate(frames)]
     Bn, Tmax = len(frames), max(frames)
@@ -55,6 +57,8 @@ def dump(path):
     angle = synth.synth_angle(Bn, Tmax, 31).to(dev)
     y = gen.convert(wf.to(dev), tgt, -1.5, noise_angle=angle, lengths=lens)
     out["wave_ragged"] = y.cpu().numpy()
+    torch.manual_seed(99)
+    out["wave_ragged_default_draw"] = gen.convert(wf.to(dev), tgt, -1.5, lengths=lens).cpu().numpy()
     np.savez(path, **out)
     print("dumped", len(out), "tensors to", path)
 
