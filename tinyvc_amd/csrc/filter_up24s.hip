@@ -108,11 +108,7 @@ __device__ __forceinline__ void conv24_phase(f32x16& hi, f32x16& lo, const u32x4
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             bf[fb][p] = __builtin_bit_cast(f16x8, src[p * 3 * P + row[s]]);
-#ifdef U24_ABL_A
-            if (s == 0) af[0][p] = af[1][p] = __builtin_bit_cast(f16x8, wt[(s * 2 + p) * 64 + lane]);      // what-if: A fragments read once per phase
-#else
             af[fb][p] = __builtin_bit_cast(f16x8, wt[(s * 2 + p) * 64 + lane]);
-#endif
         }
     };
     frags(0, 0);
@@ -190,16 +186,11 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         const int px0 = rt.tin * W - E - H;
         const uint4* xb = reinterpret_cast<const uint4*>(RAG ? a.x + 8L * (CF::SECOND ? rt.off : rt.off / a.xf) : a.x + (long)rt.b * C * rsl);      // G8: group g, column p at 32 (g rsl + p) bytes
         auto ld8 = [&](float (&dst)[8], unsigned o) __attribute__((always_inline)) {
-#ifdef U24_ABL_FETCH
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dst[j] = (float)(o + j);      // what-if: no input loads
-#else
             // (element by element: indexing an ext_vector with the induction variable of an unrolled loop is folded wrongly by this compiler -
             // elements 2 and 3 came out dead, their registers were handed to the next load; gemm_s2.h met the same)
             const f32x4s q0 = __builtin_bit_cast(f32x4s, ldg_so4(xb, o)), q1 = __builtin_bit_cast(f32x4s, ldg_so4(xb, o + 16u));
             dst[0] = q0.x; dst[1] = q0.y; dst[2] = q0.z; dst[3] = q0.w;
             dst[4] = q1.x; dst[5] = q1.y; dst[6] = q1.z; dst[7] = q1.w;
-#endif
         };
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
