@@ -304,3 +304,23 @@ def test_default_phase_draw_does_not_depend_on_the_batch(gen):
     torch.manual_seed(78)
     c = gen.convert(wf, tgt, 0.0, lengths=lens)
     assert not torch.equal(a, c), "another seed, other phases"
+
+
+def test_grn_tile_sums_add_up_the_same_way_alone_and_next_to_a_long_utterance(gen):
+    """GRN's norm over time is added up from per-tile sums (cnx_s3.h): by every cnx2 workgroup itself up to 16 tiles, by one small
+    launch before it when the longest utterance of the batch has more.  A 200-frame utterance takes the first route alone and the second
+    next to a 1100-frame one (18 tiles); a 1100-frame utterance alone takes the second.  Same order in both: bit-identical samples."""
+    frames = [200, 1100, 131, 1030]
+    lens = [480 * f for f in frames]
+    wf = torch.zeros(len(frames), max(lens))
+    for b, n in enumerate(lens):
+        wf[b, :n] = synth.synth_wave(1, n, seed=900 + b)[0]
+    tgt = synth.synth_index(2000, seed=8).to(DEV)
+    angle = synth.synth_angle(len(frames), max(frames), 41).to(DEV)
+    out = gen.convert(wf.to(DEV), tgt, 0.5, noise_angle=angle, lengths=lens)
+    for b, f in enumerate(frames):
+        one = gen.convert(wf[b:b + 1, :lens[b]].to(DEV), tgt, 0.5, noise_angle=angle[b:b + 1, :, :f].contiguous())
+        assert torch.equal(out[b, :lens[b]], one[0]), f"utterance {b} ({f} frames)"
+    # an equal-length batch of the long one (B = 2, not ragged) against the same B = 1 call
+    two = gen.convert(wf[1:2, :lens[1]].repeat(2, 1).to(DEV), tgt, 0.5, noise_angle=angle[1:2].repeat(2, 1, 1).contiguous())
+    assert torch.equal(two[0], out[1, :lens[1]]) and torch.equal(two[1], two[0])

@@ -1,15 +1,16 @@
 // ConvNeXt-v2 layer (convnext.py:38-58) as TWO launches around GRN's global-time norm:
 //
-//   cnx1_kernel   x -> [depthwise k7 dilated conv -> LayerNorm(C)] -> c2 (C -> 2C) -> GELU -> h
-//   (grn_norm_kernel, encoder.hip: || h[b][c][:] ||_2 - the one reduction that spans every column of an utterance)
-//   cnx2_kernel   [GRN factors of the utterance] -> c3 (2C -> C) over h * factor -> + bias' + x -> x      (in place)
+//   cnx1_kernel   x -> [depthwise k7 dilated conv -> LayerNorm(C)] -> c2 (C -> 2C) -> GELU -> h, and sum_t h^2 of its column tile -> gp
+//   cnx2_kernel   [|| h[b][c][:] ||_2 from the utterance's tile sums -> GRN factors] -> c3 (2C -> C) over h * factor -> + bias' + x -> x      (in place)
+//   (utterances of more than CNX_GP_INLINE tiles: grn_tiles_kernel adds the tile sums up once, in the same order, between the two)
 //
 // Same arithmetic as the five launches they replace (dwconv_ln, gemm_s2 / EpiBias<GELU>, grn_norm, grn_finalize, gemm_s2 SCALED /
-// EpiBias<RES>): the LayerNorm moments are summed in dwconv_ln_kernel's order (16 channel classes c % 16, each in ascending order,
-// then the 16 partial sums in ascending order), the K16 steps of a contraction are walked in ascending order with the three
-// part-products in conv3s.h's order, GRN's mean in grn_finalize_kernel's order, and the epilogues are gemm_epi.h's: every column of
-// every tensor comes out bit for bit as before, whatever the batch, the tile width or the row split (a column's arithmetic never
-// looks at another column).
+// EpiBias<RES>), except for the order in which GRN's sum over time is added up: the LayerNorm moments are summed in
+// dwconv_ln_kernel's order (16 channel classes c % 16, each in ascending order, then the 16 partial sums in ascending order), the
+// K16 steps of a contraction are walked in ascending order with the three part-products in conv3s.h's order, GRN's mean in
+// grn_finalize_kernel's order, and the epilogues are gemm_epi.h's.  A column's arithmetic never looks at another column, and the
+// time sum's order is a function of the utterance's own length (its equal-width tiles of <= 64 columns, ascending): an utterance
+// comes out bit for bit the same whatever the batch, the launch geometry or the row split.
 //
 // Schedule: the B operand is STATIONARY.  A workgroup owns <= 64 columns of ONE utterance and ALL K input channels of them: the
 // prologue leaves the whole split operand tile in LDS (C x 64 x 4 B = 96 KiB at C = 384) and no barrier follows it.  Every wave then
@@ -41,7 +42,9 @@ struct CnxArgs {
     const float *dw_w, *dw_b, *ln_g, *ln_b;
     int dil;
     // cnx2
-    const float* gx;     // [B][2C] row norms (grn_norm_kernel)
+    float* gp;           // [B][gp_tiles][2C] GRN partials: sum of h^2 over one column tile's valid columns (cnx1 writes, cnx2 reads)
+    int gp_tiles;        // tile slots per utterance (the longest utterance's tile count)
+    int gp_sum;          // cnx2: 0 = add this utterance's own tiles up in ascending order; 1 = grn_tiles_kernel already did, into slot 0
     const float* grn_g;  // [2C]
     float* amax_y;       // optional per-utterance |max| slot of the output x (zeroed by the caller)
 #ifdef CNX_TRACE
@@ -63,6 +66,7 @@ struct CnxArgs {
 #define CNX_STAMP(id) do {} while (0)
 #endif
 
+constexpr int CNX_GP_INLINE = 16;   // tile sums a cnx2 workgroup adds up itself
 constexpr int CNX_PD = 4;      // A-fragment ring depth (K16 steps in flight)
 #ifndef CNX_ABL
 #define CNX_ABL 0                // what-if builds of tools/micro/cnx_bench.hip (timing only, wrong results)
@@ -284,6 +288,15 @@ __global__ __launch_bounds__((Cnx1<C, NT>::NTHR)) void cnx1_kernel(CnxArgs a) {
         const int n = j * 32 + l31;
         oo[j] = 4u * (unsigned)(4 * lh * rs + t0 + (n < tw ? n : tw - 1));
     }
+    // GRN's row norms need sum_t h^2 over the whole utterance.  This tile's share - in a FIXED order, so that an utterance's result
+    // never depends on the batch around it: a lane adds its own column of n-tile 0, then of n-tile 1 (columns past the tile's end
+    // add nothing), five xor steps add the 32 columns of a half wave - leaves for gp[b][tile][row] right behind the
+    // item's last store; cnx2 adds an utterance's tiles in ascending order.
+    bool live[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) live[j] = j * 32 + l31 < tw;
+    float sq[16];
+    float* gpb = a.gp + ((long)b * a.gp_tiles + blockIdx.x) * (2 * C) + ((l31 >> 1) & 3) + 8 * (l31 >> 3) + 4 * lh;
     auto finish2 = [&](int e) __attribute__((always_inline)) {      // values e, e + 1 (same n-tile: e is even)
         const int j = e >> 4;
         f32x2e v = {pend[e], pend[e + 1]};
@@ -293,6 +306,23 @@ __global__ __launch_bounds__((Cnx1<C, NT>::NTHR)) void cnx1_kernel(CnxArgs a) {
         for (int i = 0; i < 2; ++i) {
             const int r = (e + i) & 15;
             if (!((CNX_ABL & 8) && o[i] != 1.2345f)) stg_so(hb + (long)(pmt * 32 + (r & 3) + 8 * (r >> 2)) * rs, oo[j], o[i]);
+            if (j == 0) sq[r] = live[0] ? o[i] * o[i] : 0.f;
+            else sq[r] = live[j] ? fmaf(o[i], o[i], sq[r]) : sq[r];
+        }
+        if (e == NPEND - 2) {
+            // reduce-scatter over the 32 columns of a half wave: each xor step halves the rows a lane still carries; lane l31 ends
+            // up with row value l31 >> 1 (both lanes of a pair hold and store it: no exec-masked block)
+            const bool b4 = l31 & 16, b3 = l31 & 8, b2 = l31 & 4, b1 = l31 & 2;
+            float w8[8], w4[4], w2[2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w8[i] = (b4 ? sq[i + 8] : sq[i]) + __shfl_xor(b4 ? sq[i] : sq[i + 8], 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w4[i] = (b3 ? w8[i + 4] : w8[i]) + __shfl_xor(b3 ? w8[i] : w8[i + 4], 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) w2[i] = (b2 ? w4[i + 2] : w4[i]) + __shfl_xor(b2 ? w4[i] : w4[i + 2], 4);
+            float w1 = (b1 ? w2[1] : w2[0]) + __shfl_xor(b1 ? w2[0] : w2[1], 2);
+            w1 += __shfl_xor(w1, 1);
+            gpb[pmt * 32] = w1;
         }
     };
     auto post = [&](int k) __attribute__((always_inline)) {
@@ -374,13 +404,16 @@ __global__ __launch_bounds__((Cnx2<C, KPASS>::NTHR)) void cnx2_kernel(CnxArgs a)
     // ---- GRN factors: grn_finalize_kernel's arithmetic and order (256 threads) --------------------------------------------
     // (their inputs are requested first and the first operand half right behind them, so that it flies under the reductions:
     // one in-order counter - waiting for a load waits for every older one)
-    const float* g = a.gx + (long)b * K;
+    const float* g = a.gp + (long)b * a.gp_tiles * K;
+    const int gtiles = a.gp_sum ? 1 : ntu;                          // (cnx1's tiles are these: 64 columns, or one tile of <= 32)
     constexpr int GPT = K / 256;
     float gv[GPT], gm[GPT];
     if (tid < 256) {
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
-            gv[i] = g[tid + 256 * i];
+            float ss = g[tid + 256 * i];
+            for (int t = 1; t < gtiles; ++t) ss += g[(long)t * K + tid + 256 * i];
+            gv[i] = ss;
             gm[i] = a.grn_g[tid + 256 * i];
         }
     }
@@ -416,6 +449,8 @@ __global__ __launch_bounds__((Cnx2<C, KPASS>::NTHR)) void cnx2_kernel(CnxArgs a)
     fetch(0);
     if (tid < 256) {
         float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) gv[i] = sqrtf(gv[i]);
 #pragma unroll
         for (int i = 0; i < GPT; ++i) s += gv[i];
 #pragma unroll

@@ -185,7 +185,18 @@ int run_layernorm(tvc_ctx* ctx, hipStream_t s, float* x, const float* g, const f
     return launch_check(ctx, "layernorm");
 }
 
-// The two fused launches of cnx_s3.h around grn_norm; false = the layer is outside their preconditions (run_convnext's five launches take it)
+// gp[b][0][c] = sum of gp[b][t][c] over utterance b's tiles, in cnx2_kernel's own order (long utterances: added up once, not per workgroup)
+static __global__ void grn_tiles_kernel(float* __restrict__ gp, int gp_tiles, int K, int T, RagDev rg) {
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= K) return;
+    const int Tb = rg.tb ? rg.tb[b] : T, n = (Tb + 63) / 64;
+    float* g = gp + (long)b * gp_tiles * K + c;
+    float s = g[0];
+    for (int t = 1; t < n; ++t) s += g[(long)t * K];
+    g[0] = s;
+}
+
+// The two fused launches of cnx_s3.h; false = the layer is outside their preconditions (run_convnext's five launches take it)
 template <int C>
 static bool cnx_try(int* rc, tvc_ctx* ctx, hipStream_t s, const ConvNeXtW& w, float* x, float* h, float* gx, int B, int T, float* amax_out) {
     if (w.C != C || !(w.ln_bound < 32768.f) || w.c2.MT6 != 2 * C / 32 || w.c3.MT6 != C / 32 || w.c2.S6 < C / 16 || w.c3.S6 < 2 * C / 16) return false;
@@ -230,6 +241,8 @@ static bool cnx_try(int* rc, tvc_ctx* ctx, hipStream_t s, const ConvNeXtW& w, fl
         a.ln_b = w.ln_b;
         a.dil = w.dilation;
         const int nt = Tl <= 32 ? 1 : 2, tx = (Tl + 32 * nt - 1) / (32 * nt);
+        a.gp = gx;
+        a.gp_tiles = tx;
         const int d = split(a.MT, tx * NB);
         a.mt_per_wg = a.MT / d;
         const dim3 grid((unsigned)tx, (unsigned)NB, (unsigned)d);
@@ -237,13 +250,13 @@ static bool cnx_try(int* rc, tvc_ctx* ctx, hipStream_t s, const ConvNeXtW& w, fl
         if (nt == 1) hipLaunchKernelGGL((cnx1_kernel<C, 1>), grid, dim3(nthr), lds1, s, a);
         else hipLaunchKernelGGL((cnx1_kernel<C, 2>), grid, dim3(nthr), lds2, s, a);
     }
-    hipLaunchKernelGGL(grn_norm_kernel, dim3(grid_for((long)NB * 2 * C * 64)), dim3(256), 0, s, h, gx, (long)NB * 2 * C, T, a.rg, 2 * C);
+    a.gp_sum = a.gp_tiles > CNX_GP_INLINE;
+    if (a.gp_sum) hipLaunchKernelGGL(grn_tiles_kernel, dim3((2 * C + 255) / 256, (unsigned)NB), dim3(256), 0, s, gx, a.gp_tiles, 2 * C, T, a.rg);
     {
         a.A6 = reinterpret_cast<const uint4*>(w.c3.A6);
         a.wsc = w.c3.wscale;
         a.bias = w.c3_bias_grn;
         a.MT = w.c3.MT6;
-        a.gx = gx;
         a.grn_g = w.grn_g;
         a.amax_y = amax_out;
         const int tx = (Tl + 63) / 64;
@@ -263,7 +276,8 @@ int run_convnext(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const ConvNeXtW&
     size_t mk = ws.mark();
     float* y = ws.get<float>((size_t)B * C * T);
     float* h = ws.get<float>((size_t)B * C2 * T);
-    float* gx = ws.get<float>((size_t)NB * C2);
+    const int Tlong = ctx->rag ? ctx->rag->Tlong : T;
+    float* gx = ws.get<float>((size_t)NB * C2 * ((Tlong + 63) / 64));      // row norms; the fused launches keep one sum of squares per 64-column tile
     float* nx = ws.get<float>((size_t)NB * C2);
     float* ymax = ws.get<float>((size_t)NB);      // |max| slots of the two 1x1s' inputs (block-floating-point guard, conv3s.h)
     float* hmax = ws.get<float>((size_t)NB);
@@ -422,7 +436,8 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     // stacked input 1x1: fork the pitch chain onto the context's side stream and join before returning, so its
     // small launches fill the gaps of the SSL chain instead of extending the critical path.  Each chain gets its own
     // scratch block (the per-layer mark/release scratch would alias otherwise).
-    const size_t ssl_scratch = ((size_t)B * kSslCh * T * 3 + (size_t)NB * kSslCh * 4) * sizeof(float) + (size_t)NB * 8 + 4096;
+    const int gtiles = ((ctx->rag ? ctx->rag->Tlong : T) + 63) / 64;      // run_convnext: y, h, the GRN tile sums, nx, two slots
+    const size_t ssl_scratch = ((size_t)B * kSslCh * T * 3 + (size_t)NB * kSslCh * 2 * (gtiles + 1)) * sizeof(float) + (size_t)NB * 8 + 4096;
     char* ssl_blk = ws.get<char>(ssl_scratch);
     Ws wssl(ssl_blk, ssl_scratch, dry);
     hipStream_t sp = s;

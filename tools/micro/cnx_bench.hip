@@ -29,7 +29,7 @@ static void run(int B, int T) {
     float *x, *h, *gx, *misc;
     hipMalloc(&x, nx * 4);
     hipMalloc(&h, nh * 4);
-    hipMalloc(&gx, (size_t)B * 2 * C * 4);
+    hipMalloc(&gx, (size_t)B * 2 * C * 4 * ((T + 63) / 64));
     hipMalloc(&misc, 65536 * 4);
     std::vector<float> hx(nx), hm(65536);
     for (auto& v : hx) v = (float)rand() / RAND_MAX - 0.5f;
@@ -60,7 +60,9 @@ static void run(int B, int T) {
     a.ln_g = misc + 9216;
     a.ln_b = misc + 10240;
     a.dil = 3;
-    a.gx = gx;
+    a.gp = gx;
+    a.gp_tiles = (T + 63) / 64;
+    a.gp_sum = 0;
     a.grn_g = misc + 12288;
     const int tx = (T + 63) / 64;
     CnxArgs a1 = a, a2 = a;
