@@ -664,7 +664,8 @@ template <bool F16, int MODE>
 static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __restrict__ blob, long Npad, int N, const uint4* __restrict__ qh,
                                                                 int ncols, int nsplit, int tiles_per_split, int t2_cover,
                                                                 float* __restrict__ c4v, const float* __restrict__ theta,
-                                                                int* __restrict__ cnt, int* __restrict__ cand, int* __restrict__ overflow) {
+                                                                int* __restrict__ cnt, int* __restrict__ cand, float* __restrict__ candv,
+                                                                int* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) uint4 csmem[];
     uint4* As = csmem;
     uint4* Xs = csmem + 2 * C_A_U4;
@@ -803,14 +804,23 @@ static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __r
                                     }
                                 } else {
                                     bool hit;                                                  // a NaN similarity is a candidate (the exact kernel ranks it first)
+                                    float cv = a;                                              // the coarse similarity the list keeps beside the row (rescore's second threshold)
                                     if (!F16) hit = !(a < th[j]);
-                                    else hit = a != a || ((fmaxf(a, 0.f) * imx >= th[j]) && (a * inv[row] >= th[j]));
+                                    else {
+                                        hit = a != a || (fmaxf(a, 0.f) * imx >= th[j]);
+                                        if (hit) {
+                                            cv = a * inv[row];
+                                            hit = a != a || cv >= th[j];
+                                        }
+                                    }
                                     hit = hit && th[j] != INFINITY;                            // a padding column of the 256-query tile has no list (its threshold is +inf)
                                     if (hit) {
                                         const int n = n0 + wn * 64 + j * 32 + l31;
                                         const int pos = atomicAdd(&cnt[n], 1);
-                                        if (pos < C_CAP) cand[(long)n * C_CAP + pos] = row;
-                                        else *overflow = 1;
+                                        if (pos < C_CAP) {
+                                            cand[(long)n * C_CAP + pos] = row;
+                                            candv[(long)n * C_CAP + pos] = cv;
+                                        } else *overflow = 1;
                                     }
                                 }
                             }
@@ -878,7 +888,7 @@ static __global__ __launch_bounds__(256) void knn_theta_kernel(const float* __re
 // similarity +inf, what the exact kernel's NaN-as-maximum rule selects.
 static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restrict__ blob, long Npad, int N, const float* __restrict__ qn,
                                                                  int ncols, int T, const int* __restrict__ cnt, const int* __restrict__ cand,
-                                                                 float* __restrict__ rv, int* __restrict__ ri) {
+                                                                 const float* __restrict__ candv, float* __restrict__ rv, int* __restrict__ ri) {
     constexpr int RG = 4;                           // candidates scored together
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -890,6 +900,43 @@ static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __
     const int nc = min(cnt[n], C_CAP);
     Top4 t4;
     t4.init();
+    // Second threshold.  Pass B's was cut from a SAMPLE of the index, so a list holds the few dozen rows above the sample's fourth best.
+    // The list itself knows better: it contains every row with coarse >= theta, hence the four largest coarse values of the WHOLE index;
+    // with c4 the fourth of them, four rows have exact >= c4 - eps, so a row of the exact top four has exact >= c4 - eps and coarse
+    // >= c4 - 2 eps.  Only those are scored (a handful): the 3 KB gather per candidate was the kernel's whole cost.  NaN coarse values are
+    // left out of the ranking (a lower c4: more rows kept) and always scored.
+    float cvl[C_CAP / 64];
+    float th2;
+    {
+        float rk[C_CAP / 64];
+#pragma unroll
+        for (int c = 0; c < C_CAP / 64; ++c) {
+            cvl[c] = 64 * c + lane < nc ? candv[(long)n * C_CAP + 64 * c + lane] : -INFINITY;
+            rk[c] = cvl[c] == cvl[c] ? cvl[c] : -INFINITY;
+        }
+        float wm = -INFINITY;
+#pragma unroll
+        for (int round = 0; round < 4; ++round) {
+            float lm = rk[0];
+#pragma unroll
+            for (int c = 1; c < C_CAP / 64; ++c) lm = fmaxf(lm, rk[c]);
+            wm = lm;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+            const unsigned long long who = __builtin_amdgcn_ballot_w64(lm == wm);
+            if (lane == __builtin_ctzll(who)) {       // one instance leaves the ranking (equal values count once each)
+                bool done = false;
+#pragma unroll
+                for (int c = 0; c < C_CAP / 64; ++c)
+                    if (!done && rk[c] == wm) {
+                        rk[c] = -INFINITY;
+                        done = true;
+                    }
+            }
+        }
+        th2 = wm - 2.f * C_EPS;                       // (fewer than four finite values: -inf, everything is scored)
+    }
+    static_assert(C_CAP == 256, "four 64-entry chunks");
     if (kind == KIND_F16) {
         // the fp16 image keeps a vector as 96 16-byte segments (8 consecutive channels each, 4 KiB apart): lane l reads
         // segments l and 64 + l (l < 32) with one 16-byte load each instead of twelve 2-byte loads
@@ -905,16 +952,24 @@ static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __
         // The candidate list is read 64 entries at a time (one coalesced load, the row numbers then come out of a register by lane
         // broadcast) and the candidates are scored four at a time: their loads are in flight together instead of one list entry -> one
         // vector -> one reduction after the other (the chain was 2 - 3 us per candidate with nothing else to issue: ACTIVE 0.06).
-        for (int base = 0; base < nc; base += 64) {
+        for (int base = 0, ch = 0; base < nc; base += 64, ++ch) {
             const int mine = base + lane < nc ? cand[(long)n * C_CAP + base + lane] : 0;
-            const int m = min(64, nc - base);
-            for (int c0 = 0; c0 < m; c0 += RG) {
+            const float cvv = ch == 0 ? cvl[0] : (ch == 1 ? cvl[1] : (ch == 2 ? cvl[2] : cvl[3]));
+            unsigned long long mask = __builtin_amdgcn_ballot_w64(base + lane < nc && !(cvv < th2));      // the entries that pass (NaN does)
+            while (mask) {
                 int row[RG];
+                bool live[RG];
                 float d[RG], iv[RG];
                 u32x4 w[RG][2];
+                int pos = 0;
 #pragma unroll
                 for (int g = 0; g < RG; ++g) {
-                    row[g] = __shfl(mine, min(c0 + g, m - 1));
+                    live[g] = mask != 0ull;
+                    if (live[g]) {
+                        pos = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                    }
+                    row[g] = __shfl(mine, pos);      // (past the end: the last one again, not inserted)
                     const long rbase = ((long)(row[g] >> 7) * STEPS * 4 + ((row[g] & 127) >> 5)) * 64 + (row[g] & 31);     // + (step * 4) * 64 + half * 32
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -941,7 +996,7 @@ static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __
                     for (int g = 0; g < RG; ++g) d[g] += __shfl_xor(d[g], o);
 #pragma unroll
                 for (int g = 0; g < RG; ++g)
-                    if (c0 + g < m) t4.insert(nan_max(d[g] * iv[g]), row[g]);
+                    if (live[g]) t4.insert(nan_max(d[g] * iv[g]), row[g]);
             }
         }
     } else {
@@ -949,15 +1004,23 @@ static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __
 #pragma unroll
         for (int u = 0; u < 12; ++u) qv[u] = qp[(long)(lane + 64 * u) * T];
         const float* rows = blob + HDR;
-        for (int base = 0; base < nc; base += 64) {
+        for (int base = 0, ch = 0; base < nc; base += 64, ++ch) {
             const int mine = base + lane < nc ? cand[(long)n * C_CAP + base + lane] : 0;
-            const int m = min(64, nc - base);
-            for (int c0 = 0; c0 < m; c0 += RG) {
+            const float cvv = ch == 0 ? cvl[0] : (ch == 1 ? cvl[1] : (ch == 2 ? cvl[2] : cvl[3]));
+            unsigned long long mask = __builtin_amdgcn_ballot_w64(base + lane < nc && !(cvv < th2));      // the entries that pass (NaN does)
+            while (mask) {
                 int row[RG];
+                bool live[RG];
                 float d[RG], iv[RG], xv[RG][12];
+                int pos = 0;
 #pragma unroll
                 for (int g = 0; g < RG; ++g) {
-                    row[g] = __shfl(mine, min(c0 + g, m - 1));      // (past the end: the last candidate again, not inserted)
+                    live[g] = mask != 0ull;
+                    if (live[g]) {
+                        pos = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                    }
+                    row[g] = __shfl(mine, pos);      // (past the end: the last one again, not inserted)
                     const float* rp = rows + (long)row[g] * KD + lane;
 #pragma unroll
                     for (int u = 0; u < 12; ++u) xv[g][u] = rp[64 * u];
@@ -975,7 +1038,7 @@ static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __
                     for (int g = 0; g < RG; ++g) d[g] += __shfl_xor(d[g], o);
 #pragma unroll
                 for (int g = 0; g < RG; ++g)
-                    if (c0 + g < m) t4.insert(nan_max(d[g] * iv[g]), row[g]);
+                    if (live[g]) t4.insert(nan_max(d[g] * iv[g]), row[g]);
             }
         }
     }
@@ -1023,7 +1086,7 @@ struct KnnLists {        // where the merge kernels find the per-query top-4 lis
 
 template <bool F16, int MODE>
 static int coarse_launch(tvc_ctx* ctx, hipStream_t s, const float* prepared, long Npad, int N, const uint4* qh, int ncols, int qtiles, int t2_cover,
-                         float* c4v, const float* theta, int* cnt, int* cand, int* flag, int* nsplit_out) {
+                         float* c4v, const float* theta, int* cnt, int* cand, float* candv, int* flag, int* nsplit_out) {
     static bool ready_dev[64] = {};
     bool& ready = ready_dev[ctx->device & 63];
     if (!ready) {
@@ -1038,7 +1101,7 @@ static int coarse_launch(tvc_ctx* ctx, hipStream_t s, const float* prepared, lon
     nsplit = (t2_cover + tps - 1) / tps;
     if (nsplit_out) *nsplit_out = nsplit;
     hipLaunchKernelGGL((knn_coarse_kernel<F16, MODE>), dim3((unsigned)(qtiles * nsplit)), dim3(512), C_LDS, s, prepared, Npad, N, qh, ncols, nsplit, tps, t2_cover,
-                       c4v, theta, cnt, cand, flag);
+                       c4v, theta, cnt, cand, candv, flag);
     return 0;
 }
 
@@ -1058,6 +1121,7 @@ static int knn_candidates(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
     uint4* qh = nullptr;
     float *c4v = nullptr, *theta = nullptr;
     int *cnt = nullptr, *cand = nullptr;
+    float* candv = nullptr;
     const int cq = (p.ncols + C_QT - 1) / C_QT;
     if (two_stage) {
         qh = ws.get<uint4>((size_t)cq * STEPS * 2 * 256);
@@ -1065,6 +1129,7 @@ static int knn_candidates(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
         theta = ws.get<float>((size_t)p.ncols);
         cnt = ws.get<int>((size_t)p.ncols);
         cand = ws.get<int>((size_t)p.ncols * C_CAP);
+        candv = ws.get<float>((size_t)p.ncols * C_CAP);
         L->rv = ws.get<float>((size_t)p.ncols * 4);
         L->ri = ws.get<int>((size_t)p.ncols * 4);
         L->flag = ws.get<int>(64);
@@ -1081,12 +1146,12 @@ static int knn_candidates(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
         if (sample > t2) sample = t2;
         int nsA = 1;
         // both storages' instantiations are launched; each returns at once unless the blob is of its kind
-        TVC_CHECK((coarse_launch<false, 0>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, sample, c4v, nullptr, cnt, cand, L->flag, &nsA)));
-        TVC_CHECK((coarse_launch<true, 0>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, sample, c4v, nullptr, cnt, cand, L->flag, &nsA)));
+        TVC_CHECK((coarse_launch<false, 0>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, sample, c4v, nullptr, cnt, cand, candv, L->flag, &nsA)));
+        TVC_CHECK((coarse_launch<true, 0>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, sample, c4v, nullptr, cnt, cand, candv, L->flag, &nsA)));
         hipLaunchKernelGGL(knn_theta_kernel, dim3((p.ncols + 255) / 256), dim3(256), 0, s, c4v, nsA, p.ncols, theta);
-        TVC_CHECK((coarse_launch<false, 1>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, t2, c4v, theta, cnt, cand, L->flag, nullptr)));
-        TVC_CHECK((coarse_launch<true, 1>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, t2, c4v, theta, cnt, cand, L->flag, nullptr)));
-        hipLaunchKernelGGL(knn_rescore_kernel, dim3((p.ncols + 3) / 4), dim3(256), 0, s, prepared, p.Npad, (int)N, qn, p.ncols, T, cnt, cand, L->rv, L->ri);
+        TVC_CHECK((coarse_launch<false, 1>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, t2, c4v, theta, cnt, cand, candv, L->flag, nullptr)));
+        TVC_CHECK((coarse_launch<true, 1>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, t2, c4v, theta, cnt, cand, candv, L->flag, nullptr)));
+        hipLaunchKernelGGL(knn_rescore_kernel, dim3((p.ncols + 3) / 4), dim3(256), 0, s, prepared, p.Npad, (int)N, qn, p.ncols, T, cnt, cand, candv, L->rv, L->ri);
     }
     ProfScope ps(ctx, s, dry, "knn.exact");       // ~0 when the two-stage search succeeded (the kernel exits on the flag)
     hipLaunchKernelGGL(knn_topk_split_kernel, dim3((unsigned)(p.qtiles * p.nsplit)), dim3(512), 0, s, prepared, p.Npad, (int)N, qn, p.ncols, T,
