@@ -1141,8 +1141,11 @@ static int knn_candidates(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
     if (two_stage) {
         ProfScope ps(ctx, s, dry, "knn.coarse+rescore");
         const int t2 = (int)((p.Npad + C_MT - 1) / C_MT);          // 256-vector tiles
-        int sample = t2 / 8;                                         // pass A: an eighth of the index, at least 2048 vectors
-        if (sample < 8) sample = 8;
+        // pass A: an eighth of the index, at least 1280 vectors.  (A smaller sample lowers the threshold: longer lists - whose rows the
+        // rescoring wave's own threshold then drops unscored - and, past C_CAP entries, the exact fallback: a sixteenth sends the
+        // 100 000-vector index there.  Five tiles x 50 query tiles of the bench batch are one round of the chip.)
+        int sample = t2 / 8;
+        if (sample < 5) sample = 5;
         if (sample > t2) sample = t2;
         int nsA = 1;
         // both storages' instantiations are launched; each returns at once unless the blob is of its kind
