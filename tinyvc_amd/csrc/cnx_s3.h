@@ -348,7 +348,7 @@ __global__ __launch_bounds__((Cnx1<C, NT>::NTHR)) void cnx1_kernel(CnxArgs a) {
             for (int r = 0; r < 16; ++r) pend[j * 16 + r] = comb(hi[j][r], lo[j][r], cw, cl) + bv[r];
         pmt = mt;
     };
-    int stamp = 7;
+    [[maybe_unused]] int stamp = 7;
     {
         CnxNoPost none;
         walk(none);

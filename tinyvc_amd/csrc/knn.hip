@@ -196,9 +196,14 @@ static __global__ __launch_bounds__(QN_WAVES * 64) void query_normalize_kernel(c
     const int b = (int)(nn / T), t = (int)(nn - (long)b * T);
     const float* p = src + (long)b * KD * T + t;
     float* q = qn + (long)b * KD * T + t;
-    const int k0 = wave * (KD / QN_WAVES), k1 = k0 + KD / QN_WAVES;
+    constexpr int KW = KD / QN_WAVES;
+    const int k0 = wave * KW;
+    float x[KW];       // the wave's 48 channels stay in registers: requested together (the summing loop was a chain of load latencies), read once
+#pragma unroll
+    for (int i = 0; i < KW; ++i) x[i] = p[(long)(k0 + i) * T];
     float s = 0.f;
-    for (int k = k0; k < k1; ++k) s = fmaf(p[(long)k * T], p[(long)k * T], s);
+#pragma unroll
+    for (int i = 0; i < KW; ++i) s = fmaf(x[i], x[i], s);
     part[wave][lane] = s;
     __syncthreads();
     float ss = part[0][lane];
@@ -208,10 +213,12 @@ static __global__ __launch_bounds__(QN_WAVES * 64) void query_normalize_kernel(c
     if (blockIdx.x == 0 && threadIdx.x == 0 && flag) *flag = 0;
     if (wave == 0 && ok && cnt) cnt[n] = 0;
     uint4* qhp = qh ? qh + (n >> 8) * (long)(STEPS * 2 * 256) + (n & 255) : nullptr;
-    for (int k = k0; k < k1; k += 8) {
+#pragma unroll
+    for (int i = 0; i < KW; i += 8) {
+        const int k = k0 + i;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ok ? p[(long)(k + j) * T] / den : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = ok ? x[i + j] / den : 0.f;
         if (ok) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) q[(long)(k + j) * T] = v[j];
