@@ -806,8 +806,9 @@ static int convert_impl(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const flo
     // |max| slots the path can bound without a pass over the tensors (block-floating-point guard of the fp16 split, conv3s.h; equal-length
     // batches): emax = max |wav| per utterance (the energy stage's pooled maxima, 1 500 values each) bounds the energy envelope - a linear
     // interpolation of them - and, times the Hann window's sum (960), every |STFT| bin; `matched` is a mean of index rows.
-    float* emax = ws.get<float>((size_t)2 * B);
+    float* emax = ws.get<float>((size_t)5 * B);
     float* spec_bound = emax + B;
+    float* enc_slots = spec_bound + B;      // the encoder's three atomicMax slots: zeroed by the energy stage's pooled-maximum launch
     const bool bounds = !ctx->rag;
     size_t m = ws.mark();
     {
@@ -817,13 +818,12 @@ static int convert_impl(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const flo
     ws.release(m);
     {
         ProfScope ps(ctx, s, dry, "energy");
-        TVC_CHECK(run_energy(ctx, s, ws, dry, wav, energy, B, L, bounds ? emax : nullptr));
-        if (!dry && bounds) TVC_CHECK(run_slot_affine(ctx, s, spec_bound, emax, 1, 960.5f, 0.f, B));
+        TVC_CHECK(run_energy(ctx, s, ws, dry, wav, energy, B, L, bounds ? emax : nullptr, bounds ? spec_bound : nullptr, bounds ? enc_slots : nullptr, 3 * B));
     }
     ws.release(m);
     {
         ProfScope ps(ctx, s, dry, "encoder");
-        TVC_CHECK(run_encoder(ctx, s, ws, dry, spec, ssl, f0, nullptr, B, T, bounds ? spec_bound : nullptr));
+        TVC_CHECK(run_encoder(ctx, s, ws, dry, spec, ssl, f0, nullptr, B, T, bounds ? spec_bound : nullptr, bounds ? enc_slots : nullptr, f0s, pitch_shift));
     }
     ws.release(m);
     {
@@ -831,7 +831,6 @@ static int convert_impl(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const flo
         TVC_CHECK(run_knn(ctx, s, ws, dry, ssl, prepared, N, matched, nullptr, B, T));
     }
     ws.release(m);
-    if (!dry) TVC_CHECK(run_shift(ctx, s, f0, f0s, (int64_t)B * T, pitch_shift));
     TVC_CHECK(run_decoder(ctx, s, ws, dry, matched, f0s, energy, angle, seed, wave, nullptr, nullptr, nullptr, B, T, dry ? nullptr : knn_index_amax(prepared),
                           bounds ? emax : nullptr));
     ws.release(m);

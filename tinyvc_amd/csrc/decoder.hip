@@ -193,12 +193,12 @@ static __global__ __launch_bounds__(256) void noise_ola_kernel(const float* __re
 // =================================================================================================
 // cmax: per-utterance |max| slot of `content` (block-floating-point guard of the fp16 split, conv3s.h)
 static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
-                          const float* energy, float* amps, float* kern, int B, int T, const float* cmax) {
+                          const float* energy, float* amps, float* kern, int B, int T, const float* cmax, float* xmax_zeroed) {
     const int ncols = B * T;
     float* ef = ws.get<float>((size_t)B * T);
     float* x = ws.get<float>((size_t)B * kSrcCh * T);
     const int NB = ctx->rag ? ctx->rag->B : B;      // utterances (a ragged batch runs as B = 1, T = all its frames: ragged.h)
-    float* xmax = ws.get<float>((size_t)NB);
+    float* xmax = xmax_zeroed ? xmax_zeroed : ws.get<float>((size_t)NB);      // (the caller's, zeroed with its other slots, or an own one)
     if (!dry) {
         hipLaunchKernelGGL(window_max_kernel, dim3(grid_for((long)ncols * 64)), dim3(256), 0, s, energy, ef, (long)B, T, kHop);
         EpiSumCond ep{x, ctx->src_content_in.bias, ef, f0, ctx->src_e_w, ctx->src_e_b, ctx->src_f_w, ctx->src_f_b, kSrcCh, T, ncols};
@@ -206,7 +206,7 @@ static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
         if (!gemm_s2_try(&rc, ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep, cmax)) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_content_in, content, B, kSslDim, T, 0, ep, cmax);
         TVC_CHECK(rc);
     }
-    if (!dry) TVC_HIP(ctx, hipMemsetAsync(xmax, 0, (size_t)NB * sizeof(float), s));
+    if (!dry && !xmax_zeroed) TVC_HIP(ctx, hipMemsetAsync(xmax, 0, (size_t)NB * sizeof(float), s));
     for (int i = 0; i < 3; ++i) TVC_CHECK(run_convnext(ctx, s, ws, dry, ctx->src_mid[i], x, B, T, i == 2 ? xmax : nullptr));     // the last layer publishes the |max| slot of its output
     if (dry) return 0;
     // to_amps (128 -> 15 rows: one 32-row m-tile)
@@ -329,7 +329,7 @@ static __global__ void g8_to_planar_kernel(const float* __restrict__ x, float* _
 
 // cmax / smax (nullable): |max| slots of `content` / of cat[source, energy] if the caller already has them
 int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
-               const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps, const float* cmax, const float* smax) {
+               const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps, const float* cmax, const float* smax, float* zeroed_slots) {
     const long L = (long)T * kHop;
     static const int ch[5] = {384, 192, 96, 48, 24};
     const long len_dn[5] = {L, L / 5, L / 20, L / 80, L / 240};   // skip i lives at len_dn[i]
@@ -347,12 +347,13 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
     enum { S_CONTENT = 0, S_SRC, S_X, S_SKIP0, S_DH1 = S_SKIP0 + 5, S_DH2 = S_DH1 + 4, S_UHA = S_DH2 + 4, S_UX1 = S_UHA + 5, S_UHB = S_UX1 + 5, S_UXU = S_UHB + 5,
            S_LEV = S_UXU + 5, S_COUNT = S_LEV + 5 };
     const int NB = ctx->rag ? ctx->rag->B : B;      // utterances (a ragged batch runs as B = 1, T = all its frames: ragged.h)
-    float* slots = ws.get<float>((size_t)S_COUNT * NB);
+    static_assert(S_COUNT == kFilterSlots, "tvc_common.h kFilterSlots");
+    float* slots = zeroed_slots ? zeroed_slots : ws.get<float>((size_t)S_COUNT * NB);
     auto slot = [&](int i) { return slots + (size_t)i * NB; };
 
     if (!dry) {
         ProfScope ps(ctx, s, dry, "filter.in+down0");
-        TVC_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)S_COUNT * NB * sizeof(float), s));
+        if (!zeroed_slots) TVC_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)S_COUNT * NB * sizeof(float), s));
         if (!cmax) {
             TVC_CHECK(run_amax_rows(ctx, s, content, B, kSslDim, T, slot(S_CONTENT)));
             cmax = slot(S_CONTENT);
@@ -499,19 +500,21 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
     float* source = source_out ? source_out : ws.get<float>((size_t)B * 16 * L);
     // |max| slots shared by the stages: content (SourceNet's and FilterNet's input contraction), cat[source, energy] (FilterNet's first conv)
     const int NB = ctx->rag ? ctx->rag->B : B;
-    float* cmax = ws.get<float>((size_t)2 * NB);
+    // (one block, zeroed by one launch together with the two bounds: [cmax | smax | SourceNet's output slot | FilterNet's slots])
+    float* cmax = ws.get<float>((size_t)(3 + kFilterSlots) * NB);
     float* smax = cmax + NB;
+    float* xmax = smax + NB;
+    float* fslots = xmax + NB;
     if (!dry) {
-        if (!content_bound || !energy_bound) TVC_HIP(ctx, hipMemsetAsync(cmax, 0, (size_t)2 * NB * sizeof(float), s));
-        if (content_bound) TVC_CHECK(run_slot_affine(ctx, s, cmax, content_bound, 0, 1.f, 0.f, NB));
-        else TVC_CHECK(run_amax_rows(ctx, s, content, B, kSslDim, T, cmax));
-        if (energy_bound) TVC_CHECK(run_slot_affine(ctx, s, smax, energy_bound, 1, 1.f, 0.f, NB));      // (the dsp kernels raise it to cat[source, energy]'s)
-        else TVC_CHECK(run_amax_rows(ctx, s, energy, B, 1, L, smax));
+        TVC_CHECK(run_slot_prep(ctx, s, cmax, (3 + kFilterSlots) * NB, content_bound ? cmax : nullptr, content_bound, 0, 1.f, 0.f, energy_bound ? smax : nullptr,
+                                energy_bound, 1, 1.f, 0.f, NB));      // (the dsp kernels raise smax to cat[source, energy]'s)
+        if (!content_bound) TVC_CHECK(run_amax_rows(ctx, s, content, B, kSslDim, T, cmax));
+        if (!energy_bound) TVC_CHECK(run_amax_rows(ctx, s, energy, B, 1, L, smax));
     }
     size_t mk = ws.mark();
     {
         ProfScope ps(ctx, s, dry, "source_net");
-        TVC_CHECK(run_source_net(ctx, s, ws, dry, content, f0, energy, amps, kern, B, T, cmax));
+        TVC_CHECK(run_source_net(ctx, s, ws, dry, content, f0, energy, amps, kern, B, T, cmax, xmax));
     }
     ws.release(mk);
     if (!dry && !wave && !source_out) return 0;  // SourceNet.forward alone (decoder.py:126-134): the caller asked for amps / kernel only
@@ -522,7 +525,7 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
     ws.release(mk);
     if (!dry && !wave) return 0;                 // ... or for Decoder.dsp's output (decoder.py:259-266) without the FilterNet pass
     ProfScope ps(ctx, s, dry, "filter_net");
-    TVC_CHECK(run_filter(ctx, s, ws, dry, content, f0, energy, source, wave, B, T, nullptr, cmax, smax));
+    TVC_CHECK(run_filter(ctx, s, ws, dry, content, f0, energy, source, wave, B, T, nullptr, cmax, smax, fslots));
     ws.release(mk);
     return 0;
 }

@@ -368,7 +368,7 @@ struct PTop4 {
 
 constexpr int kPdWaves = 16;
 static __global__ __launch_bounds__(kPdWaves * 64) void pitch_decode_kernel(const float* __restrict__ logits, const float* __restrict__ freq,
-                                                                  float* __restrict__ f0, int B, int T) {
+                                                                  float* __restrict__ f0, int B, int T, float* __restrict__ f0s, float shift) {
     __shared__ float sv[kPdWaves][4][64];     // [wave][entry][lane]: lanes along the fastest axis (the [lane][entry] order was a 4-way bank conflict)
     __shared__ int si[kPdWaves][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -401,18 +401,20 @@ static __global__ __launch_bounds__(kPdWaves * 64) void pitch_decode_kernel(cons
     acc = __fadd_rn(acc, __fmul_rn(e1 / den, freq[top.i[1]]));
     acc = __fadd_rn(acc, __fmul_rn(e2 / den, freq[top.i[2]]));
     acc = __fadd_rn(acc, __fmul_rn(e3 / den, freq[top.i[3]]));
-    f0[n] = acc <= 20.f ? 0.f : acc;
+    const float fv = acc <= 20.f ? 0.f : acc;
+    f0[n] = fv;
+    if (f0s) f0s[n] = shift_frequency_one(fv, shift);      // the caller's shift_frequency(f0, shift), in the same launch
 }
 
 int run_pitch_decode(tvc_ctx* ctx, hipStream_t s, const float* logits, float* f0, int B, int T) {
     if (!ctx->pitch_freq) return fail(ctx, TVC_ERR_STATE, "pitch table not uploaded (tvc_set_pitch_table + tvc_finalize_weights)");
     const long ncols = (long)B * T;
-    hipLaunchKernelGGL(pitch_decode_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(kPdWaves * 64), 0, s, logits, ctx->pitch_freq, f0, B, T);
+    hipLaunchKernelGGL(pitch_decode_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(kPdWaves * 64), 0, s, logits, ctx->pitch_freq, f0, B, T, (float*)nullptr, 0.f);
     return launch_check(ctx, "pitch_decode");
 }
 
 int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec, float* ssl, float* f0,
-                float* logits, int B, int T, const float* spec_bound) {
+                float* logits, int B, int T, const float* spec_bound, float* zeroed_slots, float* f0_shifted, float shift) {
     const int ncols = B * T;
     float* xs = ws.get<float>((size_t)B * kSslCh * T);
     float* xp = ws.get<float>((size_t)B * kPitchCh * T);
@@ -420,11 +422,11 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     // |max| slots (block-floating-point guard of the fp16 split, conv3s.h): the spectrogram and the two residual streams the output
     // projections read; the ConvNeXt layers keep their own (run_convnext)
     const int NB = ctx->rag ? ctx->rag->B : B;      // utterances (ragged batch: B = 1, T = all frames)
-    float* slots = ws.get<float>((size_t)3 * NB);
+    float* slots = zeroed_slots ? zeroed_slots : ws.get<float>((size_t)3 * NB);
     float *spec_max = slots, *xs_max = slots + NB, *xp_max = slots + 2 * NB;
     if (!dry) {
-        TVC_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)3 * NB * sizeof(float), s));
-        if (spec_bound) TVC_CHECK(run_slot_affine(ctx, s, spec_max, spec_bound, 1, 1.f, 0.f, NB));      // the caller's bound instead of a pass over the 961 x T tensor
+        if (!zeroed_slots) TVC_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)3 * NB * sizeof(float), s));
+        if (spec_bound) spec_max = const_cast<float*>(spec_bound);      // the caller's bound IS the slot: no pass over the 961 x T tensor
         else TVC_CHECK(run_amax_rows(ctx, s, spec, B, kBins, T, spec_max));
         EpiSplit ep{xs, xp, ctx->enc_in.bias, kSslCh, kPitchCh, T, ncols};
         // 961 input rows: the last slab is clamped to row 960 (zero weights beyond)
@@ -453,7 +455,7 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
         int rc = 0;
         if (!gemm_s2_try(&rc, ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep, xp_max)) rc = gemm_s_launch<ENC_MTB, ENC_NWV, ENC_BPC>(ctx, sp, ctx->pit_out, xp, B, kPitchCh, T, 0, ep, xp_max);
         TVC_CHECK(rc);
-        hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(kPdWaves * 64), 0, sp, lg, ctx->pitch_freq, f0, B, T);
+        hipLaunchKernelGGL(pitch_decode_kernel, dim3((ncols + 63) / 64), dim3(kPdWaves * 64), 0, sp, lg, ctx->pitch_freq, f0, B, T, f0_shifted, shift);
     }
     if (fork) TVC_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
     for (int i = 0; i < 6; ++i) TVC_CHECK(run_convnext(ctx, s, wssl, dry, ctx->ssl_mid[i], xs, B, T, i == 5 ? xs_max : nullptr));

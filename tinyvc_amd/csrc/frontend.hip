@@ -75,17 +75,38 @@ int run_slot_affine(tvc_ctx* ctx, hipStream_t s, float* out, const float* in, in
     hipLaunchKernelGGL(slot_affine_kernel, dim3(1), dim3(64), 0, s, out, in, in_stride, a, c, n);
     return launch_check(ctx, "slot_affine");
 }
-// emax[b] = max_j e[b][j] (one wavefront per utterance: 1 500 values)
-static __global__ void pooled_max_kernel(const float* __restrict__ e, int ne, float* __restrict__ emax) {
+// The decoder's slots in one launch: zero[0 .. nz) = 0 (the slots its kernels raise with atomicMax), then the two bounds it is handed:
+// o1[b] = a1 in1[b * s1] + c1, o2[b] = a2 in2[b * s2] + c2 (either pair may be null).  One workgroup.
+static __global__ void slot_prep_kernel(float* __restrict__ zero, int nz, float* __restrict__ o1, const float* __restrict__ in1, int s1, float a1, float c1,
+                                        float* __restrict__ o2, const float* __restrict__ in2, int s2, float a2, float c2, int n) {
+    for (int i = threadIdx.x; i < nz; i += blockDim.x) zero[i] = 0.f;
+    __syncthreads();      // (the bounds' slots lie inside the zeroed block)
+    for (int b = threadIdx.x; b < n; b += blockDim.x) {
+        if (o1) o1[b] = fmaf(a1, in1[(long)b * s1], c1);
+        if (o2) o2[b] = fmaf(a2, in2[(long)b * s2], c2);
+    }
+}
+int run_slot_prep(tvc_ctx* ctx, hipStream_t s, float* zero, int nz, float* o1, const float* in1, int s1, float a1, float c1, float* o2, const float* in2, int s2,
+                  float a2, float c2, int n) {
+    hipLaunchKernelGGL(slot_prep_kernel, dim3(1), dim3(256), 0, s, zero, nz, o1, in1, s1, a1, c1, o2, in2, s2, a2, c2, n);
+    return launch_check(ctx, "slot_prep");
+}
+// emax[b] = max_j e[b][j] (one wavefront per utterance: 1 500 values); spec_bound[b] = 960.5 emax[b] >= every |STFT| bin (the Hann window's sum)
+// zero[0 .. nz) = 0: the encoder's atomicMax slots, zeroed here instead of by a memset of their own
+static __global__ void pooled_max_kernel(const float* __restrict__ e, int ne, float* __restrict__ emax, float* __restrict__ spec_bound, float* __restrict__ zero, int nz) {
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < nz; i += gridDim.x * 64) zero[i] = 0.f;
     const float* p = e + (long)blockIdx.x * ne;
     float m = 0.f;
     for (int j = threadIdx.x; j < ne; j += 64) m = fmaxf(m, p[j]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (threadIdx.x == 0) emax[blockIdx.x] = m;
+    if (threadIdx.x == 0) {
+        emax[blockIdx.x] = m;
+        if (spec_bound) spec_bound[blockIdx.x] = fmaf(960.5f, m, 0.f);
+    }
 }
 
-int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, float* energy, int B, int64_t L, float* emax) {
+int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, float* energy, int B, int64_t L, float* emax, float* spec_bound, float* zero, int nz) {
     const int ne = (int)((L + 2 * 32 - 128) / 64 + 1);
     float* e = ws.get<float>((size_t)B * ne + 8);
     if (dry) return 0;
@@ -98,7 +119,7 @@ int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, 
         return launch_check(ctx, "energy (ragged)");
     }
     hipLaunchKernelGGL(energy_pool_kernel, dim3(grid_for((long)B * ne * 64)), dim3(256), 0, s, wav, e, B, (int)L, ne);
-    if (emax) hipLaunchKernelGGL(pooled_max_kernel, dim3(B), dim3(64), 0, s, e, ne, emax);
+    if (emax) hipLaunchKernelGGL(pooled_max_kernel, dim3(B), dim3(64), 0, s, e, ne, emax, spec_bound, zero, nz);
     // F.interpolate(e, L): `size` given -> scale = float(in) / float(out)
     float scale = (float)ne / (float)L;
     {
@@ -116,15 +137,7 @@ int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, 
 // is 2.2e-7 of f0, which the harmonic oscillator integrates over the whole utterance (measured: 4.5e-5 of the 7.1e-5
 // end-to-end rms difference at 4 s came from this function alone before the change).
 static __global__ void shift_kernel(const float* __restrict__ f0, float* __restrict__ out, long n, float shift) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float r = __fdiv_rn(f0[i], 440.f);
-        r = r < 0.f ? 0.f : r;                       // relu; NaN stays NaN as in F.relu
-        const float lg = (float)log2((double)__fadd_rn(r, 1e-6f));
-        float midi = __fadd_rn(__fmul_rn(lg, 12.f), 69.f);
-        midi = __fadd_rn(midi, shift);
-        float e = __fdiv_rn(__fsub_rn(midi, 69.f), 12.f);
-        out[i] = __fmul_rn(440.f, (float)exp2((double)e));
-    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = shift_frequency_one(f0[i], shift);
 }
 
 // u in [0, 1) -> u * 2 * pi - pi with the reference expression's three fp32 roundings (decoder.py:78: `torch.rand(...) * 2 * math.pi - math.pi`

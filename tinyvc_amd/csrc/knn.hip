@@ -668,16 +668,15 @@ struct Top4V {   // four largest values
 // the queries' fp16 image), so staging is copies only: 8 loads + 8 ds_write_b128 per thread and K = 64 step, 32 MFMAs per
 // wave and step.  MODE 0: coarse top-4 values per (split, query) -> c4v.  MODE 1: rows with c >= theta -> candidate lists.
 template <bool F16, int MODE>
-static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __restrict__ blob, long Npad, int N, const uint4* __restrict__ qh,
-                                                                int ncols, int nsplit, int tiles_per_split, int t2_cover,
-                                                                float* __restrict__ c4v, const float* __restrict__ theta,
-                                                                int* __restrict__ cnt, int* __restrict__ cand, float* __restrict__ candv,
-                                                                int* __restrict__ overflow) {
+static __device__ __forceinline__ void knn_coarse_body(const float* __restrict__ blob, long Npad, int N, const uint4* __restrict__ qh,
+                                                       int ncols, int nsplit, int tiles_per_split, int t2_cover,
+                                                       float* __restrict__ c4v, int ns_sample,
+                                                       int* __restrict__ cnt, int* __restrict__ cand, float* __restrict__ candv,
+                                                       int* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) uint4 csmem[];
     uint4* As = csmem;
     uint4* Xs = csmem + 2 * C_A_U4;
     const int kind = F16 ? KIND_F16 : KIND_F32;
-    if (reinterpret_cast<const int*>(blob)[1] != kind) return;      // launched for both storages: the other instantiation does the work
     const uint4* img = blob_img16(blob, kind, N, Npad);
     const float* inv = blob_inv(blob, kind, N, Npad);          // fp16 storage: the image holds the raw vectors
 
@@ -722,8 +721,20 @@ static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __r
     if (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            // theta = (fourth largest coarse similarity of pass A's sample: its splits' top-4 lists, c4v) - 2 eps
             const int n = n0 + wn * 64 + j * 32 + l31;
-            th[j] = n < ncols ? theta[n] : INFINITY;
+            if (n < ncols) {
+                Top4V t4;
+                t4.init();
+                for (int sp = 0; sp < ns_sample; ++sp) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(c4v + ((long)sp * ncols + n) * 4);
+                    t4.insert(v4.x);
+                    t4.insert(v4.y);
+                    t4.insert(v4.z);
+                    t4.insert(v4.w);
+                }
+                th[j] = t4.v[3] - 2.f * C_EPS;
+            }
         }
     }
     f32x16 acc[4][2];
@@ -877,16 +888,18 @@ static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __r
     }
 }
 
-// theta[n] = (4th largest coarse similarity of the sample) - 2 eps
-static __global__ __launch_bounds__(256) void knn_theta_kernel(const float* __restrict__ c4v, int nsplit, int ncols, float* __restrict__ theta) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= ncols) return;
-    Top4V t4;
-    t4.init();
-    for (int sp = 0; sp < nsplit; ++sp)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t4.insert(c4v[((long)sp * ncols + n) * 4 + e]);
-    theta[n] = t4.v[3] - 2.f * C_EPS;
+// The blob's kind lives in device memory (its header): one launch, the workgroup branches to the storage's instantiation of the body
+// (both fit the 256 registers a wave has at one 128 KiB workgroup per CU; two launches cost an empty 4.6 us one per pass).
+template <int MODE>
+static __global__ __launch_bounds__(512) void knn_coarse_kernel(const float* __restrict__ blob, long Npad, int N, const uint4* __restrict__ qh,
+                                                                int ncols, int nsplit, int tiles_per_split, int t2_cover,
+                                                                float* __restrict__ c4v, int ns_sample,
+                                                                int* __restrict__ cnt, int* __restrict__ cand, float* __restrict__ candv,
+                                                                int* __restrict__ overflow) {
+    if (reinterpret_cast<const int*>(blob)[1] == KIND_F16)
+        knn_coarse_body<true, MODE>(blob, Npad, N, qh, ncols, nsplit, tiles_per_split, t2_cover, c4v, ns_sample, cnt, cand, candv, overflow);
+    else
+        knn_coarse_body<false, MODE>(blob, Npad, N, qh, ncols, nsplit, tiles_per_split, t2_cover, c4v, ns_sample, cnt, cand, candv, overflow);
 }
 
 // One wavefront per query: exact similarity of every candidate = (fp32 FMA chain of q_hat against the raw vector, lanes
@@ -1091,13 +1104,13 @@ struct KnnLists {        // where the merge kernels find the per-query top-4 lis
     int* flag = nullptr;    // 0 = the two-stage lists are valid; nullptr = exact kernel only
 };
 
-template <bool F16, int MODE>
+template <int MODE>
 static int coarse_launch(tvc_ctx* ctx, hipStream_t s, const float* prepared, long Npad, int N, const uint4* qh, int ncols, int qtiles, int t2_cover,
-                         float* c4v, const float* theta, int* cnt, int* cand, float* candv, int* flag, int* nsplit_out) {
+                         float* c4v, int ns_sample, int* cnt, int* cand, float* candv, int* flag, int* nsplit_out) {
     static bool ready_dev[64] = {};
     bool& ready = ready_dev[ctx->device & 63];
     if (!ready) {
-        hipError_t e = hipFuncSetAttribute((const void*)knn_coarse_kernel<F16, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, C_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)knn_coarse_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, C_LDS);
         if (e != hipSuccess) return fail(ctx, TVC_ERR_HIP, "knn coarse setup: %s", hipGetErrorString(e));
         ready = true;
     }
@@ -1107,8 +1120,8 @@ static int coarse_launch(tvc_ctx* ctx, hipStream_t s, const float* prepared, lon
     const int tps = (t2_cover + nsplit - 1) / nsplit;
     nsplit = (t2_cover + tps - 1) / tps;
     if (nsplit_out) *nsplit_out = nsplit;
-    hipLaunchKernelGGL((knn_coarse_kernel<F16, MODE>), dim3((unsigned)(qtiles * nsplit)), dim3(512), C_LDS, s, prepared, Npad, N, qh, ncols, nsplit, tps, t2_cover,
-                       c4v, theta, cnt, cand, candv, flag);
+    hipLaunchKernelGGL((knn_coarse_kernel<MODE>), dim3((unsigned)(qtiles * nsplit)), dim3(512), C_LDS, s, prepared, Npad, N, qh, ncols, nsplit, tps, t2_cover,
+                       c4v, ns_sample, cnt, cand, candv, flag);
     return 0;
 }
 
@@ -1116,9 +1129,7 @@ static int coarse_launch(tvc_ctx* ctx, hipStream_t s, const float* prepared, lon
 static int coarse_max_nsplit(int qtiles) { return (768 + qtiles - 1) / qtiles; }
 
 // query normalisation + the per-query top-4 lists; shared by the whole-index match and the index-sharded variant.
-// The blob's kind lives in device memory (its header), so the host cannot pick the coarse kernel's instantiation: both
-// are launched and the one that does not match the blob returns at once (the exact kernel dispatches inside one launch;
-// the coarse kernel's two instantiations differ in register use enough to keep them apart).
+// (The blob's kind lives in device memory - its header -, so the host cannot pick an instantiation: the kernels branch on it.)
 static int knn_candidates(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* src, const float* prepared, int64_t N, int B, int T,
                           const KnnPlan& p, KnnLists* L) {
     float* qn = ws.get<float>((size_t)B * KD * T);
@@ -1126,14 +1137,13 @@ static int knn_candidates(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
     L->ci = ws.get<int>((size_t)p.nsplit * p.ncols * 4);
     const bool two_stage = N >= KNN_COARSE_MIN;
     uint4* qh = nullptr;
-    float *c4v = nullptr, *theta = nullptr;
+    float* c4v = nullptr;
     int *cnt = nullptr, *cand = nullptr;
     float* candv = nullptr;
     const int cq = (p.ncols + C_QT - 1) / C_QT;
     if (two_stage) {
         qh = ws.get<uint4>((size_t)cq * STEPS * 2 * 256);
         c4v = ws.get<float>((size_t)coarse_max_nsplit(cq) * p.ncols * 4);
-        theta = ws.get<float>((size_t)p.ncols);
         cnt = ws.get<int>((size_t)p.ncols);
         cand = ws.get<int>((size_t)p.ncols * C_CAP);
         candv = ws.get<float>((size_t)p.ncols * C_CAP);
@@ -1155,12 +1165,8 @@ static int knn_candidates(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
         if (sample < 5) sample = 5;
         if (sample > t2) sample = t2;
         int nsA = 1;
-        // both storages' instantiations are launched; each returns at once unless the blob is of its kind
-        TVC_CHECK((coarse_launch<false, 0>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, sample, c4v, nullptr, cnt, cand, candv, L->flag, &nsA)));
-        TVC_CHECK((coarse_launch<true, 0>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, sample, c4v, nullptr, cnt, cand, candv, L->flag, &nsA)));
-        hipLaunchKernelGGL(knn_theta_kernel, dim3((p.ncols + 255) / 256), dim3(256), 0, s, c4v, nsA, p.ncols, theta);
-        TVC_CHECK((coarse_launch<false, 1>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, t2, c4v, theta, cnt, cand, candv, L->flag, nullptr)));
-        TVC_CHECK((coarse_launch<true, 1>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, t2, c4v, theta, cnt, cand, candv, L->flag, nullptr)));
+        TVC_CHECK((coarse_launch<0>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, sample, c4v, 0, cnt, cand, candv, L->flag, &nsA)));
+        TVC_CHECK((coarse_launch<1>(ctx, s, prepared, p.Npad, (int)N, qh, p.ncols, cq, t2, c4v, nsA, cnt, cand, candv, L->flag, nullptr)));
         hipLaunchKernelGGL(knn_rescore_kernel, dim3((p.ncols + 3) / 4), dim3(256), 0, s, prepared, p.Npad, (int)N, qn, p.ncols, T, cnt, cand, candv, L->rv, L->ri);
     }
     ProfScope ps(ctx, s, dry, "knn.exact");       // ~0 when the two-stage search succeeded (the kernel exits on the flag)

@@ -48,6 +48,17 @@ __device__ __forceinline__ float2 sincos_small(float a) {
     return make_float2((q & 2) ? -vs : vs, ((q + 1) & 2) ? -vc : vc);
 }
 
+// shift_frequency of one value (frontend.hip has the notes on its arithmetic; also applied by the pitch decoder when the caller wants the shifted copy)
+__device__ __forceinline__ float shift_frequency_one(float f, float shift) {
+    float r = __fdiv_rn(f, 440.f);
+    r = r < 0.f ? 0.f : r;                       // relu; NaN stays NaN as in F.relu
+    const float lg = (float)log2((double)__fadd_rn(r, 1e-6f));
+    float midi = __fadd_rn(__fmul_rn(lg, 12.f), 69.f);
+    midi = __fadd_rn(midi, shift);
+    const float e = __fdiv_rn(__fsub_rn(midi, 69.f), 12.f);
+    return __fmul_rn(440.f, (float)exp2((double)e));
+}
+
 // The library's own noise phases (noise_angle = NULL): the phase of (utterance row, bin, frame) is a counter-based hash of the call's seed and
 // of those three numbers alone - whatever else is in the batch and however a ragged call is cut into in-kernel batches -, uniform in [-pi, pi).
 __device__ __forceinline__ float noise_phase_hash(unsigned long long seed, int row, int k, int t) {

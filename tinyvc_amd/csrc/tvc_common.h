@@ -225,13 +225,19 @@ int run_stft(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* spec
 int run_stft_fft(tvc_ctx*, hipStream_t, const float* wav, float* spec, int B, int64_t L);
 int run_noise_ifft(tvc_ctx*, hipStream_t, const float* kern, const float* angle, uint64_t seed, float* frames, int B, int T, bool angle_padded = false);      // angle == nullptr: phases drawn in the kernel from `seed`
 // emax (optional, equal-length batches only): per-utterance max of the pooled |x| = max |wav| of the utterance, written (not accumulated)
-int run_energy(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* energy, int B, int64_t L, float* emax = nullptr);
+int run_energy(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* wav, float* energy, int B, int64_t L, float* emax = nullptr, float* spec_bound = nullptr,
+               float* zero = nullptr, int nz = 0);      // (emax given: the pooled-maximum launch also zeroes zero[0 .. nz))
 const float* knn_index_amax(const float* prepared);
 // out[b] = a * in[b * in_stride] + c for b < n: a |max| slot from the slot of the tensor it is a bounded function of (frontend.hip)
-int run_slot_affine(tvc_ctx*, hipStream_t, float* out, const float* in, int in_stride, float a, float c, int n);      // device pointer to the prepared index's |max| (one float)
+int run_slot_affine(tvc_ctx*, hipStream_t, float* out, const float* in, int in_stride, float a, float c, int n);
+int run_slot_prep(tvc_ctx*, hipStream_t, float* zero, int nz, float* o1, const float* in1, int s1, float a1, float c1, float* o2, const float* in2, int s2, float a2,
+                  float c2, int n);
+constexpr int kFilterSlots = 41;      // run_filter's |max| slots per utterance (decoder.hip S_COUNT)
+      // device pointer to the prepared index's |max| (one float)
 // spec_bound (optional): per-utterance upper bounds of |spec| (the slot of the input contraction); nullptr = one pass over spec measures it
 int run_encoder(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* spec, float* ssl, float* f0,
-                float* logits, int B, int T, const float* spec_bound = nullptr);
+                float* logits, int B, int T, const float* spec_bound = nullptr, float* zeroed_slots = nullptr,      // zeroed_slots: 3 x utterances floats already zeroed on this stream
+                float* f0_shifted = nullptr, float shift = 0.f);      // f0_shifted: also shift_frequency(f0, shift)
 int run_pitch_decode(tvc_ctx*, hipStream_t, const float* logits, float* f0, int B, int T);
 int run_knn(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* src, const float* prepared, int64_t N,
             float* out, int64_t* idx_out, int B, int T);
@@ -253,7 +259,8 @@ struct FilterTaps {   // optional copies of FilterNet's block outputs (tvc_filte
 // cmax / smax / the trailing float* of run_dsp: per-utterance |max| slots of content / cat[source, energy] (block-floating-point
 // guard of the fp16 split, conv3s.h); nullptr = the stage computes (or keeps) its own
 int run_filter(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* content, const float* f0, const float* energy,
-               const float* source, float* wave, int B, int T, const FilterTaps* taps = nullptr, const float* cmax = nullptr, const float* smax = nullptr);
+               const float* source, float* wave, int B, int T, const FilterTaps* taps = nullptr, const float* cmax = nullptr, const float* smax = nullptr,
+               float* zeroed_slots = nullptr);      // kFilterSlots x utterances floats the caller has already zeroed on this stream
 int run_dsp(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* f0, const float* amps, const float* kern,
             const float* angle, uint64_t seed, float* source, int B, int T, float* smax = nullptr);
 int run_sola(tvc_ctx*, hipStream_t, const float* y, float* sola_buf, const float* fade_in, float* out, int32_t* shift_out,
