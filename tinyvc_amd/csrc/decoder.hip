@@ -329,7 +329,7 @@ static __global__ void g8_to_planar_kernel(const float* __restrict__ x, float* _
 
 // cmax / smax (nullable): |max| slots of `content` / of cat[source, energy] if the caller already has them
 int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
-               const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps, const float* cmax, const float* smax, float* zeroed_slots) {
+               const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps, const float* cmax, const float* smax, float* zeroed_slots, bool x_slot_set) {
     const long L = (long)T * kHop;
     static const int ch[5] = {384, 192, 96, 48, 24};
     const long len_dn[5] = {L, L / 5, L / 20, L / 80, L / 240};   // skip i lives at len_dn[i]
@@ -347,7 +347,7 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
     enum { S_CONTENT = 0, S_SRC, S_X, S_SKIP0, S_DH1 = S_SKIP0 + 5, S_DH2 = S_DH1 + 4, S_UHA = S_DH2 + 4, S_UX1 = S_UHA + 5, S_UHB = S_UX1 + 5, S_UXU = S_UHB + 5,
            S_LEV = S_UXU + 5, S_COUNT = S_LEV + 5 };
     const int NB = ctx->rag ? ctx->rag->B : B;      // utterances (a ragged batch runs as B = 1, T = all its frames: ragged.h)
-    static_assert(S_COUNT == kFilterSlots, "tvc_common.h kFilterSlots");
+    static_assert(S_COUNT == kFilterSlots && S_X == kFilterSlotX, "tvc_common.h kFilterSlots / kFilterSlotX");
     float* slots = zeroed_slots ? zeroed_slots : ws.get<float>((size_t)S_COUNT * NB);
     auto slot = [&](int i) { return slots + (size_t)i * NB; };
 
@@ -368,7 +368,7 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
         if (!gemm_s2_try(&rc, ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax)) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax);
         TVC_CHECK(rc);
         // x0's |max| slot: the functor finishes the elements, so the slot is the bound bw |content|max + bb instead of a pass over x0
-        TVC_CHECK(run_slot_affine(ctx, s, slot(S_X), cmax, 1, ctx->flt_in_bw, ctx->flt_in_bb, NB));
+        if (!(zeroed_slots && x_slot_set)) TVC_CHECK(run_slot_affine(ctx, s, slot(S_X), cmax, 1, ctx->flt_in_bw, ctx->flt_in_bb, NB));
         // skips[0] is read as FiLM cond only (ups[4]): it is written as the two halves' ready operand; the fp32 tensor exists for the parity tap alone
         TVC_CHECK(run_down0_split(ctx, s, ctx->flt_down0s, source, energy, skip[0], taps ? taps->skips[0] : nullptr, xi_pre[1], B, (int)L, smax, slot(S_SKIP0)));
     }
@@ -460,13 +460,13 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
                 }
             }
             if (C != 48) {   // c5 (1x1, C -> C/2) as a split-precision GEMM launch; its output's |max| slot = the bound c5_bw |xu|max + c5_bb (the functor finishes the elements)
-                EpiBias<ACT_NONE, false> ep{xlev[i], u.c5.bias, nullptr, u.cout, lo, nc, (long)u.cout * lo, 0};
+                // (the launch also writes the level output's slot: the bound c5_bw |xu|max + c5_bb from its input's slot)
+                EpiBias<ACT_NONE, false> ep{xlev[i], u.c5.bias, nullptr, u.cout, lo, nc, (long)u.cout * lo, 0, slot(S_LEV + i), slot(S_UXU + i), u.c5_bw, u.c5_bb, NB};
                 if (u.cout == 48) {   // the 48-channel level output: G8 layout (conv48s.hip's interpolating launch reads 16-byte rows)
-                    EpiBiasG8 eg{xlev[i], u.c5.bias, u.cout, lo, nc};
+                    EpiBiasG8 eg{xlev[i], u.c5.bias, u.cout, lo, nc, slot(S_LEV + i), slot(S_UXU + i), u.c5_bw, u.c5_bb, NB};
                     TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, u.c5, xu, B, C, lo, 0, eg, slot(S_UXU + i))));
                 } else if (u.c5.MT6 % 3 == 0) TVC_CHECK((gemm_s_launch<3, 4, 1>(ctx, s, u.c5, xu, B, C, lo, 0, ep, slot(S_UXU + i))));
                 else TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, u.c5, xu, B, C, lo, 0, ep, slot(S_UXU + i))));
-                TVC_CHECK(run_slot_affine(ctx, s, slot(S_LEV + i), slot(S_UXU + i), 1, u.c5_bw, u.c5_bb, NB));      // bound of the 1x1's output from its input's slot
             }
         }
         ws.release(mk);
@@ -507,7 +507,8 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
     float* fslots = xmax + NB;
     if (!dry) {
         TVC_CHECK(run_slot_prep(ctx, s, cmax, (3 + kFilterSlots) * NB, content_bound ? cmax : nullptr, content_bound, 0, 1.f, 0.f, energy_bound ? smax : nullptr,
-                                energy_bound, 1, 1.f, 0.f, NB));      // (the dsp kernels raise smax to cat[source, energy]'s)
+                                energy_bound, 1, 1.f, 0.f, content_bound ? fslots + (size_t)kFilterSlotX * NB : nullptr, ctx->flt_in_bw, ctx->flt_in_bb,
+                                NB));      // (the dsp kernels raise smax to cat[source, energy]'s; the third: FilterNet's x0 slot from |content|max)
         if (!content_bound) TVC_CHECK(run_amax_rows(ctx, s, content, B, kSslDim, T, cmax));
         if (!energy_bound) TVC_CHECK(run_amax_rows(ctx, s, energy, B, 1, L, smax));
     }
@@ -525,7 +526,7 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
     ws.release(mk);
     if (!dry && !wave) return 0;                 // ... or for Decoder.dsp's output (decoder.py:259-266) without the FilterNet pass
     ProfScope ps(ctx, s, dry, "filter_net");
-    TVC_CHECK(run_filter(ctx, s, ws, dry, content, f0, energy, source, wave, B, T, nullptr, cmax, smax, fslots));
+    TVC_CHECK(run_filter(ctx, s, ws, dry, content, f0, energy, source, wave, B, T, nullptr, cmax, smax, fslots, content_bound != nullptr));
     ws.release(mk);
     return 0;
 }

@@ -76,19 +76,25 @@ int run_slot_affine(tvc_ctx* ctx, hipStream_t s, float* out, const float* in, in
     return launch_check(ctx, "slot_affine");
 }
 // The decoder's slots in one launch: zero[0 .. nz) = 0 (the slots its kernels raise with atomicMax), then the two bounds it is handed:
-// o1[b] = a1 in1[b * s1] + c1, o2[b] = a2 in2[b * s2] + c2 (either pair may be null).  One workgroup.
+// o1[b] = a1 in1[b * s1] + c1, o2[b] = a2 in2[b * s2] + c2 (either pair may be null), and o3[b] = a3 o1[b] + c3 (a bound of a bounded function
+// of the first tensor; null without o1).  One workgroup.
 static __global__ void slot_prep_kernel(float* __restrict__ zero, int nz, float* __restrict__ o1, const float* __restrict__ in1, int s1, float a1, float c1,
-                                        float* __restrict__ o2, const float* __restrict__ in2, int s2, float a2, float c2, int n) {
+                                        float* __restrict__ o2, const float* __restrict__ in2, int s2, float a2, float c2, float* __restrict__ o3, float a3,
+                                        float c3, int n) {
     for (int i = threadIdx.x; i < nz; i += blockDim.x) zero[i] = 0.f;
     __syncthreads();      // (the bounds' slots lie inside the zeroed block)
     for (int b = threadIdx.x; b < n; b += blockDim.x) {
-        if (o1) o1[b] = fmaf(a1, in1[(long)b * s1], c1);
+        if (o1) {
+            const float v1 = fmaf(a1, in1[(long)b * s1], c1);
+            o1[b] = v1;
+            if (o3) o3[b] = fmaf(a3, v1, c3);
+        }
         if (o2) o2[b] = fmaf(a2, in2[(long)b * s2], c2);
     }
 }
 int run_slot_prep(tvc_ctx* ctx, hipStream_t s, float* zero, int nz, float* o1, const float* in1, int s1, float a1, float c1, float* o2, const float* in2, int s2,
-                  float a2, float c2, int n) {
-    hipLaunchKernelGGL(slot_prep_kernel, dim3(1), dim3(256), 0, s, zero, nz, o1, in1, s1, a1, c1, o2, in2, s2, a2, c2, n);
+                  float a2, float c2, float* o3, float a3, float c3, int n) {
+    hipLaunchKernelGGL(slot_prep_kernel, dim3(1), dim3(256), 0, s, zero, nz, o1, in1, s1, a1, c1, o2, in2, s2, a2, c2, o3, a3, c3, n);
     return launch_check(ctx, "slot_prep");
 }
 // emax[b] = max_j e[b][j] (one wavefront per utterance: 1 500 values); spec_bound[b] = 960.5 emax[b] >= every |STFT| bin (the Hann window's sum)

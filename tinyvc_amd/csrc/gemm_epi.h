@@ -78,8 +78,17 @@ struct EpiBias {
     const float* res;
     int M, T, ncols;
     long y_bs, res_bs;  // batch strides
+    // optional: the |max| slot of y as a bound from the slot of the GEMM's input, bound_out[u] = bw bound_in[u] + bb for every utterance u
+    // (the functor finishes the elements, so no maximum is tracked; the one thread that stores element (0, 0) writes all nb of them -
+    // a 64-thread launch of its own otherwise)
+    float* bound_out = nullptr;
+    const float* bound_in = nullptr;
+    float bw = 0.f, bb = 0.f;
+    int nb = 0;
     __device__ __forceinline__ void store(int n, int m, const float v[4]) const {
         if (n >= ncols) return;
+        if (bound_out != nullptr && n == 0 && m == 0)
+            for (int u = 0; u < nb; ++u) bound_out[u] = fmaf(bw, bound_in[u], bb);
         int b = n / T, t = n - b * T;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -99,8 +108,14 @@ struct EpiBiasG8 {
     float* y;
     const float* bias;
     int M, T, ncols;
+    float* bound_out = nullptr;      // (as in EpiBias)
+    const float* bound_in = nullptr;
+    float bw = 0.f, bb = 0.f;
+    int nb = 0;
     __device__ __forceinline__ void store(int n, int m, const float v[4]) const {
         if (n >= ncols || m >= M) return;
+        if (bound_out != nullptr && n == 0 && m == 0)
+            for (int u = 0; u < nb; ++u) bound_out[u] = fmaf(bw, bound_in[u], bb);
         const int b = n / T, t = n - b * T;
         typedef float f32x4e __attribute__((ext_vector_type(4)));
         const f32x4e o = {v[0] + bias[m], v[1] + bias[m + 1], v[2] + bias[m + 2], v[3] + bias[m + 3]};

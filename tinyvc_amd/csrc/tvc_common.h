@@ -231,7 +231,8 @@ const float* knn_index_amax(const float* prepared);
 // out[b] = a * in[b * in_stride] + c for b < n: a |max| slot from the slot of the tensor it is a bounded function of (frontend.hip)
 int run_slot_affine(tvc_ctx*, hipStream_t, float* out, const float* in, int in_stride, float a, float c, int n);
 int run_slot_prep(tvc_ctx*, hipStream_t, float* zero, int nz, float* o1, const float* in1, int s1, float a1, float c1, float* o2, const float* in2, int s2, float a2,
-                  float c2, int n);
+                  float c2, float* o3, float a3, float c3, int n);
+constexpr int kFilterSlotX = 2;       // ... and the one of its input contraction's output (S_X)
 constexpr int kFilterSlots = 41;      // run_filter's |max| slots per utterance (decoder.hip S_COUNT)
       // device pointer to the prepared index's |max| (one float)
 // spec_bound (optional): per-utterance upper bounds of |spec| (the slot of the input contraction); nullptr = one pass over spec measures it
@@ -260,7 +261,8 @@ struct FilterTaps {   // optional copies of FilterNet's block outputs (tvc_filte
 // guard of the fp16 split, conv3s.h); nullptr = the stage computes (or keeps) its own
 int run_filter(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* content, const float* f0, const float* energy,
                const float* source, float* wave, int B, int T, const FilterTaps* taps = nullptr, const float* cmax = nullptr, const float* smax = nullptr,
-               float* zeroed_slots = nullptr);      // kFilterSlots x utterances floats the caller has already zeroed on this stream
+               float* zeroed_slots = nullptr, bool x_slot_set = false);      // zeroed_slots: kFilterSlots x utterances floats the caller has already zeroed on this
+                                                                             // stream; x_slot_set: ... and has set slot kFilterSlotX to flt_in_bw |content|max + flt_in_bb
 int run_dsp(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* f0, const float* amps, const float* kern,
             const float* angle, uint64_t seed, float* source, int B, int T, float* smax = nullptr);
 int run_sola(tvc_ctx*, hipStream_t, const float* y, float* sola_buf, const float* fade_in, float* out, int32_t* shift_out,
