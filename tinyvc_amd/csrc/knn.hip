@@ -529,15 +529,23 @@ static __global__ __launch_bounds__(256) void knn_merge_gather_kernel(const floa
     const int lane = tid & 63, wave = tid >> 6;
     for (int kc = 0; kc < KD; kc += 192) {
         // gather: wave handles queries wave, wave+4, ...; lanes run along k (3 x 64 = 192)
-        for (int q = wave; q < 32; q += 4) {
+        // (four queries' 48 loads in flight per lane: one query at a time was eight serial round trips per wave and chunk - 48 us per
+        // launch whatever the batch, a chain of latencies)
+        for (int q0 = wave; q0 < 32; q0 += 16) {
+            float r[4][3][4];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int k = kc + lane + 64 * u;
-                const float r0 = blob_row_value(blob, kind, N, Npad, sel[q][0], k), r1 = blob_row_value(blob, kind, N, Npad, sel[q][1], k);
-                const float r2 = blob_row_value(blob, kind, N, Npad, sel[q][2], k), r3 = blob_row_value(blob, kind, N, Npad, sel[q][3], k);
-                float sum = __fadd_rn(__fadd_rn(__fadd_rn(r0, r1), r2), r3);
-                tile[q][lane + 64 * u] = sum * 0.25f;
-            }
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[qq][u][e] = blob_row_value(blob, kind, N, Npad, sel[q0 + 4 * qq][e], kc + lane + 64 * u);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const float sum = __fadd_rn(__fadd_rn(__fadd_rn(r[qq][u][0], r[qq][u][1]), r[qq][u][2]), r[qq][u][3]);
+                    tile[q0 + 4 * qq][lane + 64 * u] = sum * 0.25f;
+                }
         }
         __syncthreads();
         // scatter: lanes run along the 32 queries (time), 8 k-rows per pass
