@@ -97,16 +97,20 @@ int run_slot_prep(tvc_ctx* ctx, hipStream_t s, float* zero, int nz, float* o1, c
     hipLaunchKernelGGL(slot_prep_kernel, dim3(1), dim3(256), 0, s, zero, nz, o1, in1, s1, a1, c1, o2, in2, s2, a2, c2, o3, a3, c3, n);
     return launch_check(ctx, "slot_prep");
 }
-// emax[b] = max_j e[b][j] (one wavefront per utterance: 1 500 values); spec_bound[b] = 960.5 emax[b] >= every |STFT| bin (the Hann window's sum)
+// emax[b] = max_j e[b][j] (one workgroup per utterance: 1 500 values); spec_bound[b] = 960.5 emax[b] >= every |STFT| bin (the Hann window's sum)
 // zero[0 .. nz) = 0: the encoder's atomicMax slots, zeroed here instead of by a memset of their own
-static __global__ void pooled_max_kernel(const float* __restrict__ e, int ne, float* __restrict__ emax, float* __restrict__ spec_bound, float* __restrict__ zero, int nz) {
-    for (int i = blockIdx.x * 64 + threadIdx.x; i < nz; i += gridDim.x * 64) zero[i] = 0.f;
+static __global__ __launch_bounds__(256) void pooled_max_kernel(const float* __restrict__ e, int ne, float* __restrict__ emax, float* __restrict__ spec_bound, float* __restrict__ zero, int nz) {
+    __shared__ float red[4];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nz; i += gridDim.x * 256) zero[i] = 0.f;
     const float* p = e + (long)blockIdx.x * ne;
     float m = 0.f;
-    for (int j = threadIdx.x; j < ne; j += 64) m = fmaxf(m, p[j]);
+    for (int j = threadIdx.x; j < ne; j += 256) m = fmaxf(m, p[j]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         emax[blockIdx.x] = m;
         if (spec_bound) spec_bound[blockIdx.x] = fmaf(960.5f, m, 0.f);
     }
@@ -125,7 +129,7 @@ int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, 
         return launch_check(ctx, "energy (ragged)");
     }
     hipLaunchKernelGGL(energy_pool_kernel, dim3(grid_for((long)B * ne * 64)), dim3(256), 0, s, wav, e, B, (int)L, ne);
-    if (emax) hipLaunchKernelGGL(pooled_max_kernel, dim3(B), dim3(64), 0, s, e, ne, emax, spec_bound, zero, nz);
+    if (emax) hipLaunchKernelGGL(pooled_max_kernel, dim3(B), dim3(256), 0, s, e, ne, emax, spec_bound, zero, nz);
     // F.interpolate(e, L): `size` given -> scale = float(in) / float(out)
     float scale = (float)ne / (float)L;
     {
