@@ -925,6 +925,15 @@ static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __
     const float* inv = blob_inv(blob, kind, N, Npad);
     const int b = n / T, t = n - b * T;
     const float* qp = qn + (long)b * KD * T + t;
+    // the list's rows and coarse values are requested together with its length (all C_CAP entries exist; those past the end are masked
+    // below): one round trip instead of three in a kernel that is a chain of them (WAIT 0.64, ACTIVE 0.09)
+    int rowl[C_CAP / 64];
+    float cvl[C_CAP / 64];
+#pragma unroll
+    for (int c = 0; c < C_CAP / 64; ++c) {
+        rowl[c] = cand[(long)n * C_CAP + 64 * c + lane];
+        cvl[c] = candv[(long)n * C_CAP + 64 * c + lane];
+    }
     const int nc = min(cnt[n], C_CAP);
     Top4 t4;
     t4.init();
@@ -933,13 +942,15 @@ static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __
     // with c4 the fourth of them, four rows have exact >= c4 - eps, so a row of the exact top four has exact >= c4 - eps and coarse
     // >= c4 - 2 eps.  Only those are scored (a handful): the 3 KB gather per candidate was the kernel's whole cost.  NaN coarse values are
     // left out of the ranking (a lower c4: more rows kept) and always scored.
-    float cvl[C_CAP / 64];
     float th2;
     {
         float rk[C_CAP / 64];
 #pragma unroll
         for (int c = 0; c < C_CAP / 64; ++c) {
-            cvl[c] = 64 * c + lane < nc ? candv[(long)n * C_CAP + 64 * c + lane] : -INFINITY;
+            if (!(64 * c + lane < nc)) {
+                cvl[c] = -INFINITY;
+                rowl[c] = 0;
+            }
             rk[c] = cvl[c] == cvl[c] ? cvl[c] : -INFINITY;
         }
         float wm = -INFINITY;
@@ -981,7 +992,7 @@ static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __
         // broadcast) and the candidates are scored four at a time: their loads are in flight together instead of one list entry -> one
         // vector -> one reduction after the other (the chain was 2 - 3 us per candidate with nothing else to issue: ACTIVE 0.06).
         for (int base = 0, ch = 0; base < nc; base += 64, ++ch) {
-            const int mine = base + lane < nc ? cand[(long)n * C_CAP + base + lane] : 0;
+            const int mine = ch == 0 ? rowl[0] : (ch == 1 ? rowl[1] : (ch == 2 ? rowl[2] : rowl[3]));
             const float cvv = ch == 0 ? cvl[0] : (ch == 1 ? cvl[1] : (ch == 2 ? cvl[2] : cvl[3]));
             unsigned long long mask = __builtin_amdgcn_ballot_w64(base + lane < nc && !(cvv < th2));      // the entries that pass (NaN does)
             while (mask) {
@@ -1033,7 +1044,7 @@ static __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __
         for (int u = 0; u < 12; ++u) qv[u] = qp[(long)(lane + 64 * u) * T];
         const float* rows = blob + HDR;
         for (int base = 0, ch = 0; base < nc; base += 64, ++ch) {
-            const int mine = base + lane < nc ? cand[(long)n * C_CAP + base + lane] : 0;
+            const int mine = ch == 0 ? rowl[0] : (ch == 1 ? rowl[1] : (ch == 2 ? rowl[2] : rowl[3]));
             const float cvv = ch == 0 ? cvl[0] : (ch == 1 ? cvl[1] : (ch == 2 ? cvl[2] : cvl[3]));
             unsigned long long mask = __builtin_amdgcn_ballot_w64(base + lane < nc && !(cvv < th2));      // the entries that pass (NaN does)
             while (mask) {
