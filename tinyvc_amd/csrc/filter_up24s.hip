@@ -256,7 +256,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
     float mx_run = 0.f;
     int mx_b = bh;
     int slot_b = -1;
-    float slot_x = 0.f, slot_c = 0.f;
+    Bfp sx{1.f, 1.f}, sc{1.f, 1.f}, sh_{1.f, 1.f};
 
     for (; tile < tend; ++tile) {
         U24_STAMP(0);
@@ -270,14 +270,14 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
         }
         // block-floating-point scales: input (per-utterance |max| slot), cond, and the on-chip intermediate h = lrelu(conv_a + b_a),
         // bounded by sum|w_a| * amax_x + max|b_a| (never measured: it does not leave the CU)
-        if (b != slot_b) {      // the utterance's slots: read when the walk enters it (one or two utterances per workgroup), not per tile
+        if (b != slot_b) {      // the utterance's slots and the scales they give: when the walk enters it (one or two utterances per workgroup), not per tile (600 cycles of 11 000)
             slot_b = b;
-            slot_x = a.amax_x ? sload_f32(a.amax_x + b) : 0.f;
-            slot_c = a.amax_c ? sload_f32(a.amax_c + b) : 0.f;
+            const float slot_x = a.amax_x ? sload_f32(a.amax_x + b) : 0.f;
+            const float slot_c = a.amax_c ? sload_f32(a.amax_c + b) : 0.f;
+            sx = a.amax_x ? bfp_from_amax(slot_x) : Bfp{1.f, 1.f};
+            sc = a.amax_c ? norm_from_amax(fmaf(a.cbw, slot_c, a.cbb)) : Bfp{1.f, 1.f};      // the scale down0s_kernel wrote the planes with
+            sh_ = a.amax_x ? bfp_from_amax(fmaf(wl1, slot_x, bamax)) : Bfp{1.f, 1.f};
         }
-        const Bfp sx = a.amax_x ? bfp_from_amax(slot_x) : Bfp{1.f, 1.f};
-        const Bfp sc = a.amax_c ? norm_from_amax(fmaf(a.cbw, slot_c, a.cbb)) : Bfp{1.f, 1.f};      // the scale down0s_kernel wrote the planes with
-        const Bfp sh_ = a.amax_x ? bfp_from_amax(fmaf(wl1, slot_x, bamax)) : Bfp{1.f, 1.f};
         const int t0 = rt.tin * W;
         const int ph0 = t0 - E - D2;      // position of Hs column 0
         const int p20 = t0 - E;           // position of second-conv column 0
@@ -305,16 +305,23 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 cq[1][p] = ldg_so4(cb + (long)(3 * p + 2) * rs, o1);
             }
         }
-        if (next < tend) fetch(next);   // lands in registers during the whole tile
         U24_STAMP(1);
 
         // ---- S1: Hs = split(lrelu(conv_a(lrelu(x)) + ba)) ---------------------------------------------
+        // The next tile's input is requested behind the wave's first group of MFMAs: the loads are independent of everything in this
+        // tile and land in registers during it, but ISSUING them is 1 200 - 1 600 cycles of the address path (eight waves x eight 16-byte loads
+        // behind the previous tile's stores), a phase of its own when it sat in front of S1 with the matrix pipe idle.
+        bool fetched = false;
         for (int nt = wave; nt < CF::NT1; nt += CF::NWAVES) {
             f32x16 acc, alo;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = alo[r] = 0.f;
             const int h = nt * 32 + l31;
             conv24_phase<XP, D1>(acc, alo, Xs, Wt, h, 0, XW - 1, lane);      // Xs already holds the replicate-padded input
+            if (!fetched) {
+                fetched = true;
+                if (next < tend) fetch(next);
+            }
             const float c = wsa * sx.inv, cl = c * kLoInv;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
@@ -337,6 +344,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(U24S_WPE
                 *reinterpret_cast<u32x4*>(Hs + (3 * lh + g) * HP + h) = row;
             }
         }
+        if (!fetched && next < tend) fetch(next);
         U24_STAMP(2);
         slab_barrier();
         U24_STAMP(3);

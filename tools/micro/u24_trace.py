@@ -21,7 +21,7 @@ buf = (ctypes.c_ulonglong * (2 * 4 * 64))()
 lib.tvc_debug_trace_u24.argtypes = [ctypes.c_void_p]
 assert lib.tvc_debug_trace_u24(buf) == 0
 tr = np.frombuffer(buf, dtype=np.uint64).reshape(2, 4, 64)
-names = {0: "top", 1: "cond+fetch issued", 2: "S1 done", 3: "barrier", 4: "S2 done", 5: "barrier(S4)", 6: "S4 done", 7: "barrier", 8: "deposit done"}
+names = {9: "scales", 10: "cond issued", 0: "top", 1: "cond+fetch issued", 2: "S1 done", 3: "barrier", 4: "S2 done", 5: "barrier(S4)", 6: "S4 done", 7: "barrier", 8: "deposit done"}
 for half in range(2):
     print("half", "AB"[half])
     for slot, w in enumerate((0, 1, 4, 7)):
@@ -38,4 +38,4 @@ for half in range(2):
                 acc.setdefault(k, []).append(t - prev)
             prev = t
         tot = sum(sum(v) / len(v) for v in acc.values())
-        print(f"  wave {w}: " + "  ".join(f"{names[k]} {sum(v) / len(v):.0f}" for k, v in sorted(acc.items())) + f"   | tile {tot:.0f} cycles")
+        print(f"  wave {w}: " + "  ".join(f"{names[k]} {sum(v) / len(v):.0f}" for k, v in acc.items()) + f"   | tile {tot:.0f} cycles")
