@@ -177,10 +177,11 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
     bh = utt(tile);
     fetch(tile);
     deposit(bfp_load_u(a.amax_x, bh).s);
-    if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
     float mx_run = 0.f;
     int mx_b = bh;
+    int sc_b = -1;      // the utterance whose scales sx / sc hold: computed when the walk enters it, not per tile
+    Bfp sx{1.f, 1.f}, sc{1.f, 1.f};
 
     for (; tile < tend; ++tile) {
         const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
@@ -191,7 +192,11 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
             mx_run = 0.f;
             mx_b = b;
         }
-        const Bfp sx = bfp_load_u(a.amax_x, b), sc = FILM ? bfp_load_u(a.amax_c, b) : Bfp{1.f, 1.f};
+        if (b != sc_b) {
+            sc_b = b;
+            sx = bfp_load_u(a.amax_x, b);
+            sc = FILM ? bfp_load_u(a.amax_c, b) : Bfp{1.f, 1.f};
+        }
         const int t0 = rt.tin * BN;
         const int next = tile + 1;
         const int n = nt * 32 + l31;
@@ -264,6 +269,10 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // The next tile's input is requested here, behind the conv's MFMAs (issuing the loads is a phase of the address path: between the
+        // closing barriers it ran with the matrix pipe idle); unconditional - the last tile re-reads itself - so that the waits for the
+        // older cond / residual loads stay exact counts.
+        fetch(next < tend ? next : tile);
         {   // the conv result without its bias
             const float c = cw * sx.inv, cl = c * kLoInv;
 #pragma unroll
@@ -402,11 +411,11 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(FILM ? 2 
                 mx_run = fmaxf(mx_run, m5);
             }
         }
-        // ---- next tile's input: registers -> LDS, then request the one after --------------------------------
+        // ---- next tile's input: registers -> LDS ---------------------------------------------------------------
         slab_barrier();                                   // every wave is done reading Xs
         if (next < tend) {
-            deposit(bfp_load_u(a.amax_x, utt(next)).s);
-            if (next + 1 < tend) fetch(next + 1);
+            const int bn = utt(next);
+            deposit(bn == b ? sx.s : bfp_load_u(a.amax_x, bn).s);
         }
         slab_barrier();
     }
@@ -562,10 +571,11 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
     bh = utt(tile);
     fetch(tile);
     deposit(bfp_load_u(a.amax_x, bh).s);
-    if (tile + 1 < tend) fetch(tile + 1);
     slab_barrier();
     float mx_run = 0.f;
     int mx_b = bh;
+    int sc_b = -1;      // the utterance whose scales sx / sc hold: computed when the walk enters it, not per tile
+    Bfp sx{1.f, 1.f}, sc{1.f, 1.f};
 
     for (; tile < tend; ++tile) {
         const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
@@ -576,7 +586,11 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
             mx_run = 0.f;
             mx_b = b;
         }
-        const Bfp sx = bfp_load_u(a.amax_x, b), sc = FILM ? bfp_load_u(a.amax_c, b) : Bfp{1.f, 1.f};
+        if (b != sc_b) {
+            sc_b = b;
+            sx = bfp_load_u(a.amax_x, b);
+            sc = FILM ? bfp_load_u(a.amax_c, b) : Bfp{1.f, 1.f};
+        }
         const int t0 = rt.tin * BNO;
         const int next = tile + 1;
         const int n = nt * 32 + l31;                       // this lane's column: of h in the first conv, of the output in the second
@@ -636,6 +650,7 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        fetch(next < tend ? next : tile);      // the next tile's input, requested behind the first conv's MFMAs (conv48s_kernel has the note)
         // h = lrelu(conv_a + b_a); its tile |max| -> LDS; after the barrier: pre-scale, split, rows [part][group 4 mt + g][column]
         float hv[4][4];
         float hmx = 0.f;
@@ -774,11 +789,11 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
             }
             mx_run = fmaxf(mx_run, mx);
         }
-        // ---- next tile's input: registers -> LDS, then request the one after ------------------------------------------------
+        // ---- next tile's input: registers -> LDS -------------------------------------------------------------------------------
         slab_barrier();                                   // every wave is done reading Xs and Hs
         if (next < tend) {
-            deposit(bfp_load_u(a.amax_x, utt(next)).s);
-            if (next + 1 < tend) fetch(next + 1);
+            const int bn = utt(next);
+            deposit(bn == b ? sx.s : bfp_load_u(a.amax_x, bn).s);
         }
         slab_barrier();
     }
