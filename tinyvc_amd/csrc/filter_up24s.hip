@@ -884,6 +884,8 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
     const int len2 = rs >> 2;            // row stride of the 1/4-rate copy
     float mx_run = 0.f;
     int mx_b = bh;
+    int sc_b = -1;
+    Sc sc{};
     for (; tile < tend; ++tile, cur ^= 1) {
         const RagTile rt = rag_tile<RAG>(a.rag, tile, a.tiles_per_utt, rs, bh);
         const int b = rt.b, len = rt.len;
@@ -895,9 +897,14 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
         }
         const int t0 = rt.tin * W;
         const int next = tile + 1, next2 = next + 1;
-        if (next < tend) deposit(cur ^ 1, bfp_load_u(a.amax_x, utt(next)).s);   // tile i + 1 (requested one tile ago) -> the other buffer
-        if (next2 < tend) fetch(next2);                        // tile i + 2 flies across this tile
-        const Sc sc = scales(b);
+        if (b != sc_b) {      // the utterance's scales: when the walk enters it, not per tile
+            sc_b = b;
+            sc = scales(b);
+        }
+        if (next < tend) {      // tile i + 1 (requested one tile ago) -> the other buffer
+            const int bn = utt(next);
+            deposit(cur ^ 1, bn == b ? sc.x.s : bfp_load_u(a.amax_x, bn).s);
+        }
         const int n = wave * 32 + l31;                         // this lane's column of every conv's tile
         const int t = t0 + n;                                  // ... = the output position of c3's
         const bool live = n < W && t < len;
@@ -915,6 +922,7 @@ static __global__ __launch_bounds__(D24F::NT) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = alo[r] = 0.f;
             conv24_phase<XP, 1>(acc, alo, Xs + cur * 6 * XP, W1, n, 0, XW - 1, lane);       // Xs holds the replicate-padded input
+            fetch(next2 < tend ? next2 : tile);      // tile i + 2 flies across this tile; requested behind c1's MFMAs (up24s_kernel has the note), the last tiles re-read themselves
             to_tile(acc, alo, Bi[62] * sc.x.inv, Bi, sc.h1.s, H1, n);
         }
         slab_barrier();
