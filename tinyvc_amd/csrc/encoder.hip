@@ -443,7 +443,13 @@ int run_encoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* spec
     char* ssl_blk = ws.get<char>(ssl_scratch);
     Ws wssl(ssl_blk, ssl_scratch, dry);
     hipStream_t sp = s;
-    const bool fork = !dry && ctx->side;
+    bool fork = !dry && ctx->side;
+    if (fork) {
+        // Not while the stream is being captured: a replayed graph with the second branch is slower than the one chain (32-stream block
+        // 1.90 -> 1.71 ms; one 4 s utterance 1.36 ... 1.59 ms from box to box with the branch, 1.43 without)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) fork = false;
+    }
     if (fork) {
         TVC_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
         TVC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
