@@ -44,7 +44,7 @@ def test_force_dist_rehearses_the_multi_gpu_branch_at_world_size_1():
     assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1 and j["forced_dist_rehearsal"] is True
     assert "configs[3]" in j["config"]["workload"] and j["config"]["index_vectors"] == 100000
     assert j["gather_ms"] is not None and j["gather_ms"] > 0 and j["gather_bytes_per_rank"] == 64 * 96000 * 4
-    assert j["n1_same_workload_value"] > 0 and 0.5 < j["scaling_efficiency"] <= 1.05
+    assert j["n1_same_workload_value"] > 0 and 0.5 < j["scaling_efficiency"] <= 1.25      # (two 3-step timings of the same work at world size 1: a sanity range, not a measurement)
     assert j["value"] > 3.2e6                       # north_star's 200x real time, by a wide margin
     p = j["parity"]
     assert p["knn_idx_equal"] and p["rms_vs_golden_max"] <= 1e-4 and p["ok"], p
