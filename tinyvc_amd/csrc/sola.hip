@@ -61,7 +61,8 @@ static __device__ void phase_vocoder_block(const float* a, const float* b, const
 static __global__ __launch_bounds__(256) void sola_corr_kernel(const float* __restrict__ y, const float* __restrict__ sola_buf,
                                                                float* __restrict__ part, long Ly, int block) {
     constexpr int LPG = (SEARCH + 1 + kSolaGroups - 1) / kSolaGroups;     // 241 lags per group
-    __shared__ float ci[LPG + CROSS], sq[LPG + CROSS], sb[CROSS];
+    __shared__ float ci[LPG + CROSS];
+    __shared__ __attribute__((aligned(16))) float sb[CROSS];
     __shared__ float bestv[4];
     __shared__ int besti[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,9 +72,7 @@ static __global__ __launch_bounds__(256) void sola_corr_kernel(const float* __re
     const float* tw = y + (long)st * Ly + (Ly - tw_len - DELAY) + lag0;
     const int nload = (lag0 + LPG + CROSS <= CROSS + SEARCH ? LPG + CROSS : CROSS + SEARCH - lag0);
     for (int i = tid; i < LPG + CROSS; i += 256) {
-        const float v = i < nload ? tw[i] : 0.f;
-        ci[i] = v;
-        sq[i] = v * v;
+        ci[i] = i < nload ? tw[i] : 0.f;
     }
     for (int i = tid; i < CROSS; i += 256) sb[i] = sola_buf[(long)st * CROSS + i];
     __syncthreads();
@@ -82,12 +81,22 @@ static __global__ __launch_bounds__(256) void sola_corr_kernel(const float* __re
     const int lag = lag0 + tid;
     if (tid < LPG && lag <= SEARCH) {
         float nom = 0.f, den = 0.f;
+        // (the loop is LDS-bound - three 4-byte reads per term for four waves -: the buffer's four values come as one 16-byte broadcast read
+        // and the square is taken in a register; same products and sums in the same order)
         const float* c = ci + tid;
-        const float* q = sq + tid;
-#pragma unroll 8
-        for (int j = 0; j < CROSS; ++j) {
-            nom = fmaf(c[j], sb[j], nom);
-            den += q[j];
+        static_assert(CROSS % 4 == 0, "four terms per broadcast read");
+#pragma unroll 2
+        for (int j = 0; j < CROSS; j += 4) {
+            const float4 b4 = *reinterpret_cast<const float4*>(sb + j);
+            const float c0 = c[j], c1 = c[j + 1], c2 = c[j + 2], c3 = c[j + 3];
+            nom = fmaf(c0, b4.x, nom);
+            den = __fadd_rn(den, __fmul_rn(c0, c0));
+            nom = fmaf(c1, b4.y, nom);
+            den = __fadd_rn(den, __fmul_rn(c1, c1));
+            nom = fmaf(c2, b4.z, nom);
+            den = __fadd_rn(den, __fmul_rn(c2, c2));
+            nom = fmaf(c3, b4.w, nom);
+            den = __fadd_rn(den, __fmul_rn(c3, c3));
         }
         bv = nom / sqrtf(den + 1e-8f);
         bi = lag;
