@@ -385,7 +385,7 @@ __global__ __launch_bounds__((Cnx2<C, KPASS>::NTHR)) void cnx2_kernel(CnxArgs a)
     uint4* Ys = smem_c2;
     float* Fl = reinterpret_cast<float*>(smem_c2 + CF::YS_U4);      // GRN factors of this utterance [2C], then 32 floats of exchange
     float* red = Fl + K;
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
     int Tb = a.T;
@@ -474,6 +474,8 @@ __global__ __launch_bounds__((Cnx2<C, KPASS>::NTHR)) void cnx2_kernel(CnxArgs a)
     }
     slab_barrier();
     sx = bfp_from_amax(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));      // |h * factor| <= max_c gx[c] |f[c]|
+    sx.s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx.s)));       // (uniform: two scalar registers instead of two vector ones held across both K passes)
+    sx.inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx.inv)));
     deposit(0);
     if (KPASS == 2) fetch(1);                                       // lands under the first pass's MFMAs
     slab_barrier();
@@ -512,6 +514,9 @@ __global__ __launch_bounds__((Cnx2<C, KPASS>::NTHR)) void cnx2_kernel(CnxArgs a)
         }
         // epilogue: EpiBias<ACT_NONE, true> (bias' = c3.bias + c3.weight . grn.beta), residual = the layer's input, in place
         const float cw = a.wsc[mt] * sx.inv, cl = cw * kLoInv;
+        int el = tid;
+        asm volatile("" : "+v"(el));      // (the epilogue's lane-derived indices are recomputed here instead of living - spilled, at K = 768 - across the MFMA walks)
+        const int l31 = el & 31, lh = (el >> 5) & 1;
         float bv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) bv[r] = a.bias[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];

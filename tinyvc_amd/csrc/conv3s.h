@@ -165,9 +165,11 @@ __device__ __forceinline__ float wave_max(float mx) {
 // every thread of the workgroup calls it (it contains a barrier); red = LDS scratch of >= (workgroup waves) floats
 __device__ __forceinline__ void amax_flush_wg(float* slot, float mx, float* red) {
     mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));      // (the LDS address below is not worth a register held - or spilled - across the caller's tile loop)
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         float m = 0.f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
         if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));
@@ -297,9 +299,13 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
     // c2b = frame -> utterance for GEMM tiles over the whole batch (the per-utterance scale is then the column's, as on flat tiles)
     const int rs = rs_ ? rs_ : len;
     const int xw = TL::BN + 2 * dil;
+    // (the thread index is laundered: the map depends on it and on launch constants only, so the compiler would compute the items' (group, column)
+    // once per kernel and keep them - then spill them - across every tile's MFMA phases; recomputing them per phase costs a few instructions)
+    int tid0 = threadIdx.x;
+    asm volatile("" : "+v"(tid0));
 #pragma unroll
     for (int i = 0; i < TL::X_PER; ++i) {
-        int idx = threadIdx.x + i * TL::NTHR;
+        int idx = tid0 + i * TL::NTHR;
         int gk = idx / xw, c = idx - gk * xw;                // gk = 2 * (channel group) + (8-channel half)
         int p = t0 - dil + c;
         p = p < 0 ? 0 : (p > len - 1 ? len - 1 : p);
@@ -333,12 +339,13 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
 // global -> registers only (no use of the values here: the loads stay in flight behind the MFMAs)
 template <class TL, int TAPS, bool LERP = false, bool CLAMP = false>
 __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m, const uint4* __restrict__ A6, int MT, int mt0,
-                                          const float* __restrict__ xb, int Cin, int len, int s, int fT = 0, int cmax = 0, int lin = 0, int rs_ = 0) {
+                                          const float* __restrict__ xb, int Cin, int len, int s, int fT = 0, int cmax = 0, int lin = 0, int rs_ = 0, int tid_ = -1) {
     constexpr int MTB = TL::MTB, NW = TL::NW, X_PER = TL::X_PER, STEPS = TAPS * TL::KG;
     const int cs = LERP ? lin : (fT > 0 ? fT : (rs_ ? rs_ : len));     // channel stride
     constexpr int PIECES = STEPS * MTB * kParts, A_PER = (PIECES + NW - 1) / NW;
     static_assert(A_PER <= SlabRegs<TL>::A_MAX, "weight pieces must fit the staging registers");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = tid_ >= 0 ? tid_ : (int)threadIdx.x;      // (split_phase passes its laundered copy: the piece offsets live for one phase, not across the tile loop)
+    const int lane = tid & 63, wave = tid >> 6;
     const int ci0 = s * 16 * TL::KG;
     {
         const uint4* a_src = A6 + (long)mt0 * kPU4;
@@ -385,7 +392,9 @@ __device__ __forceinline__ void first_load(SlabRegs<TL>& r, const uint4* __restr
                                            float lscale = 0.f, int rs_ = 0) {
     SlabMap<TL> m;
     make_map<TL, LERP>(m, len, dil, t0, fT, fstride, 0, lin, lscale, 1.f, nullptr, rs_);
-    slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT, cmax, lin, rs_);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, 0, fT, cmax, lin, rs_, tid);
 }
 
 // (hi, lo) += W (.) x over all slabs of one input tensor (hi: the h1 w1 products, lo: h1 w2 + h2 w1 in units of 2^-11).
@@ -401,7 +410,11 @@ __device__ __forceinline__ void split_phase(f32x16 (&hi)[TL::WM][TL::WN], f32x16
                                             const float* Ks = nullptr, int fT = 0, unsigned fstride = 0, int cmax = 0, int lin = 0, float lscale = 0.f,
                                             int mt0b = 0, Mid mid = Mid(), const float* amax = nullptr, int rs_ = 0, const int* __restrict__ c2b = nullptr, int cmult = 1) {
     constexpr int MTB = TL::MTB, WM = TL::WM, WN = TL::WN, NWV = TL::NWV, NW = TL::NW, XROW = TL::XROW, X_PER = TL::X_PER;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (laundered thread index: everything derived from it - piece offsets, LDS fragment addresses - is recomputed per phase instead of being
+    // hoisted out of the persistent tile loop, kept live across every other phase and spilled)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NWV, wn = wave - wm * NWV;
     SlabMap<TL> m;
@@ -454,8 +467,8 @@ __device__ __forceinline__ void split_phase(f32x16 (&hi)[TL::WM][TL::WN], f32x16
         lstore(TWO && s >= nslab1 ? s - nslab1 : s);   // slab s: registers -> LDS
         TR_STAMP(r, 2);
         if (s + 1 < nslab) {                       // flies across this slab's MFMAs
-            if (TWO) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, s + 1 >= nslab1 ? mt0b : mt0, xb, Cin, len, s + 1 >= nslab1 ? s + 1 - nslab1 : s + 1, fT, cmax, lin, rs_);
-            else slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin, rs_);
+            if (TWO) slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, s + 1 >= nslab1 ? mt0b : mt0, xb, Cin, len, s + 1 >= nslab1 ? s + 1 - nslab1 : s + 1, fT, cmax, lin, rs_, tid);
+            else slab_load<TL, TAPS, LERP, CLAMP>(r, m, A6, MT, mt0, xb, Cin, len, s + 1, fT, cmax, lin, rs_, tid);
         } else next();
         TR_STAMP(r, 3);
         slab_barrier();
@@ -881,7 +894,7 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
     float mx_run = 0.f;                  // this wave's |max| of what it stored for utterance mx_b
     int mx_b = b;
     float* const red = reinterpret_cast<float*>(smem_s) + TL::bias_off(TAPS) + 12 * TL::BM + TL::KS_MAX;
-    const int fT = a.flatT;
+    const int fT = (TAPS == 1 && !FILM && !LERP && !RAGT) ? a.flatT : 0;      // flat column tiles are a property of the plain-GEMM launches (conv3s_launch_t checks): the convs compile without that path
     const unsigned fstride = (unsigned)a.xstride;
     // narrow FiLM tiles run their FiLM phase FIRST (scale and shift pairs: 4 accumulator sets, folded to 2 before the conv's pair comes
     // alive: 4 sets at the peak instead of 5, which did not fit the 168 registers of a 12-wave workgroup)
@@ -954,14 +967,23 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
         clear(hi);
         clear(lo);
         // hi <- (hi + 2^-11 lo) * wscale(row) * inv  (the conv result without its bias); wtab = the per-row weight-scale table
+        // (the row tables are read four rows at a time behind a compiler fence: left alone, the scheduler hoists every table read of the
+        // epilogue - 64 values per lane on the FiLM tiles - above the arithmetic and spills them)
         auto fold = [&](f32x16 (&h)[WM][WN], const f32x16 (&l)[WM][WN], const float* wtab, float inv) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float c = wtab[rl + i * 32 + (r & 3) + 8 * (r >> 2)] * inv, cl = c * kLoInv;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(wtab + rl + i * 32 + 8 * q);
+                    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) h[i][j][r] = comb(h[i][j][r], l[i][j][r], c, cl);
+                    for (int u = 0; u < 4; ++u) {
+                        const float c = wv[u] * inv, cl = c * kLoInv;
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) h[i][j][4 * q + u] = comb(h[i][j][4 * q + u], l[i][j][4 * q + u], c, cl);
+                    }
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(h[i][j]) : : "memory");
                 }
         };
 
@@ -1031,12 +1053,18 @@ __global__ __launch_bounds__(TL::NTHR) __attribute__((amdgpu_waves_per_eu(FILM ?
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = rl + i * 32 + (r & 3) + 8 * (r >> 2);
-                        const float bm = Bs[row], bs = Bs[TL::BM + row], bh = Bs[2 * TL::BM + row];
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = rl + i * 32 + 8 * q;
+                        const float4 m4 = *reinterpret_cast<const float4*>(Bs + row), s4 = *reinterpret_cast<const float4*>(Bs + TL::BM + row),
+                                     h4 = *reinterpret_cast<const float4*>(Bs + 2 * TL::BM + row);
+                        const float bm[4] = {m4.x, m4.y, m4.z, m4.w}, bs[4] = {s4.x, s4.y, s4.z, s4.w}, bh[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
-                        for (int j = 0; j < WN; ++j)
-                            hi[i][j][r] = __fadd_rn(__fmul_rn(hi[i][j][r] + bm, asc[i][j][r] + bs), ash[i][j][r] + bh);
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int j = 0; j < WN; ++j)
+                                hi[i][j][4 * q + u] = __fadd_rn(__fmul_rn(hi[i][j][4 * q + u] + bm[u], asc[i][j][4 * q + u] + bs[u]), ash[i][j][4 * q + u] + bh[u]);
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(hi[i][j]) : : "memory");
                     }
                 tile_store<TL, true>(reinterpret_cast<float*>(smem_s), hi, ep.y, ep.res, RAGT ? 0 : b, ep.M, len, mt0, t0, mx_run, nullptr, 0, ep.res_lin, ep.res_scale, rs, coloff);
             }

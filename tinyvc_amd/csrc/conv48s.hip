@@ -513,7 +513,10 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         }
     }
     if (tid == 0) Bi[256] = 0.f;
-    const float cwa = a.wsc_a[mt], cwb = a.wsc_b[mt], cwsc = FILM ? a.fsc[mt] : 1.f, cwsh = FILM ? a.fsc[2 + mt] : 1.f;
+    // (wave-uniform: read through the scalar cache into scalar registers - as vector registers the four were spilled by the FiLM instantiation and
+    // reloaded, s_waitcnt vmcnt(0), in the middle of every tile)
+    const int mtu = __builtin_amdgcn_readfirstlane(mt);
+    const float cwa = a.wsc_a[mtu], cwb = a.wsc_b[mtu], cwsc = FILM ? a.fsc[mtu] : 1.f, cwsh = FILM ? a.fsc[2 + mtu] : 1.f;
 
     // staging items (8-channel group, column): 6 * XW <= 816 of them, two per thread
     constexpr int XPER = 2;
@@ -549,9 +552,15 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
         }
     };
     auto deposit = [&](float xs) __attribute__((always_inline)) {
+        // (the items' LDS rows are recomputed from a laundered thread index: as kernel-long invariants they were spilled, and their reload -
+        // s_waitcnt vmcnt(0) - waited for the tile's stores)
+        int td = tid;
+        asm volatile("" : "+v"(td));
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
-            if (ig[i] > 5) continue;
+            const int idx = td + i * NT;
+            const int g = idx / XW, c = idx - g * XW;
+            if (g > 5) continue;
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -560,8 +569,8 @@ __global__ __launch_bounds__(kNT48) __attribute__((amdgpu_waves_per_eu(2))) void
             }
             uint4 p1, p2;
             split8(v, p1, p2);
-            Xs[(0 + ig[i]) * XP + ic[i]] = __builtin_bit_cast(u32x4, p1);
-            Xs[(6 + ig[i]) * XP + ic[i]] = __builtin_bit_cast(u32x4, p2);
+            Xs[(0 + g) * XP + c] = __builtin_bit_cast(u32x4, p1);
+            Xs[(6 + g) * XP + c] = __builtin_bit_cast(u32x4, p2);
         }
     };
 

@@ -109,14 +109,19 @@ __global__ __launch_bounds__(FS2T<NWV_>::NTHR) __attribute__((amdgpu_waves_per_e
     u32x4 ar[A_PER];
     float xr[XPRE ? 1 : XS][8], cr[8];
     uint4 xq[XPRE ? XS : 1][2];          // XPRE: the two parts of an item, as stored
-    int ig[XS], ic[XS], xdst[XS];
+    // (an item's (half, column) pair is needed once per tile - tile_offsets recomputes it from a laundered thread index -; only its LDS row lives across the steps)
+    auto item_of = [&](int t_, int k, int& g, int& c) __attribute__((always_inline)) {
+        int item = t_ + k * TL::NTHR;
+        item = item < nitems ? item : item - nitems;
+        g = item / xw;
+        c = item - g * xw;
+    };
+    int xdst[XS];
 #pragma unroll
     for (int k = 0; k < XS; ++k) {
-        int item = tid + k * TL::NTHR;
-        item = item < nitems ? item : item - nitems;
-        ig[k] = item / xw;
-        ic[k] = item - ig[k] * xw;
-        xdst[k] = ig[k] * XROW + ic[k];
+        int g, c;
+        item_of(tid, k, g, c);
+        xdst[k] = g * XROW + c;
     }
     const int cg = tid >= BN ? 1 : 0, cc = tid - cg * BN;      // (NTHR = 2 BN)
     const int cdst = cg * BN + cc;
@@ -127,11 +132,15 @@ __global__ __launch_bounds__(FS2T<NWV_>::NTHR) __attribute__((amdgpu_waves_per_e
     coords(lv, lmb, lb, lt0, llen, loff);
     auto tile_offsets = [&]() __attribute__((always_inline)) {
         const int ub = RAG ? loff : 0;             // RAG: the utterance's first column rides in the lane offsets
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
 #pragma unroll
         for (int k = 0; k < XS; ++k) {
-            int p = lt0 - dil + ic[k];
+            int g, c;
+            item_of(tl, k, g, c);
+            int p = lt0 - dil + c;
             p = p < 0 ? 0 : (p > llen - 1 ? llen - 1 : p);
-            xo[k] = (unsigned)(8 * ig[k] * rs + ub + p);
+            xo[k] = (unsigned)((XPRE ? 1 : 8) * g * rs + ub + p);      // XPRE: row g of the slab's two plane rows (16-byte elements); else channel 8 g of its sixteen
         }
         int pc = lt0 + cc;
         pc = pc > llen - 1 ? llen - 1 : pc;
@@ -151,11 +160,11 @@ __global__ __launch_bounds__(FS2T<NWV_>::NTHR) __attribute__((amdgpu_waves_per_e
         const long ubase = RAG ? 0L : (long)lb * C;
         const float* xc = a.x + (ubase + (long)ls * 16) * rs;
         const float* cc_ = a.cond + (ubase + (long)ls * 16) * rs;
-        if (XPRE) {      // item (8-channel half ig, column): one 16-byte load per part; xo = 8 ig rs + p -> plane row 2 ls + ig, column p
+        if (XPRE) {      // item (8-channel half g, column p): one 16-byte load per part; xo = g rs + p -> plane row 2 ls + g, column p
             const uint4* xp = a.xpre + ((RAG ? 0L : (long)lb * 2 * (C >> 3)) + 2 * ls) * rs;
 #pragma unroll
             for (int k = 0; k < XS; ++k) {
-                const unsigned e = xo[k] - (unsigned)(7 * ig[k] * rs);            // = ig rs + p
+                const unsigned e = xo[k];
                 xq[k][0] = __builtin_bit_cast(uint4, ldg_so4(xp, 16u * e));
                 xq[k][1] = __builtin_bit_cast(uint4, ldg_so4(xp + (long)(C >> 3) * rs, 16u * e));
             }
