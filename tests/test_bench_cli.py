@@ -59,5 +59,6 @@ def test_default_line_carries_parity_roofline_and_cpu_baseline_keys():
     p = j["parity"]
     assert "timed" in p["checked"] and len(p["rms_vs_golden"]) == 4
     assert p["knn_idx_equal"] and p["knn_idx_mismatches"] == 0 and p["rms_vs_golden_max"] <= 1e-4 and p["ok"], p
+    assert p["drawn_equals_injected_hash"] is True, "the timed instantiation (phases drawn in-kernel) must equal the injected restatement of its hash"
     rf = j["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1 and rf["launch_ms"] > 0

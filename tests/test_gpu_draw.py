@@ -1,0 +1,106 @@
+"""The instantiation the bench times: `convert(noise_angle=None)` draws the decoder's noise phases INSIDE noise_ifft_kernel<DRAW = true>
+(csrc/fft.hip, noise_phase_hash in csrc/small_kernels.h) instead of reading a phase tensor.  Every other parity test injects `noise_angle`
+and so runs noise_ifft_kernel<false>.  Here the draw is pinned from both sides:
+  (a) the drawn call equals, sample for sample, the injecting call fed with the hash restated on the host (tinyvc_amd/synth.py) - equal
+      batch, ragged batch, B = 1;
+  (b) the oracle (the reference's arithmetic) on those phases is within 1e-4;
+  (c) the phases are what decoder.py:78 draws: uniform on [-pi, pi) - two moments and a 64-bin histogram over 961 x 200 x 64 values.
+Reference: module/tinyvc/decoder.py:78 (`angle = torch.rand(...) * 2 * math.pi - math.pi`)."""
+import math
+
+import pytest
+import torch
+
+from helpers import oracle_one_thread, rms, state_dicts
+from oracle import ref_cpu as R
+from tinyvc_amd import synth
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gen():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from tinyvc_amd.module.infer import Generator
+    from tinyvc_amd.module.tinyvc import Decoder, Encoder
+    enc_sd, dec_sd = state_dicts(0)
+    enc, dec = Encoder(), Decoder()
+    enc.load_state_dict(enc_sd)
+    dec.load_state_dict(dec_sd)
+    return Generator(enc, dec).to(DEV)
+
+
+def seed_of_next_draw():
+    """What Engine._angle will hand the library for the NEXT drawing call on cuda:0 (restated: generator state -> 64-bit seed)."""
+    g = torch.cuda.default_generators[0]
+    return synth.draw_seed(g.initial_seed(), g.get_offset())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(1, 28), (3, 50), (1, 200), (5, 140)])
+def test_drawn_call_equals_the_injected_hash_and_the_oracle(gen, B, T):
+    enc_sd, dec_sd = state_dicts(0)
+    L = 480 * T
+    wf = synth.synth_wave(B, L, seed=40 + B)
+    tgt = synth.synth_index(600, seed=8)
+    torch.manual_seed(1000 + T)
+    seed = seed_of_next_draw()
+    drawn = gen.convert(wf.to(DEV), tgt.to(DEV), 0.5)                              # noise_ifft_kernel<true>
+    assert seed_of_next_draw() != seed, "a drawing call advances the generator like a torch.rand draw"
+    angle = synth.noise_phase_hash(seed, range(B), T)
+    injected = gen.convert(wf.to(DEV), tgt.to(DEV), 0.5, noise_angle=angle.to(DEV))      # noise_ifft_kernel<false>
+    assert torch.equal(drawn, injected), f"B = {B}, T = {T}: the library's draw is not the restated hash"
+    with oracle_one_thread():
+        ref = R.convert(enc_sd, dec_sd, wf[:1], tgt, 0.5, angle[:1])
+    d = rms(drawn[0].cpu() - ref[0])
+    print(f"[draw] B = {B}, T = {T}: drawn == injected(hash); row 0 vs the oracle on the drawn phases {d:.3e}")
+    assert d <= 1e-4, d
+
+
+@pytest.mark.gpu
+def test_drawn_ragged_call_equals_the_injected_hash(gen):
+    """A ragged call is cut into classes of frame counts and each class is one in-kernel batch; the hash's row is the utterance's row in
+    the CALL, so the padded [B, 961, Tmax] tensor of hashed phases reproduces the draw whatever the cut."""
+    enc_sd, dec_sd = state_dicts(0)
+    frames = [50, 7, 131, 20, 200, 9, 131]
+    lens = [480 * f for f in frames]
+    B, Tmax = len(frames), max(frames)
+    wf = torch.zeros(B, max(lens))
+    for b, n in enumerate(lens):
+        wf[b, :n] = synth.synth_wave(1, n, seed=300 + b)[0]
+    tgt = synth.synth_index(5003, seed=8)                                           # (the two-stage search)
+    torch.manual_seed(5)
+    seed = seed_of_next_draw()
+    drawn = gen.convert(wf.to(DEV), tgt.to(DEV), -1.0, lengths=lens)
+    angle = synth.noise_phase_hash(seed, range(B), Tmax)
+    injected = gen.convert(wf.to(DEV), tgt.to(DEV), -1.0, noise_angle=angle.to(DEV), lengths=lens)
+    for b in range(B):
+        assert torch.equal(drawn[b], injected[b]), f"row {b} ({frames[b]} frames)"
+    b = 3
+    with oracle_one_thread():
+        ref = R.convert(enc_sd, dec_sd, wf[b:b + 1, :lens[b]], tgt, -1.0, angle[b:b + 1, :, :frames[b]])
+    d = rms(drawn[b, :lens[b]].cpu() - ref[0])
+    assert d <= 1e-4, d
+
+
+def test_the_draw_is_uniform_on_minus_pi_pi():
+    """decoder.py:78 draws torch.rand * 2 pi - pi.  The hash over the headline batch's index space (64 rows x 961 bins x 200 frames =
+    12.3 M values): range, mean, variance, a 64-bin chi-square, and no correlation between neighbours along any of the three axes."""
+    a = synth.noise_phase_hash(0xC0FFEE1234567, range(64), 200).double()
+    n = a.numel()
+    assert float(a.min()) >= -math.pi - 1e-6 and float(a.max()) < math.pi + 1e-6
+    sd = math.pi / math.sqrt(3.0)
+    assert abs(float(a.mean())) < 5 * sd / math.sqrt(n)
+    var = float(a.var())
+    assert abs(var - math.pi ** 2 / 3) < 5 * (math.pi ** 2 / 3) * math.sqrt(0.8 / n) + 1e-6      # var of the sample variance of a uniform: (4/5) s^4 / n
+    h = torch.histc(a.float(), bins=64, min=-math.pi, max=math.pi).double()
+    chi2 = float(((h - n / 64) ** 2 / (n / 64)).sum())
+    assert chi2 < 63 + 6 * math.sqrt(2 * 63), chi2                                               # 63 degrees of freedom, six sigma
+    z = a / sd
+    for dim in (0, 1, 2):
+        x, y = z.narrow(dim, 0, z.shape[dim] - 1), z.narrow(dim, 1, z.shape[dim] - 1)
+        r = float((x * y).mean())
+        assert abs(r) < 6 / math.sqrt(x.numel()), (dim, r)
+    # another seed, another row: other phases
+    b = synth.noise_phase_hash(0xC0FFEE1234568, range(2), 50)
+    assert not torch.equal(b[0], b[1]) and not torch.equal(b[0], a[0, :, :50].float())

@@ -69,7 +69,7 @@ __device__ __forceinline__ float noise_phase_hash(unsigned long long seed, int r
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
     const float u = (float)(z >> 40) * (1.0f / 16777216.0f);  // [0, 1)
-    return u * 6.2831854820251465f - 3.1415927410125732f;
+    return fmaf(u, 6.2831854820251465f, -3.1415927410125732f);      // one rounding (what -ffp-contract=on made of `u * 2 pi - pi`; tinyvc_amd/synth.py noise_phase_hash restates it)
 }
 
 // y[row][d] = lerp(x[row][:]) — F.interpolate(mode='linear') on `rows` independent rows.
