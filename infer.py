@@ -11,6 +11,13 @@ skipped with a message); `-d` defaults to `cuda` and must be a GPU (there is no 
 the whole directory is converted in one call (a ragged batch: every file over its own length); resampling to 24 kHz runs on the GPU
 (tvc_resample_f32); an index.pt stored in half precision is matched with the fp16 index storage.
 
+Under a launcher (`python -m torch.distributed.run --nproc-per-node N infer.py ...`, WORLD_SIZE > 1) every rank converts ITS share of the
+directory on cuda:LOCAL_RANK and writes its own outputs: the files are split by length (longest-processing-time-first on padded samples,
+read from the WAV headers alone, tinyvc_amd/parallel.py lpt_split), every rank computes the same split by itself, and no collective runs at
+all - utterances are independent (reference infer.py:60-69 is a loop over files).  `--seed S` (extension) makes a file's noise phases a
+function of (S, file name) alone, so its output does not depend on the call it rides in or the rank that converts it (default, as in the
+reference: an unseeded draw).
+
 `--chunk-size / --buffer-size / --no-chunking`: the reference parses them and then converts every file
 whole (infer.py:27-29,40-41,66), so that is the default here too (identical output).  `--chunked` makes
 them real: the file is fed through the streaming converter in blocks of --chunk-size
@@ -22,10 +29,11 @@ import argparse
 import glob
 import os
 import sys
+import zlib
 
 import torch
 
-from tinyvc_amd import audio_io
+from tinyvc_amd import audio_io, parallel, spec
 from tinyvc_amd.module.infer import Generator
 from tinyvc_amd.module.tinyvc import Decoder, Encoder
 
@@ -48,7 +56,32 @@ def build_parser():
     p.add_argument("-nc", "--no-chunking", default=False, type=bool)
     p.add_argument("--chunked", action="store_true", help="honour --chunk-size / --buffer-size: block-wise conversion with SOLA cross-fades (bounded memory)")
     p.add_argument("--phase-vocoder", action="store_true", help="--chunked: phase-vocoder cross-fade (StreamInfer's use_phase_vocoder) instead of sin^2")
+    p.add_argument("--seed", default=None, type=int, help="a file's noise phases become a function of (seed, file name) alone (default: unseeded, as in the reference)")
     return p
+
+
+def file_angle(gen, device, seed, path, frames):
+    """[1, 961, frames] noise phases of one file under --seed: the reference's own draw (decoder.py:78: torch.rand * 2 pi - pi) from a device
+    generator seeded by (seed, crc32 of the file's base name) - the same phases whichever call, row or rank converts the file."""
+    g = torch.Generator(device=device)
+    g.manual_seed((int(seed) * 0x9E3779B1 + zlib.crc32(os.path.basename(path).encode())) & 0x7FFFFFFFFFFFFFFF)
+    return gen.engine(device).noise_angle_from_uniform(torch.rand(1, spec.FFT_BIN, frames, device=device, generator=g))
+
+
+def my_share(paths, world, rank):
+    """This rank's files (indices into `paths`, ascending): longest-processing-time split on the padded 24 kHz sample counts read from the
+    headers.  A file whose header cannot be read costs 0 here; whoever gets it reports the error it raises when it is loaded."""
+    if world <= 1:
+        return list(range(len(paths)))
+    costs = []
+    for p_ in paths:
+        try:
+            frames, sr, _ch = audio_io.info(p_)
+            n = -(-frames * SAMPLE_RATE // sr)
+            costs.append(-(-n // 480) * 480)
+        except (OSError, ValueError):
+            costs.append(0)
+    return parallel.lpt_split(costs, world)[rank]
 
 
 def load_generator(encoder_path, decoder_path, device):
@@ -104,11 +137,19 @@ def convert_chunked(gen, batch, tgt, pitch_shift, chunk_size, buffer_blocks, use
     return out
 
 
-def main(argv=None):
+def main(argv=None, world=None, rank=None, local_rank=None):
+    """`world / rank / local_rank` default to the launcher's environment (WORLD_SIZE / RANK / LOCAL_RANK); tests pass them to run one
+    rank's share in-process."""
     args = build_parser().parse_args(argv)
+    env = parallel.dist_env()
+    world, rank, local_rank = (env[0] if world is None else world), (env[1] if rank is None else rank), (env[2] if local_rank is None else local_rank)
     device = torch.device(args.device)
     if device.type != "cuda":
         sys.exit("infer.py: this build runs on an AMD GPU only; pass -d cuda (the reference's CPU path is not part of it)")
+    if world > 1 and device.index is None:
+        device = torch.device("cuda", local_rank)            # one process per GPU
+    if device.index is not None:
+        torch.cuda.set_device(device)
     gen = load_generator(args.encoder_path, args.decoder_path, device)
     tgt = load_target(gen, args, device)
     os.makedirs(args.outputs, exist_ok=True)
@@ -116,11 +157,14 @@ def main(argv=None):
     paths = []
     for ext in ("wav", "ogg", "mp3"):
         paths += sorted(glob.glob(os.path.join(args.inputs, "*." + ext)))
+    for path in paths:
+        if not path.lower().endswith(".wav") and rank == 0:
+            print(f"Skipping {path}: no decoder for this container in this build")
+    paths = [p_ for p_ in paths if p_.lower().endswith(".wav")]
+    paths = [paths[i] for i in my_share(paths, world, rank)]        # WORLD_SIZE > 1: this rank's files; nothing is exchanged between ranks
+    tag = f"[rank {rank}/{world}] " if world > 1 else ""
     jobs = []
     for path in paths:
-        if not path.lower().endswith(".wav"):
-            print(f"Skipping {path}: no decoder for this container in this build")
-            continue
         wf, sr = audio_io.load(path)
         wf = gen.engine(device).resample(wf.to(device), sr, SAMPLE_RATE).mean(dim=0, keepdim=True)       # mono, 24 kHz (infer.py:63-64), on the GPU
         jobs.append((path, wf))
@@ -133,13 +177,23 @@ def main(argv=None):
     if not jobs:
         return 0
     lengths = [wf.shape[1] for _p, wf in jobs]
-    print(f"Converting {len(jobs)} file(s), {min(lengths)} .. {max(lengths)} samples ...")
+    print(f"{tag}Converting {len(jobs)} file(s), {min(lengths)} .. {max(lengths)} samples ...")
     outs = [None] * len(jobs)
     if args.chunked and not args.no_chunking:
         for length in sorted(set(lengths)):      # streams of one group advance in lock step: chunked mode batches equal lengths
             rows = [i for i, n in enumerate(lengths) if n == length]
             batch = torch.cat([jobs[i][1][:, :length] for i in rows], dim=0)
-            o = convert_chunked(gen, batch, tgt, args.pitch_shift, args.chunk_size, args.buffer_size, args.phase_vocoder).cpu()
+            angles = None
+            if args.seed is not None:      # one generator per file, drawn from block after block: a stream's phases do not depend on its neighbours
+                gens = []
+                for i in rows:
+                    g = torch.Generator(device=device)
+                    g.manual_seed((int(args.seed) * 0x9E3779B1 + zlib.crc32(os.path.basename(jobs[i][0]).encode())) & 0x7FFFFFFFFFFFFFFF)
+                    gens.append(g)
+                tb = max(args.chunk_size + 1920 + 1920 + 2 * 3840, args.chunk_size + args.buffer_size * args.chunk_size) // 480      # frames of a stream's rolling buffer (BatchedStreamInfer.input_size, stream.py:52-53)
+                angles = lambda _i: gen.engine(device).noise_angle_from_uniform(      # noqa: E731
+                    torch.cat([torch.rand(1, spec.FFT_BIN, tb, device=device, generator=g) for g in gens], dim=0))
+            o = convert_chunked(gen, batch, tgt, args.pitch_shift, args.chunk_size, args.buffer_size, args.phase_vocoder, noise_angles=angles).cpu()
             for i, y in zip(rows, o):
                 outs[i] = y
     else:
@@ -159,10 +213,16 @@ def main(argv=None):
             batch = torch.zeros(len(rows), Lmax, device=device)
             for r, i in enumerate(rows):
                 batch[r, :lengths[i]] = jobs[i][1][0]
+            angle = None
+            if args.seed is not None:      # per-file phases in the padded [rows, 961, Tmax] layout the ragged call takes
+                angle = torch.zeros(len(rows), spec.FFT_BIN, Lmax // 480, device=device)
+                for r, i in enumerate(rows):
+                    f = -(-lengths[i] // 480)
+                    angle[r, :, :f] = file_angle(gen, device, args.seed, jobs[i][0], f)[0]
             if len(set(lens)) == 1:
-                out = gen.convert(batch[:, :lens[0]], tgt, args.pitch_shift).cpu()
+                out = gen.convert(batch[:, :lens[0]], tgt, args.pitch_shift, noise_angle=angle).cpu()
             else:
-                out = gen.convert(batch, tgt, args.pitch_shift, lengths=lens).cpu()
+                out = gen.convert(batch, tgt, args.pitch_shift, noise_angle=angle, lengths=lens).cpu()
             for r, i in enumerate(rows):
                 outs[i] = out[r, :-(-lengths[i] // 480) * 480]
             del batch, out

@@ -179,3 +179,62 @@ def test_merge_topk_tie_rule():
     idx = torch.tensor([[10, 7, 3, 1, 5, 2]])
     v, i = parallel.merge_topk(sims, idx)
     assert i.tolist() == [[3, 5, 7, 10]] and torch.equal(v, torch.tensor([[0.9, 0.9, 0.9, 0.5]]))
+
+
+# ---- extract_index.py under a launcher: the clips of the needed prefix encoded by all ranks, one gather (extract_index.sharded_features) ----
+def _fake_encode(i, n):
+    g = torch.Generator().manual_seed(1000 + i)
+    return torch.randn(1, 768, n, generator=g)
+
+
+def _index_worker(rank, world, port, cols, order, size, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import extract_index
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def enc(i):
+            calls.append(i)
+            return _fake_encode(i, cols[i])
+        feats = extract_index.sharded_features(cols, order, size, world, rank, enc, torch.device("cpu"))
+        q.put((rank, calls, feats))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_extract_index_features_sharded_equal_the_sequential_loop(world):
+    import extract_index
+    cols = [13, 2, 40, 7, 7, 25, 1, 9, 30, 4]
+    order = torch.randperm(len(cols), generator=torch.Generator().manual_seed(3)).tolist()
+    size = 70
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_index_worker, args=(r, world, port, cols, order, size, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get() for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # the reference's loop (extract_index.py:47-55): clips in shuffled order until more than `size` vectors are there
+    ref, total = [], 0
+    for i in order:
+        ref.append(_fake_encode(i, cols[i]))
+        total += cols[i]
+        if total > size:
+            break
+    used = order[:len(ref)]
+    encoded = sorted(i for _r, calls, _f in got for i in calls)
+    assert encoded == sorted(used), "exactly the clips the sequential loop uses, each encoded by one rank"
+    feats = [f for r, _c, f in got if r == 0][0]
+    assert all(f is None for r, _c, f in got if r != 0)
+    assert len(feats) == len(ref) and all(torch.equal(a, b) for a, b in zip(feats, ref))
+    g1, g2 = torch.Generator().manual_seed(9), torch.Generator().manual_seed(9)
+    assert torch.equal(extract_index.assemble(feats, size, g1, False), extract_index.assemble(ref, size, g2, False))

@@ -27,6 +27,34 @@ def load(path):
     return torch.from_numpy(np.ascontiguousarray(x.T)), int(sr)
 
 
+def info(path):
+    """(frames, sample_rate, channels) from the RIFF header alone - what the entry scripts need to balance files over ranks before any
+    rank reads audio data.  Chunks are walked until `data`; a streaming writer's 0 / 0xFFFFFFFF data size means "to the end of the file"."""
+    import os
+    import struct
+    with open(path, "rb") as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] not in (b"RIFF", b"RF64") or head[8:12] != b"WAVE":
+            raise ValueError(f"{path}: not a RIFF/WAVE file")
+        channels = sr = align = None
+        while True:
+            ck = f.read(8)
+            if len(ck) < 8:
+                raise ValueError(f"{path}: no data chunk")
+            cid, size = ck[:4], struct.unpack("<I", ck[4:])[0]
+            if cid == b"fmt ":
+                fmt = f.read(size + (size & 1))
+                _tag, channels, sr, _rate, align, _bits = struct.unpack("<HHIIHH", fmt[:16])
+            elif cid == b"data":
+                if channels is None or not align:
+                    raise ValueError(f"{path}: data chunk before fmt")
+                if size in (0, 0xFFFFFFFF):
+                    size = os.path.getsize(path) - f.tell()
+                return size // align, int(sr), int(channels)
+            else:
+                f.seek(size + (size & 1), 1)
+
+
 def save(path, src, sample_rate):
     x = src.detach().to("cpu", torch.float32)
     if x.dim() == 1:

@@ -303,6 +303,7 @@ __device__ __forceinline__ void make_map(SlabMap<TL>& m, int len, int dil, int t
     // once per kernel and keep them - then spill them - across every tile's MFMA phases; recomputing them per phase costs a few instructions)
     int tid0 = threadIdx.x;
     asm volatile("" : "+v"(tid0));
+    __builtin_assume(tid0 >= 0 && tid0 < TL::NTHR);
 #pragma unroll
     for (int i = 0; i < TL::X_PER; ++i) {
         int idx = tid0 + i * TL::NTHR;
@@ -345,7 +346,9 @@ __device__ __forceinline__ void slab_load(SlabRegs<TL>& r, const SlabMap<TL>& m,
     constexpr int PIECES = STEPS * MTB * kParts, A_PER = (PIECES + NW - 1) / NW;
     static_assert(A_PER <= SlabRegs<TL>::A_MAX, "weight pieces must fit the staging registers");
     const int tid = tid_ >= 0 ? tid_ : (int)threadIdx.x;      // (split_phase passes its laundered copy: the piece offsets live for one phase, not across the tile loop)
-    const int lane = tid & 63, wave = tid >> 6;
+    __builtin_assume(tid >= 0 && tid < TL::NTHR);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (the laundered copy has lost its "wave-uniform" property: say it again, or `q < PIECES` becomes an exec-masked branch)
+    __builtin_assume(wave >= 0 && wave < NW);                                        // (... and its range: the first pieces' `q < PIECES` are decided at compile time)
     const int ci0 = s * 16 * TL::KG;
     {
         const uint4* a_src = A6 + (long)mt0 * kPU4;
@@ -414,7 +417,9 @@ __device__ __forceinline__ void split_phase(f32x16 (&hi)[TL::WM][TL::WN], f32x16
     // hoisted out of the persistent tile loop, kept live across every other phase and spilled)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6;
+    __builtin_assume(tid >= 0 && tid < TL::NTHR);      // (... and its range, which decides `q < PIECES` for the first pieces at compile time)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform again: see slab_load)
+    __builtin_assume(wave >= 0 && wave < NW);
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NWV, wn = wave - wm * NWV;
     SlabMap<TL> m;

@@ -13,6 +13,26 @@ def shard_bounds(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def dist_env():
+    """(world, rank, local_rank) as a launcher (`python -m torch.distributed.run`) exports them; (1, 0, 0) without one."""
+    import os
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def lpt_split(costs, world: int):
+    """Files of different lengths over `world` ranks: longest-processing-time-first (every item, in order of decreasing cost, goes to the
+    least loaded rank; ties: the lower item index first, the lower rank first).  Returns one index list per rank, each in ascending item
+    order; deterministic, so every rank computes the same split from the same list without talking to the others.  The makespan is
+    within 4/3 - 1/(3 world) of the optimum (Graham 1969); round-robin over a directory sorted by name can be off by the longest file."""
+    load = [0] * world
+    parts = [[] for _ in range(world)]
+    for i in sorted(range(len(costs)), key=lambda i: (-costs[i], i)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        load[r] += costs[i]
+        parts[r].append(i)
+    return [sorted(p) for p in parts]
+
+
 def gather_waves(local, n_items: int, dst: int = 0, group=None):
     """Collect per-rank outputs [n_local, L] on `dst` as one [n_items, L] tensor in utterance order.
     Ragged shards are padded to the largest shard for the collective and trimmed on arrival."""
