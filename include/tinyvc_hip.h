@@ -11,16 +11,26 @@
  *     (a torch tensor's data_ptr), fp32, contiguous, channels-first [B, C, T] like the reference;
  *     16-byte aligned;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all
- *     work is enqueued asynchronously on it; nothing here synchronises the device.  The encoder
- *     forks its pitch estimator onto a context-owned side stream and joins it back onto `stream`
- *     with events before the call returns, so `stream` order is all a caller ever sees (the
- *     fork/join is capturable: a HIP graph captured on `stream` includes it);
+ *     work is enqueued asynchronously on it; nothing here synchronises the device (one exception: the first use of a prepared
+ *     index this process did not prepare itself reads its 24-byte header, see tvc_knn_prepare_index_f32).  Outside a stream
+ *     capture the encoder forks its pitch estimator onto a context-owned side stream and joins it back onto `stream` with
+ *     events before the call returns, so `stream` order is all a caller ever sees; while `stream` is being captured the pitch
+ *     estimator stays on `stream` (one chain replays faster than the fork inside a graph: DESIGN.md section 4);
+ *   - stream capture: every call may be captured into a HIP graph, with two rules.  Kernel arguments are baked into the graph,
+ *     so a call that draws its own noise phases (noise_angle = NULL: the seed is an argument) is refused with TVC_ERR_STATE while
+ *     capturing - pass noise_angle and refill that buffer between replays.  And a prepared index must have been used (or
+ *     prepared) by this process once before the capture, so that its header check does not have to synchronise;
  *   - `ws` is a caller-allocated device scratch buffer of at least tvc_workspace_bytes() bytes;
  *     the library never allocates device memory after tvc_finalize_weights();
  *   - arithmetic: fp32 in, fp32 out.  Channel contractions run on the fp16 matrix pipe with every fp32 operand split into two
- *     fp16 parts (22 significand bits, fp32-GEMM-level error); a per-utterance power-of-two scale taken from each tensor's largest
- *     magnitude keeps the parts inside fp16's range, so results do not depend on the loudness of the input, and one utterance's
- *     range never affects another utterance of the batch;
+ *     fp16 parts (22 significand bits, fp32-GEMM-level error); a per-utterance power-of-two scale keeps the parts inside fp16's
+ *     range, so results do not depend on the loudness of the input, and one utterance's range never affects another utterance of
+ *     the batch.  The scale comes from an UPPER BOUND of the tensor's largest magnitude: measured by the producing kernel's epilogue
+ *     where that is free, analytic elsewhere (max |wav| bounds the energy envelope and, times the Hann window's sum, every |STFT|
+ *     bin; the index's |max|, stored in the prepared blob, bounds the matched content; an l1 norm of the weights times the input's
+ *     bound + the largest bias bounds a 1x1's output); inside [2^-10, 2^15) nothing is scaled, so a bound and the exact maximum give
+ *     the same bits.  The whole-path calls (tvc_convert_*) and the stage calls derive them per utterance in the same way for equal
+ *     and ragged batches;
  *   - return value: 0 = ok, negative = tvc_status; tvc_last_error() has the message;
  *   - one ctx per device, one host thread per ctx at a time.
  */
@@ -110,7 +120,11 @@ int tvc_pitch_decode_f32(tvc_ctx* ctx, void* stream, const float* logits, float*
  * scaled by 1/(||r||+1e-6) (feature_retrieval.py:25 recomputes that on every call) split into three bf16 parts per
  * value in MFMA lane order (the similarity GEMM's operand), plus the same vectors in fp16 and their inverse norms (the
  * coarse pass of the two-stage search): 12 bytes per index element.  The layout is private to the
- * library; the blob is self-describing, so every entry point below takes either kind of blob. */
+ * library; the blob is self-describing (magic, kind, N, the raw vectors' |max| - the decoder's bound of the matched content -,
+ * format version), so every entry point below takes either kind of blob.  A blob at an address this process did not prepare
+ * (a copy, a blob read back from a file) has its header read once, on its first use outside a stream capture - the one place the
+ * library waits for `stream` -, and is refused (TVC_ERR_ARG) if the magic, the format version or N do not match: blobs of an
+ * earlier format must be prepared again. */
 int64_t tvc_knn_prepared_elems(int64_t N);
 int tvc_knn_prepare_index_f32(tvc_ctx* ctx, void* stream, const float* index, float* prepared,
                               int64_t N);
@@ -216,13 +230,14 @@ int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* p
 int tvc_workspace_bytes_ragged(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, int64_t N, size_t* out_bytes);
 /* Which utterances of a ragged call share their kernel launches: batch_of_row[b] = the in-kernel batch (0 .. *n_batches - 1, the order they
  * run in) that utterance b is converted in.  Pure host logic, no context, no device: the split tvc_convert_ragged_f32 makes (length classes
- * at 11 / 43 / 128 frames, at most 80 000 frames per batch).  Returns TVC_ERR_ARG for a length the ragged call would refuse. */
-int tvc_ragged_plan(int B, int64_t Lmax, const int64_t* lens, int32_t* batch_of_row, int* n_batches);
-/* Frames per in-kernel batch of the ragged calls (process-wide; 0 or anything above 80 000 = the default, 80 000): a smaller cap cuts a
- * length class into several batches, one after the other.  Results do not depend on it (every utterance equals its B = 1 conversion); the
- * plan, the workspace size and the conversion all follow the value set at the time of THEIR call, so set it between calls, not during one.
- * (The tests use it to reach the several-batches-per-class path with small inputs; there is no environment variable behind it.) */
-int tvc_set_ragged_batch_frames(int max_frames);
+ * at 11 / 43 / 128 frames, at most `max_frames` frames per batch; 0 or anything above 80 000 = the default, 80 000 - pass what the context
+ * that will convert was given by tvc_ctx_set_ragged_batch_frames).  Returns TVC_ERR_ARG for a length the ragged call would refuse. */
+int tvc_ragged_plan(int B, int64_t Lmax, const int64_t* lens, int max_frames, int32_t* batch_of_row, int* n_batches);
+/* Frames per in-kernel batch of THIS context's ragged calls (0 or anything above 80 000 = the default, 80 000): a smaller cap cuts a length
+ * class into several batches, one after the other.  Results do not depend on it (every utterance equals its B = 1 conversion);
+ * tvc_workspace_bytes_ragged and tvc_convert_ragged_f32 of the context follow it, so set it between calls (one host thread per ctx at a time).
+ * (The tests use it to reach the several-batches-per-class path with small inputs; there is no environment variable and no process-wide state behind it.) */
+int tvc_ctx_set_ragged_batch_frames(tvc_ctx* ctx, int max_frames);
 int tvc_convert_ragged_f32(tvc_ctx* ctx, void* stream, const float* wav, int64_t Lmax, const int64_t* lens, const float* prepared_index,
                            int64_t N, float pitch_shift, const float* noise_angle, uint64_t seed, float* wave, int B, void* ws,
                            size_t ws_bytes);
@@ -237,6 +252,11 @@ int tvc_convert_ragged_f32(tvc_ctx* ctx, void* stream, const float* wav, int64_t
 int tvc_sola_f32(tvc_ctx* ctx, void* stream, const float* y, float* sola_buf, const float* fade_in,
                  float* out, int32_t* shift_out, int S, int64_t Ly, int block,
                  int use_phase_vocoder);
+
+/* StreamInfer.audio_callback before convert (reference module/infer/stream.py:69-70: `input_wav = torch.roll(input_wav, -block)`,
+ * `input_wav[-block:] = block`), batched over S streams, in place and in one launch: buf [S, n] rolling input buffers,
+ * blocks [S, block] the new blocks; afterwards buf[s] = (old buf[s][block:], blocks[s]).  n <= 32 768. */
+int tvc_stream_push_f32(tvc_ctx* ctx, void* stream, float* buf, const float* blocks, int S, int64_t n, int block);
 
 /* measurement ----------------------------------------------------------------------------- */
 /* on = 1: every stage (and every FilterNet block) is bracketed by a hipEvent pair on the launch stream (19 pairs per

@@ -86,12 +86,12 @@ def test_ragged_plan_is_host_logic(lib):
     frames - the kernels a FilterNet level runs depend on the utterance's length there -, a frame cap per batch), and its validation."""
     import ctypes
 
-    def plan(frames, lmax_frames=None):
+    def plan(frames, lmax_frames=None, cap=0):
         B = len(frames)
         lens = (ctypes.c_int64 * B)(*[480 * f for f in frames])
         out = (ctypes.c_int32 * B)()
         n = ctypes.c_int()
-        rc = lib.tvc_ragged_plan(B, 480 * (lmax_frames or max(frames)), lens, out, ctypes.byref(n))
+        rc = lib.tvc_ragged_plan(B, 480 * (lmax_frames or max(frames)), lens, cap, out, ctypes.byref(n))
         return rc, list(out), n.value
 
     rc, rows, n = plan([200, 5, 131, 10, 11, 42, 43, 127, 128, 3])
@@ -108,9 +108,7 @@ def test_ragged_plan_is_host_logic(lib):
     assert plan([2, 50])[0] != 0                                                    # 960 samples: too short for the STFT's reflect padding
     assert plan([50, 60], lmax_frames=55)[0] != 0                                   # longer than its row
     assert plan([90000])[0] != 0                                                    # longer than a batch may be
-    assert lib.tvc_set_ragged_batch_frames(400) == 0
-    try:
-        rc, rows, n = plan([150] * 7)
-    finally:
-        assert lib.tvc_set_ragged_batch_frames(0) == 0
+    rc, rows, n = plan([150] * 7, cap=400)
     assert rc == 0 and n == 4 and rows == [0, 0, 1, 1, 2, 2, 3]                     # the cap cuts a class into several batches, in order
+    assert plan([150] * 7, cap=-1)[0] != 0
+    assert lib.tvc_ctx_set_ragged_batch_frames(None, 400) == -1                     # the cap is a property of a context: no process-wide state

@@ -250,12 +250,12 @@ def test_many_utterances_and_several_batches_per_class(gen):
         ones[b] = gen.convert(wf[b:b + 1, :lens[b]], tgt, 0.0, noise_angle=angle[b:b + 1, :, :frames[b]].contiguous())[0]
         assert torch.equal(out[b, :lens[b]], ones[b]), f"utterance {b} ({frames[b]} frames)"
         assert not out[b, lens[b]:].any()
-    from tinyvc_amd import _lib
-    assert _lib.load_library().tvc_set_ragged_batch_frames(4000) == 0       # ~ 5 batches per class
+    eng = gen.engine(DEV)
+    eng.set_ragged_batch_frames(4000)                                       # ~ 5 batches per class (a property of this engine's context)
     try:
         out2 = gen.convert(wf, tgt, 0.0, noise_angle=angle, lengths=lens)
     finally:
-        assert _lib.load_library().tvc_set_ragged_batch_frames(0) == 0
+        eng.set_ragged_batch_frames(0)
     assert torch.equal(out2, out)
 
 

@@ -112,3 +112,70 @@ def test_out_of_range_utterance_leaves_its_batch_mates_untouched(gen):
     e = rel_rms(out[0].cpu(), ref[0])
     print(f"[range] utterance scaled by 1e5: waveform rel rms vs the oracle {e:.2e} (|wave| max {float(ref.abs().max()):.3g})")
     assert e <= 2e-3
+
+
+@pytest.mark.parametrize("scale", [1e4, 1e-7, 1.0])
+def test_ragged_rows_equal_their_own_calls_at_any_input_amplitude(gen, scale):
+    """The whole-path call derives the |max| slots of |STFT| / energy from max |wav| per utterance (analytic bounds) - in a ragged batch exactly
+    as in the equal-length call, so an utterance's power-of-two scales, and with them its bits, are those of its own B = 1 call even when the
+    input is far outside fp16's window (un-normalised int16-range floats x 1e4; near silence x 1e-7)."""
+    frames = [50, 9, 131, 20, 131]
+    lens = [480 * f for f in frames]
+    wf = torch.zeros(len(frames), max(lens))
+    for b, n in enumerate(lens):
+        wf[b, :n] = synth.synth_wave(1, n, seed=70 + b)[0] * scale
+    wf = wf.to(DEV)
+    tgt = synth.synth_index(500, seed=8).to(DEV)
+    angle = synth.synth_angle(len(frames), max(frames), 5).to(DEV)
+    out = gen.convert(wf, tgt, 0.0, noise_angle=angle, lengths=lens)
+    assert torch.isfinite(out).all()
+    for b, f in enumerate(frames):
+        one = gen.convert(wf[b:b + 1, :lens[b]], tgt, 0.0, noise_angle=angle[b:b + 1, :, :f].contiguous())
+        assert torch.equal(out[b, :lens[b]], one[0]), f"scale {scale:g}, utterance {b} ({f} frames)"
+
+
+def test_large_magnitude_index_is_range_guarded_through_the_blob_bound(gen):
+    """The decoder takes the bound of the matched content from the prepared blob's header (the raw vectors' |max|).  An index whose vectors
+    are 1e5 times larger (cosine matching does not care; the matched content is 1e5 times larger and far outside fp16) must convert like the
+    oracle: a lost bound (0 = "no scaling") would overflow the fp16 parts of SourceNet's / FilterNet's first contraction to Inf."""
+    from helpers import oracle_one_thread, state_dicts as sds
+    from oracle import ref_cpu as R
+    enc_sd, dec_sd = sds(0)
+    wf = synth.synth_wave(1, 480 * 40, seed=17)
+    tgt = synth.synth_index(700, seed=8) * 1e5
+    angle = synth.synth_angle(1, 40, 3)
+    out = gen.convert(wf.to(DEV), tgt.to(DEV), 0.0, noise_angle=angle.to(DEV)).cpu()
+    assert torch.isfinite(out).all()
+    # a content 1e5 times too large drives the decoder far out of its trained range (output rms ~ 5e12): the path is ill-conditioned there and
+    # the reference's own fp32 arithmetic is 4e-3 (relative) away from the fp64 evaluation.  So both are measured against that truth
+    # (test_gpu_truth.py's yardstick): the GPU may not be further from it than twice the reference's fp32 ops are.
+    with oracle_one_thread():
+        ref = R.convert(enc_sd, dec_sd, wf, tgt, 0.0, angle)
+        truth = R.convert({k: v.double() for k, v in enc_sd.items()}, {k: v.double() for k, v in dec_sd.items()}, wf.double(), tgt.double(), 0.0, angle.double())
+    nrm = (truth ** 2).mean().sqrt()
+    e_gpu = float(((out.double() - truth) ** 2).mean().sqrt() / nrm)
+    e_ref = float(((ref.double() - truth) ** 2).mean().sqrt() / nrm)
+    print(f"[range] index x 1e5: rel rms vs the fp64 evaluation: GPU {e_gpu:.3e}, reference fp32 {e_ref:.3e}")
+    assert e_gpu <= 2.0 * e_ref + 1e-6, (e_gpu, e_ref)
+
+
+def test_foreign_blobs_are_checked_once_and_old_formats_refused(gen):
+    """A prepared index at an address this process did not prepare (a clone) has its header read on first use: a faithful copy works and gives
+    the same bits; a header with another format version, a wrong magic or another N is refused instead of silently running without the
+    content bound (the |max| field was added without a version)."""
+    from tinyvc_amd import _lib
+    eng = gen.engine(DEV)
+    tgt = synth.synth_index(600, seed=8).to(DEV)
+    blob, n = eng.knn_prepare(tgt[0])
+    src = synth.synth_tensor("q", (1, 768, 30), seed=4).to(DEV)
+    ref = eng.knn_match(src, blob, n)
+    copy = blob.clone()
+    assert torch.equal(eng.knn_match(src, copy, n), ref)
+    hdr = copy.view(torch.int32)
+    assert int(hdr[5]) == 2 and int(hdr[2]) == 600
+    for word, value, what in ((5, 1, "format version"), (0, 0x12345678, "not a blob"), (2, 601, "prepared for N")):
+        bad = blob.clone()
+        bad.view(torch.int32)[word] = value
+        with pytest.raises(_lib.TinyVCError) as ei:
+            eng.knn_match(src, bad, n)
+        assert what in str(ei.value), str(ei.value)

@@ -34,8 +34,8 @@ SIGNATURES = {
     "tvc_knn_prepared_elems_f16": (c_int64, [c_int64]),
     "tvc_knn_prepare_index_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "tvc_knn_forget": (c_int, [c_void_p, c_void_p]),
-    "tvc_ragged_plan": (c_int, [c_int, c_int64, POINTER(c_int64), POINTER(c_int32), POINTER(c_int)]),
-    "tvc_set_ragged_batch_frames": (c_int, [c_int]),
+    "tvc_ragged_plan": (c_int, [c_int, c_int64, POINTER(c_int64), c_int, POINTER(c_int32), POINTER(c_int)]),
+    "tvc_ctx_set_ragged_batch_frames": (c_int, [c_void_p, c_int]),
     "tvc_knn_prepare_index_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "tvc_knn_match_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_knn_topk_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
@@ -51,6 +51,7 @@ SIGNATURES = {
     "tvc_workspace_bytes_ragged": (c_int, [c_void_p, c_int, c_int64, POINTER(c_int64), c_int64, POINTER(c_size_t)]),
     "tvc_convert_ragged_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int64), c_void_p, c_int64, c_float, c_void_p, c_uint64, c_void_p, c_int, c_void_p, c_size_t]),
     "tvc_sola_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int]),
+    "tvc_stream_push_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int]),
     "tvc_profile_enable": (c_int, [c_void_p, c_int]),
     "tvc_profile_read": (c_int, [c_void_p, ctypes.c_char_p, c_size_t]),
 }

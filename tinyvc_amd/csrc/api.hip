@@ -541,11 +541,41 @@ static void blob_forget(const void* p) {
     std::lock_guard<std::mutex> lk(g_blob_mu);
     g_blobs.erase(p);
 }
-static int blob_check(tvc_ctx* ctx, const void* p, int64_t N, const char* what) {
-    std::lock_guard<std::mutex> lk(g_blob_mu);
-    auto it = g_blobs.find(p);
-    if (it != g_blobs.end() && it->second != N)
-        return fail(ctx, TVC_ERR_ARG, "%s: this blob was prepared for N = %lld index vectors, the call says N = %lld", what, (long long)it->second, (long long)N);
+// A blob this process did not prepare (a copy, a blob loaded from a file) is read ONCE - its 24-byte header, after the caller's stream has drained -
+// and must carry this build's magic, format version and the caller's N; then it is recorded like a prepared one.  Inside a stream capture nothing
+// may synchronise: an unknown blob is trusted there (capture after one eager call, as the module path does).
+static int blob_check(tvc_ctx* ctx, hipStream_t s, const void* p, int64_t N, const char* what) {
+    {
+        std::lock_guard<std::mutex> lk(g_blob_mu);
+        auto it = g_blobs.find(p);
+        if (it != g_blobs.end()) {
+            if (it->second != N)
+                return fail(ctx, TVC_ERR_ARG, "%s: this blob was prepared for N = %lld index vectors, the call says N = %lld", what, (long long)it->second, (long long)N);
+            return 0;
+        }
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0;
+    int h[6] = {0, 0, 0, 0, 0, 0};
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipMemcpy(h, p, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(ctx, TVC_ERR_HIP, "%s: cannot read the prepared index's header", what);
+    const int64_t n = ((int64_t)(unsigned)h[3] << 32) | (unsigned)h[2];
+    if (h[0] != tvc::kBlobMagic || (h[1] != 0 && h[1] != 1))
+        return fail(ctx, TVC_ERR_ARG, "%s: `prepared` is not a blob of tvc_knn_prepare_index_f32 / _f16", what);
+    if (h[5] != tvc::kBlobVersion)
+        return fail(ctx, TVC_ERR_ARG, "%s: the prepared index has format version %d, this library writes and reads version %d: prepare it again", what, h[5], tvc::kBlobVersion);
+    if (n != N) return fail(ctx, TVC_ERR_ARG, "%s: this blob was prepared for N = %lld index vectors, the call says N = %lld", what, (long long)n, (long long)N);
+    blob_record(p, N);
+    return 0;
+}
+
+// noise_angle = NULL makes the library draw the phases from `seed` - a kernel ARGUMENT, which a stream capture bakes into the graph: every replay
+// would synthesise the same noise.  A capturing caller must pass the phases (a buffer it refills between replays, as the module path does).
+static int draw_under_capture(tvc_ctx* ctx, hipStream_t s, const float* noise_angle, const char* what) {
+    if (noise_angle) return 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(ctx, TVC_ERR_STATE, "%s: noise_angle = NULL inside a stream capture would replay ONE seed's phases on every graph launch; pass noise_angle", what);
     return 0;
 }
 
@@ -806,10 +836,13 @@ static int convert_impl(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const flo
     // |max| slots the path can bound without a pass over the tensors (block-floating-point guard of the fp16 split, conv3s.h; equal-length
     // batches): emax = max |wav| per utterance (the energy stage's pooled maxima, 1 500 values each) bounds the energy envelope - a linear
     // interpolation of them - and, times the Hann window's sum (960), every |STFT| bin; `matched` is a mean of index rows.
-    float* emax = ws.get<float>((size_t)5 * B);
-    float* spec_bound = emax + B;
-    float* enc_slots = spec_bound + B;      // the encoder's three atomicMax slots: zeroed by the energy stage's pooled-maximum launch
-    const bool bounds = !ctx->rag;
+    // A ragged batch (the driver passed B = 1, T = all frames: ragged.h) derives them per utterance in the same way - an utterance's scales,
+    // and with them its bits, are those of its own B = 1 call at every input amplitude (test_gpu_ragged.py scales the input by 1e4 and 1e-7).
+    const int NB = ctx->rag ? ctx->rag->B : B;
+    float* emax = ws.get<float>((size_t)5 * NB);
+    float* spec_bound = emax + NB;
+    float* enc_slots = spec_bound + NB;      // the encoder's three atomicMax slots: zeroed by the energy stage's pooled-maximum launch
+    const bool bounds = true;
     size_t m = ws.mark();
     {
         ProfScope ps(ctx, s, dry, "stft");
@@ -818,7 +851,7 @@ static int convert_impl(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const flo
     ws.release(m);
     {
         ProfScope ps(ctx, s, dry, "energy");
-        TVC_CHECK(run_energy(ctx, s, ws, dry, wav, energy, B, L, bounds ? emax : nullptr, bounds ? spec_bound : nullptr, bounds ? enc_slots : nullptr, 3 * B));
+        TVC_CHECK(run_energy(ctx, s, ws, dry, wav, energy, B, L, bounds ? emax : nullptr, bounds ? spec_bound : nullptr, bounds ? enc_slots : nullptr, 3 * NB));
     }
     ws.release(m);
     {
@@ -962,7 +995,7 @@ int tvc_knn_match_f32(tvc_ctx* ctx, void* stream, const float* src, const float*
     if (!ctx) return TVC_ERR_ARG;
     if (!src || !prepared || !out || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_match_f32: bad argument");
     if (N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_knn_match_f32: index needs at least k=4 vectors (torch.topk raises too)");
-    TVC_CHECK(blob_check(ctx, prepared, N, "tvc_knn_match_f32"));
+    TVC_CHECK(blob_check(ctx, (hipStream_t)stream, prepared, N, "tvc_knn_match_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(run_knn(ctx, s, ws, true, src, prepared, N, out, idx_out, B, T),
@@ -974,7 +1007,7 @@ int tvc_knn_topk_f32(tvc_ctx* ctx, void* stream, const float* src, const float* 
     if (!ctx) return TVC_ERR_ARG;
     if (!src || !prepared || !sims_out || !idx_out || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_topk_f32: bad argument");
     if (N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_knn_topk_f32: an index shard needs at least k=4 vectors");
-    TVC_CHECK(blob_check(ctx, prepared, N, "tvc_knn_topk_f32"));
+    TVC_CHECK(blob_check(ctx, (hipStream_t)stream, prepared, N, "tvc_knn_topk_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(run_knn_topk(ctx, s, ws, true, src, prepared, N, sims_out, idx_out, B, T),
@@ -985,7 +1018,7 @@ int tvc_knn_gather_slots_f32(tvc_ctx* ctx, void* stream, const float* prepared, 
                              int64_t nslots) {
     if (!ctx) return TVC_ERR_ARG;
     if (!prepared || !idx || !slots || N <= 0 || nslots <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_gather_slots_f32: bad argument");
-    TVC_CHECK(blob_check(ctx, prepared, N, "tvc_knn_gather_slots_f32"));
+    TVC_CHECK(blob_check(ctx, (hipStream_t)stream, prepared, N, "tvc_knn_gather_slots_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     return run_knn_slots(ctx, (hipStream_t)stream, prepared, N, idx, slots, nslots);
 }
@@ -1016,6 +1049,7 @@ int tvc_decoder_stages_f32(tvc_ctx* ctx, void* stream, const float* content, con
                            float* source, int B, int T, void* wsp, size_t ws_bytes) {
     TVC_CHECK(need_ready(ctx, NEED_DEC));
     if (!content || !f0 || !energy || B <= 0 || T <= 0 || (!wave && !amps && !kernel && !source)) return fail(ctx, TVC_ERR_ARG, "tvc_decoder_f32: bad argument");
+    if (wave || source) TVC_CHECK(draw_under_capture(ctx, (hipStream_t)stream, noise_angle, "tvc_decoder_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(run_decoder(ctx, s, ws, true, content, f0, energy, noise_angle, seed, wave, amps, kernel, source, B, T),
@@ -1039,6 +1073,7 @@ int tvc_dsp_f32(tvc_ctx* ctx, void* stream, const float* f0, const float* amps, 
                 uint64_t seed, float* source, int B, int T, void* wsp, size_t ws_bytes) {
     TVC_CHECK(need_ready(ctx, NEED_NONE));
     if (!f0 || !amps || !kernel || !source || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_dsp_f32: bad argument");
+    TVC_CHECK(draw_under_capture(ctx, (hipStream_t)stream, noise_angle, "tvc_dsp_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(run_dsp(ctx, s, ws, true, f0, amps, kernel, noise_angle, seed, source, B, T),
@@ -1057,7 +1092,8 @@ int tvc_convert_f32(tvc_ctx* ctx, void* stream, const float* wav, const float* p
     if (!wav || !prepared || !wave || B <= 0 || L <= 0 || L % kHop) return fail(ctx, TVC_ERR_ARG, "tvc_convert_f32: bad argument (L must be a positive multiple of 480)");
     if (L < kNfft / 2 + 1) return fail(ctx, TVC_ERR_ARG, "tvc_convert_f32: L must exceed 960 samples (STFT reflect padding, as torch.stft requires)");
     if (N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_convert_f32: index needs at least k=4 vectors");
-    TVC_CHECK(blob_check(ctx, prepared, N, "tvc_convert_f32"));
+    TVC_CHECK(blob_check(ctx, (hipStream_t)stream, prepared, N, "tvc_convert_f32"));
+    TVC_CHECK(draw_under_capture(ctx, (hipStream_t)stream, noise_angle, "tvc_convert_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     TVC_RUN(convert_impl(ctx, s, ws, true, wav, prepared, N, pitch_shift, noise_angle, seed, wave, B, L),
@@ -1071,15 +1107,13 @@ namespace {
 // 2 T, 6 T, 24 T >= 256, decoder.hip film_conv), so the frame counts split into four classes at 11, 43 and 128 frames; inside a class every
 // utterance takes exactly the path its own B = 1 call takes and the result is bit-identical to it.
 constexpr int kRagClassBounds[3] = {11, 43, 128};
-std::atomic<int> g_rag_batch_frames{0};
 constexpr int kRagMaxFrames = 80000;       // frames per in-kernel batch: 24 rows x 480 x 4 B x frames stays below the 32-bit byte offsets of the 24-channel kernels
 struct RagBatchPlan {
     std::vector<int> rows, frames;
     int Ttot = 0;
 };
-int ragged_split(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t* lens, std::vector<RagBatchPlan>* batches) {
-    std::vector<RagBatchPlan> open(4);          // the batch being filled, per class
-    const int cap = g_rag_batch_frames.load(std::memory_order_relaxed);      // tvc_set_ragged_batch_frames: 0 = the default
+int ragged_split(tvc_ctx* ctx, int cap, int B, int64_t Lmax, const int64_t* lens, std::vector<RagBatchPlan>* batches) {
+    std::vector<RagBatchPlan> open(4);          // the batch being filled, per class (cap: tvc_ctx_set_ragged_batch_frames / tvc_ragged_plan's argument, 0 = the default)
     const int max_frames = cap > 0 && cap < kRagMaxFrames ? cap : kRagMaxFrames;
     for (int b = 0; b < B; ++b) {
         if (lens[b] <= 0 || lens[b] % kHop || lens[b] > Lmax || lens[b] < kNfft / 2 + 1)
@@ -1128,15 +1162,16 @@ int ragged_batch_bytes(tvc_ctx* ctx, const std::vector<RagBatchPlan>& batches, i
 }
 }  // namespace
 
-int tvc_set_ragged_batch_frames(int max_frames) {
-    if (max_frames < 0) return TVC_ERR_ARG;
-    g_rag_batch_frames.store(max_frames, std::memory_order_relaxed);
+int tvc_ctx_set_ragged_batch_frames(tvc_ctx* ctx, int max_frames) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (max_frames < 0) return fail(ctx, TVC_ERR_ARG, "tvc_ctx_set_ragged_batch_frames: the cap is a frame count (0 = the default)");
+    ctx->rag_batch_frames = max_frames;
     return TVC_OK;
 }
-int tvc_ragged_plan(int B, int64_t Lmax, const int64_t* lens, int32_t* batch_of_row, int* n_batches) {
-    if (!lens || !batch_of_row || !n_batches || B <= 0 || Lmax <= 0 || Lmax % kHop != 0) return TVC_ERR_ARG;
+int tvc_ragged_plan(int B, int64_t Lmax, const int64_t* lens, int max_frames, int32_t* batch_of_row, int* n_batches) {
+    if (!lens || !batch_of_row || !n_batches || B <= 0 || Lmax <= 0 || Lmax % kHop != 0 || max_frames < 0) return TVC_ERR_ARG;
     std::vector<RagBatchPlan> batches;
-    const int rc = ragged_split(nullptr, B, Lmax, lens, &batches);
+    const int rc = ragged_split(nullptr, max_frames, B, Lmax, lens, &batches);
     if (rc) return rc;
     for (size_t i = 0; i < batches.size(); ++i)
         for (int b : batches[i].rows) batch_of_row[b] = (int32_t)i;
@@ -1148,7 +1183,7 @@ int tvc_workspace_bytes_ragged(tvc_ctx* ctx, int B, int64_t Lmax, const int64_t*
     TVC_CHECK(need_ready(ctx, NEED_NONE));
     if (!out_bytes || !lens || B <= 0 || Lmax <= 0 || Lmax % kHop != 0 || N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_workspace_bytes_ragged: need B>0, Lmax%%480==0, N>=4");
     std::vector<RagBatchPlan> batches;
-    TVC_CHECK(ragged_split(ctx, B, Lmax, lens, &batches));
+    TVC_CHECK(ragged_split(ctx, ctx->rag_batch_frames, B, Lmax, lens, &batches));
     size_t bytes = 0;
     TVC_CHECK(ragged_batch_bytes(ctx, batches, Lmax, N, &bytes, -1));
     *out_bytes = bytes + 4096;
@@ -1160,11 +1195,12 @@ int tvc_convert_ragged_f32(tvc_ctx* ctx, void* stream, const float* wav, int64_t
     TVC_CHECK(need_ready(ctx, NEED_ENC | NEED_DEC));
     if (!wav || !lens || !prepared || !wave || B <= 0 || Lmax <= 0 || Lmax % kHop) return fail(ctx, TVC_ERR_ARG, "tvc_convert_ragged_f32: bad argument (Lmax must be a positive multiple of 480)");
     if (N < 4) return fail(ctx, TVC_ERR_ARG, "tvc_convert_ragged_f32: index needs at least k=4 vectors");
-    TVC_CHECK(blob_check(ctx, prepared, N, "tvc_convert_ragged_f32"));
+    TVC_CHECK(blob_check(ctx, (hipStream_t)stream, prepared, N, "tvc_convert_ragged_f32"));
+    TVC_CHECK(draw_under_capture(ctx, (hipStream_t)stream, noise_angle, "tvc_convert_ragged_f32"));
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     std::vector<RagBatchPlan> batches;
-    TVC_CHECK(ragged_split(ctx, B, Lmax, lens, &batches));
+    TVC_CHECK(ragged_split(ctx, ctx->rag_batch_frames, B, Lmax, lens, &batches));
     size_t bytes = 0;
     TVC_CHECK(ragged_batch_bytes(ctx, batches, Lmax, N, &bytes, noise_angle ? 1 : 0));      // one dry walk per batch: host time on the launch path
     if (bytes > ws_bytes) return fail(ctx, TVC_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", bytes, ws_bytes);
@@ -1220,6 +1256,13 @@ int tvc_sola_f32(tvc_ctx* ctx, void* stream, const float* y, float* sola_buf, co
         return fail(ctx, TVC_ERR_ARG, "tvc_sola_f32: bad argument (Ly must cover block+1920+1920+3840)");
     TVC_HIP(ctx, hipSetDevice(ctx->device));
     return run_sola(ctx, (hipStream_t)stream, y, sola_buf, fade_in, out, shift_out, S, Ly, block, use_phase_vocoder);
+}
+
+int tvc_stream_push_f32(tvc_ctx* ctx, void* stream, float* buf, const float* blocks, int S, int64_t n, int block) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!buf || !blocks || S <= 0 || block <= 0 || n < block || n > 32768) return fail(ctx, TVC_ERR_ARG, "tvc_stream_push_f32: bad argument (block <= n <= 32768)");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    return run_stream_push(ctx, (hipStream_t)stream, buf, blocks, S, (int)n, block);
 }
 
 }  // extern "C"

@@ -116,6 +116,26 @@ static __global__ __launch_bounds__(256) void pooled_max_kernel(const float* __r
     }
 }
 
+// the same for a ragged batch: utterance b = blockIdx.x pools ITS floor(7.5 tb) + 1 values (energy_rag_kernel's layout) - the bound its own B = 1 call computes
+static __global__ __launch_bounds__(256) void pooled_max_rag_kernel(const float* __restrict__ e, RagDev rg, float* __restrict__ emax, float* __restrict__ spec_bound, float* __restrict__ zero, int nz) {
+    __shared__ float red[4];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nz; i += gridDim.x * 256) zero[i] = 0.f;
+    const int b = blockIdx.x;
+    const int L = rg.tb[b] * kHop, ne = (L + 2 * 32 - 128) / 64 + 1;
+    const float* p = e + (15L * rg.pre[b]) / 2;
+    float m = 0.f;
+    for (int j = threadIdx.x; j < ne; j += 256) m = fmaxf(m, p[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        emax[b] = m;
+        if (spec_bound) spec_bound[b] = fmaf(960.5f, m, 0.f);
+    }
+}
+
 int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, float* energy, int B, int64_t L, float* emax, float* spec_bound, float* zero, int nz) {
     const int ne = (int)((L + 2 * 32 - 128) / 64 + 1);
     float* e = ws.get<float>((size_t)B * ne + 8);
@@ -125,6 +145,7 @@ int run_energy(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* wav, 
         TVC_CHECK(rag_view(ctx, s, kHop, 0, &rg, nullptr));
         const int gx = ctx->rag->B >= 32 ? 8 : 64;
         hipLaunchKernelGGL(energy_rag_kernel, dim3(gx, ctx->rag->B), dim3(256), 0, s, wav, e, energy, rg, 0);
+        if (emax) hipLaunchKernelGGL(pooled_max_rag_kernel, dim3(ctx->rag->B), dim3(256), 0, s, e, rg, emax, spec_bound, zero, nz);
         hipLaunchKernelGGL(energy_rag_kernel, dim3(gx * 4, ctx->rag->B), dim3(256), 0, s, wav, e, energy, rg, 1);
         return launch_check(ctx, "energy (ragged)");
     }

@@ -27,9 +27,9 @@ namespace tvc {
 
 constexpr int KD = kSslDim;        // 768
 constexpr int STEPS = KD / 16;     // 48 K16 steps per index tile
-constexpr int HDR = 64;            // blob header, floats: [0] magic, [1] kind, [2] N (low 32 bits), [3] N (high), [4] |max| of the raw vectors (a float)
+constexpr int HDR = 64;            // blob header, floats: [0] magic, [1] kind, [2] N (low 32 bits), [3] N (high), [4] |max| of the raw vectors (a float), [5] format version (tvc_common.h)
 constexpr int KIND_F32 = 0, KIND_F16 = 1;
-constexpr int BLOB_MAGIC = 0x54564B4E;
+constexpr int BLOB_MAGIC = kBlobMagic;
 // fp32 kind:  header | rows fp32 [N][768] | bf16x3 image of v / den [Npad*768*3 bf16] | inv = 1 / den [Npad] | fp16 image of v / den [Npad*768]
 // fp16 kind:  header | inv [Npad] | fp16 image of the raw vectors [Npad*768] | largest inv of every 128-vector tile [Npad/128]
 // (both fp16 images in the 128-vector-tiled MFMA lane order, one part)
@@ -72,6 +72,7 @@ static __global__ void blob_header_kernel(float* blob, int kind, long N) {
         h[1] = kind;
         h[2] = (int)(N & 0xffffffffL);
         h[3] = (int)(N >> 32);
+        h[5] = kBlobVersion;
     }
 }
 

@@ -223,4 +223,32 @@ int run_sola(tvc_ctx* ctx, hipStream_t s, const float* y, float* sola_buf, const
     return launch_check(ctx, "sola");
 }
 
+// The rolling input buffer of a stream (stream.py:69-70: `input_wav = roll(input_wav, -block)`, `input_wav[-block:] = block`), in place and in
+// ONE launch instead of three ATen kernels: buf[st][i] = buf[st][i + m] for i < n - m, buf[st][n - m + j] = blocks[st][j].  One workgroup per
+// stream reads the whole row into registers (PER x 1024 >= n), meets at a barrier, writes it back shifted.
+template <int PER>
+static __global__ __launch_bounds__(1024) void stream_push_kernel(float* __restrict__ buf, const float* __restrict__ blocks, int n, int m) {
+    float* b = buf + (long)blockIdx.x * n;
+    const float* nb = blocks + (long)blockIdx.x * m;
+    float v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = threadIdx.x + j * 1024;
+        v[j] = i < n - m ? b[i + m] : (i < n ? nb[i - (n - m)] : 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = threadIdx.x + j * 1024;
+        if (i < n) b[i] = v[j];
+    }
+}
+int run_stream_push(tvc_ctx* ctx, hipStream_t s, float* buf, const float* blocks, int S, int n, int m) {
+    const int per = (n + 1023) / 1024;
+    if (per <= 16) hipLaunchKernelGGL(stream_push_kernel<16>, dim3((unsigned)S), dim3(1024), 0, s, buf, blocks, n, m);
+    else if (per <= 32) hipLaunchKernelGGL(stream_push_kernel<32>, dim3((unsigned)S), dim3(1024), 0, s, buf, blocks, n, m);
+    else return fail(ctx, TVC_ERR_ARG, "stream_push: a stream buffer holds at most 32 768 samples");
+    return launch_check(ctx, "stream_push");
+}
+
 }  // namespace tvc

@@ -99,6 +99,7 @@ struct tvc_ctx {
     hipStream_t side = nullptr;               // fork/join stream: the pitch estimator runs beside the SSL chain
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     tvc::RagHost* rag = nullptr;              // the ragged batch the drivers are currently running for (ragged.h); nullptr = equal lengths
+    int rag_batch_frames = 0;                 // tvc_ctx_set_ragged_batch_frames: frames per in-kernel batch of THIS context's ragged calls (0 = the default)
     bool enc_ready = false, dec_ready = false;  // which checkpoint groups tvc_finalize_weights packed
     char enc_missing[160] = {0}, dec_missing[160] = {0};
     std::map<std::string, tvc::HostTensor> host;  // staged checkpoint tensors
@@ -232,6 +233,9 @@ const float* knn_index_amax(const float* prepared);
 int run_slot_affine(tvc_ctx*, hipStream_t, float* out, const float* in, int in_stride, float a, float c, int n);
 int run_slot_prep(tvc_ctx*, hipStream_t, float* zero, int nz, float* o1, const float* in1, int s1, float a1, float c1, float* o2, const float* in2, int s2, float a2,
                   float c2, float* o3, float a3, float c3, int n);
+// prepared kNN blob (knn.hip): header word 0 = magic, word 5 = format version.  Version 2 (round 5): word 4 holds the raw vectors' |max| (a float), which
+// the decoder takes as the bound of `matched` - a blob of another version has 0 there (= "no scaling": the fp16 range guard silently off) and is refused.
+constexpr int kBlobMagic = 0x54564B4E, kBlobVersion = 2;
 constexpr int kFilterSlotX = 2;       // ... and the one of its input contraction's output (S_X)
 constexpr int kFilterSlots = 41;      // run_filter's |max| slots per utterance (decoder.hip S_COUNT)
       // device pointer to the prepared index's |max| (one float)
@@ -267,6 +271,7 @@ int run_dsp(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* f0, const float* 
             const float* angle, uint64_t seed, float* source, int B, int T, float* smax = nullptr);
 int run_sola(tvc_ctx*, hipStream_t, const float* y, float* sola_buf, const float* fade_in, float* out, int32_t* shift_out,
              int S, int64_t Ly, int block, int use_pv);
+int run_stream_push(tvc_ctx* ctx, hipStream_t s, float* buf, const float* blocks, int S, int n, int m);
 int64_t resample_out_len(int64_t n, int orig_freq, int new_freq);
 int run_resample(tvc_ctx*, hipStream_t, const float* x, float* y, int rows, int64_t n, int orig_freq, int new_freq);
 int run_pcm16_to_f32(tvc_ctx*, hipStream_t, const int16_t* pcm, float* y, int64_t n, float gain_db);

@@ -93,6 +93,10 @@ class Engine:
         ws = self.workspace(B, L, N)
         return _ptr(ws), ctypes.c_size_t(ws.numel())
 
+    def set_ragged_batch_frames(self, max_frames):
+        """Frames per in-kernel batch of this engine's ragged calls (0 = the default, 80 000); results do not depend on it."""
+        self._ok(self.lib.tvc_ctx_set_ragged_batch_frames(self.ctx, int(max_frames)), "tvc_ctx_set_ragged_batch_frames")
+
     def next_seed(self):
         self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         return self._seed
@@ -405,6 +409,16 @@ class Engine:
         self._ok(self.lib.tvc_convert_ragged_f32(self.ctx, self._stream(), _ptr(wav), Lmax, lens, _ptr(prepared), N, float(pitch_shift), _ptr(a), seed,
                                                  _ptr(wave), B, _ptr(self._ws), ctypes.c_size_t(self._ws.numel())), "tvc_convert_ragged_f32")
         return wave
+
+    def stream_push(self, buf, blocks):
+        """buf [S, n] <- (buf[:, m:], blocks [S, m]) in place, one launch (stream.py:69-70's roll + slice assignment)."""
+        _check_dev(buf, "buf", self.device)
+        blocks = _prep(blocks, "blocks", self.device)
+        S, n = buf.shape
+        if blocks.shape[0] != S or not buf.is_contiguous() or buf.dtype != _F32:
+            raise ValueError("stream_push: buf [S, n] contiguous fp32, blocks [S, m]")
+        self._ok(self.lib.tvc_stream_push_f32(self.ctx, self._stream(), _ptr(buf), _ptr(blocks), S, n, blocks.shape[1]), "tvc_stream_push_f32")
+        return buf
 
     def sola(self, y, sola_buf, fade_in, block, use_phase_vocoder=False, want_shift=False):
         """y [S, Ly]; sola_buf [S, 1920] updated in place; returns out [S, block] (and shifts)."""

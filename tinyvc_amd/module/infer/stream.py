@@ -46,9 +46,8 @@ class BatchedStreamInfer:
         self._calls = 0
 
     def _step(self, blocks, noise_angle):
-        # torch.roll + slice assignment of the reference (stream.py:69-70), in place on a fixed buffer
-        self.input_wav.copy_(torch.roll(self.input_wav, -self.block_size, dims=1))
-        self.input_wav[:, -self.block_size:] = blocks
+        # torch.roll + slice assignment of the reference (stream.py:69-70), in place on a fixed buffer, one launch
+        self.generator.engine(self.device).stream_push(self.input_wav, blocks)
         if noise_angle is None and self.use_graph:
             # a captured step bakes kernel arguments in: the library's seeded draw would replay ONE seed for every block.  torch's
             # generator is graph-safe (its offset advances per replay), so the graph path keeps the reference's torch.rand draw
