@@ -149,6 +149,15 @@ int tvc_knn_forget(tvc_ctx* ctx, const float* prepared);
 int tvc_knn_match_f32(tvc_ctx* ctx, void* stream, const float* src, const float* prepared, int64_t N,
                       float* out, int64_t* idx_out, int B, int T, void* ws, size_t ws_bytes);
 
+/* match_features with the reference's full signature (module/tinyvc/feature_retrieval.py:15-33): the k = 1 ... 8 nearest index vectors of
+ * every source frame under metric 0 = 'cos', 1 = 'IP' (inner product), 2 = 'L2' (negative Euclidean distance), out = the mean of the k RAW
+ * vectors (alpha blending is the caller's one-liner).  src [B,768,T]; index [768,N] = the raw [1,768,N] tensor of index.pt (no prepared
+ * blob: this is not the inference path - that asks for k = 4, 'cos' and runs tvc_knn_match_f32 - but every other argument the reference
+ * accepts, in plain fp32 on the raw vectors); out [B,768,T]; idx_out [B,T,k] int64 and sim_out [B,T,k] (nullable) = torch.topk's indices
+ * and values in rank order, equal similarities by lower index.  N >= k.  Workspace: B * T * k * 8 bytes + 4096 when idx_out is NULL. */
+int tvc_knn_match_general_f32(tvc_ctx* ctx, void* stream, const float* src, const float* index, int64_t N, int k, int metric,
+                              float* out, int64_t* idx_out, float* sim_out, int B, int T, void* ws, size_t ws_bytes);
+
 /* pitch shift ----------------------------------------------------------------------------- */
 /* Index-sharded variant of the match (a very large speaker index split over the GPUs of a node):
  * every rank holds a prepared shard and

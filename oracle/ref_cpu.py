@@ -127,20 +127,29 @@ def encoder_infer(sd, spec):
 
 
 # --------------------------------------------------------------------------- kNN match (a10)
-def match_features(source, reference, k=4, return_indices=False):
-    """reference module/tinyvc/feature_retrieval.py:15-33 with metrics='cos', alpha=0 —
-    cosine top-k of every source frame against the index, mean of the k raw index vectors.
+def match_features(source, reference, k=4, return_indices=False, metrics="cos", alpha=0.0):
+    """reference module/tinyvc/feature_retrieval.py:15-33 - top-k of every source frame against the index under `metrics`
+    ('cos' :24-27, 'IP' :20-21, 'L2' :22-23), mean of the k raw index vectors (:30), blended with the input by alpha (:33).
     `reference` may have batch 1 (broadcast; the reference's bmm needs equal batch)."""
     if reference.shape[0] == 1 and source.shape[0] != 1:
         reference = reference.expand(source.shape[0], -1, -1)
     s = source.transpose(1, 2)
     r = reference.transpose(1, 2)
-    rn = r / (torch.norm(r, dim=2, keepdim=True, p=2) + 1e-6)
-    sn = s / (torch.norm(s, dim=2, keepdim=True, p=2) + 1e-6)
-    sims = torch.bmm(sn, rn.transpose(1, 2))
+    if metrics == "IP":
+        sims = torch.bmm(s, r.transpose(1, 2))
+    elif metrics == "L2":
+        sims = -torch.cdist(s, r)
+    elif metrics == "cos":
+        rn = r / (torch.norm(r, dim=2, keepdim=True, p=2) + 1e-6)
+        sn = s / (torch.norm(s, dim=2, keepdim=True, p=2) + 1e-6)
+        sims = torch.bmm(sn, rn.transpose(1, 2))
+    else:
+        raise ValueError(metrics)
     best = torch.topk(sims, k, dim=2)
     picked = torch.stack([r[n][best.indices[n]] for n in range(s.shape[0])], dim=0)
     out = picked.mean(dim=2).transpose(1, 2)
+    if alpha != 0.0:
+        out = out * (1 - alpha) + source * alpha
     if return_indices:
         return out, best.indices, sims
     return out

@@ -389,3 +389,48 @@ def test_index_sharded_topk_slots_finish_equal_single_call():
         slots = part if slots is None else slots + part
     got = eng.knn_finish(slots)
     assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_match_features_every_metric_and_k_against_the_reference_fixture():
+    """The reference's full match_features signature (feature_retrieval.py:15-33: k, alpha, metrics in 'cos' / 'IP' / 'L2') through the module
+    mirror -> tvc_knn_match_general_f32: indices identical to the reference's on the gap-checked fixture, the matched output (a mean of raw
+    index rows, blended by alpha) within one rounding of it; argument errors as in the reference."""
+    import os
+    import numpy as np
+    from helpers import GOLDEN
+    from tinyvc_amd.module.tinyvc import match_features
+    g = np.load(os.path.join(GOLDEN, "match_general.npz"))
+    B, T, N = int(g["batch"]), int(g["frames"]), int(g["index_size"])
+    src = synth.synth_tensor(str(g["source_key"]), (B, 768, T), seed=int(g["source_seed"])).to(DEV)
+    ref = synth.synth_index(N, seed=int(g["index_seed"])).to(DEV)
+    for case in g["cases"]:
+        k, metric, alpha = str(case).split("|")
+        tag = f"k{k}_{metric}_a{alpha}"
+        out, idx = match_features(src, ref, k=int(k), alpha=float(alpha), metrics=metric, return_indices=True)
+        assert idx.shape == (B, T, int(k)) and torch.equal(idx.cpu(), torch.from_numpy(g[f"idx_{tag}"])), tag
+        want = torch.from_numpy(g[f"out_{tag}"])
+        err = float((out.cpu() - want).abs().max() / want.abs().max())
+        assert err <= 2e-7, (tag, err)
+    # one index per utterance (reference batch B), and the default arguments still take the prepared-index search
+    refB = torch.stack([synth.synth_index(N, seed=int(g["index_seed"]))[0], synth.synth_index(N, seed=int(g["index_seed"]) + 1)[0]]).to(DEV)
+    outB, idxB = match_features(src, refB, k=3, metrics="IP", return_indices=True)
+    assert torch.equal(idxB[0].cpu(), torch.from_numpy(g["idx_k3_IP_a0.0"])[0])
+    o4, i4 = match_features(src, ref, return_indices=True)
+    og, ig = match_features(src, ref, k=4, metrics="cos", alpha=0.0, return_indices=True)
+    assert torch.equal(o4, og) and torch.equal(i4, ig)
+    # the general kernel at k = 4 / 'cos' agrees with the prepared-index search on this gap-checked index
+    eng = gen_engine()
+    o2, i2 = eng.knn_match_general(src, ref[0], 4, "cos", want_indices=True)
+    assert torch.equal(i2, i4) and float((o2 - o4).abs().max()) <= 2e-7 * float(o4.abs().max())
+    with pytest.raises(NotImplementedError):
+        match_features(src, ref, k=9)
+    with pytest.raises(ValueError):
+        match_features(src, ref, k=2, metrics="manhattan")
+    with pytest.raises(RuntimeError):
+        match_features(src, ref[:, :, :3], k=5, metrics="L2")
+
+
+def gen_engine():
+    from tinyvc_amd.engine import default_engine
+    return default_engine(torch.device(DEV))

@@ -2,6 +2,8 @@
 itself (tools/gen_golden.py).  The oracle runs the same ATen CPU ops as the reference, so the
 match is exact (torch.equal) wherever the op sequence is the same; a tolerance appears only where
 the restatement orders fp32 ops differently."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -90,3 +92,20 @@ def test_knn_fixture_gaps_are_decidable():
     (~2e-7 for unit vectors of dim 768)."""
     for case in CASES:
         assert float(load_golden(case)["knn_min_gap64"]) > 2e-6
+
+
+def test_match_features_with_every_metric_and_k_equals_the_reference():
+    """feature_retrieval.py:15-33 with the arguments the inference path never passes (k, alpha, metrics): the oracle against the reference's
+    own outputs on the gap-checked fixture of tools/gen_golden.py --match-only."""
+    import numpy as np
+    from helpers import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "match_general.npz"))
+    src = synth.synth_tensor(str(g["source_key"]), (int(g["batch"]), 768, int(g["frames"])), seed=int(g["source_seed"]))
+    ref = synth.synth_index(int(g["index_size"]), seed=int(g["index_seed"]))
+    assert len(g["cases"]) >= 8
+    for case in g["cases"]:
+        k, metric, alpha = str(case).split("|")
+        tag = f"k{k}_{metric}_a{alpha}"
+        out, idx, _sims = R.match_features(src, ref, k=int(k), return_indices=True, metrics=metric, alpha=float(alpha))
+        assert torch.equal(idx, torch.from_numpy(g[f"idx_{tag}"])), tag
+        assert torch.equal(out, torch.from_numpy(g[f"out_{tag}"])), tag

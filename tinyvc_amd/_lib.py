@@ -38,6 +38,7 @@ SIGNATURES = {
     "tvc_ctx_set_ragged_batch_frames": (c_int, [c_void_p, c_int]),
     "tvc_knn_prepare_index_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
     "tvc_knn_match_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
+    "tvc_knn_match_general_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_knn_topk_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "tvc_knn_gather_slots_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64]),
     "tvc_knn_finish_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("TVC_LIB_PATH") or os.path.join(HERE, "libtinyvc_hip.so")
-SOURCES = ["api.hip", "ragged.hip", "frontdoor.hip", "frontend.hip", "fft.hip", "encoder.hip", "knn.hip", "decoder.hip", "filter_up24s.hip", "conv48s.hip", "sola.hip"]
+SOURCES = ["api.hip", "ragged.hip", "frontdoor.hip", "frontend.hip", "fft.hip", "encoder.hip", "knn.hip", "knn_general.hip", "decoder.hip", "filter_up24s.hip", "conv48s.hip", "sola.hip"]
 # -ffp-contract=on: a*b+c written as ONE expression may become an fma, but products and sums that the source keeps apart
 # (the __fmul_rn / __fadd_rn helpers are plain inline functions in HIP, not barriers) are NOT fused after inlining - the
 # default (fast) fused them, which broke the op-for-op restatements of ATen arithmetic (shift_frequency, pitch softmax, OLA).

@@ -1002,6 +1002,20 @@ int tvc_knn_match_f32(tvc_ctx* ctx, void* stream, const float* src, const float*
             run_knn(ctx, s, ws, false, src, prepared, N, out, idx_out, B, T));
 }
 
+int tvc_knn_match_general_f32(tvc_ctx* ctx, void* stream, const float* src, const float* index, int64_t N, int k, int metric, float* out,
+                              int64_t* idx_out, float* sim_out, int B, int T, void* wsp, size_t ws_bytes) {
+    if (!ctx) return TVC_ERR_ARG;
+    if (!src || !index || !out || B <= 0 || T <= 0) return fail(ctx, TVC_ERR_ARG, "tvc_knn_match_general_f32: bad argument");
+    if (k < 1 || k > 8) return fail(ctx, TVC_ERR_ARG, "tvc_knn_match_general_f32: k must be 1 ... 8");
+    if (metric < 0 || metric > 2) return fail(ctx, TVC_ERR_ARG, "tvc_knn_match_general_f32: metric is 0 ('cos'), 1 ('IP') or 2 ('L2')");
+    if (N < k) return fail(ctx, TVC_ERR_ARG, "tvc_knn_match_general_f32: selected index k out of range (the index has fewer than k vectors; torch.topk raises too)");
+    if (N > 0x7ffffffe || (long)B * T > 0x7fffffff) return fail(ctx, TVC_ERR_ARG, "tvc_knn_match_general_f32: sizes beyond 32-bit indexing");
+    TVC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    TVC_RUN(run_knn_general(ctx, s, ws, true, src, index, N, k, metric, out, idx_out, sim_out, B, T),
+            run_knn_general(ctx, s, ws, false, src, index, N, k, metric, out, idx_out, sim_out, B, T));
+}
+
 int tvc_knn_topk_f32(tvc_ctx* ctx, void* stream, const float* src, const float* prepared, int64_t N, float* sims_out,
                      int64_t* idx_out, int B, int T, void* wsp, size_t ws_bytes) {
     if (!ctx) return TVC_ERR_ARG;

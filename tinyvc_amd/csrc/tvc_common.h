@@ -248,6 +248,9 @@ int run_knn(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* src, const float*
             float* out, int64_t* idx_out, int B, int T);
 int run_knn_topk(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* src, const float* prepared, int64_t N,
                  float* sims_out, int64_t* idx_out, int B, int T);
+// match_features for any k <= 8 and metric (0 cos, 1 IP, 2 L2) on the RAW index [768][N] in plain fp32 (knn_general.hip)
+int run_knn_general(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* src, const float* index, int64_t N, int k, int metric, float* out, int64_t* idx_out,
+                    float* val_out, int B, int T);
 int run_knn_slots(tvc_ctx*, hipStream_t, const float* prepared, int64_t N, const int64_t* idx, float* slots, int64_t nslots);
 int run_knn_finish(tvc_ctx*, hipStream_t, const float* slots, float* out, int B, int T);
 int run_shift(tvc_ctx*, hipStream_t, const float* f0, float* out, int64_t n, float semitones);

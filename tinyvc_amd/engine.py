@@ -241,6 +241,29 @@ class Engine:
         return (out, idx) if want_indices else out
 
     # ---- index-sharded match (one prepared index shard per rank; merged by parallel.match_features_sharded) ----
+    METRICS = {"cos": 0, "IP": 1, "L2": 2}
+
+    def knn_match_general(self, src, index, k, metrics, want_indices=False):
+        """match_features for any k in 1..8 and metrics in {'cos', 'IP', 'L2'} on the RAW index [768, N] (plain fp32, csrc/knn_general.hip):
+        src [B, 768, T] -> matched [B, 768, T] (, indices [B, T, k] int64 in rank order)."""
+        src = _prep(src, "source", self.device)
+        index = _prep(index, "index", self.device)
+        if metrics not in self.METRICS:
+            raise ValueError(f"metrics must be one of {sorted(self.METRICS)}, got {metrics!r}")
+        if index.dim() != 2 or index.shape[0] != spec.SSL_DIM or src.dim() != 3 or src.shape[1] != spec.SSL_DIM:
+            raise ValueError("knn_match_general: src [B, 768, T], index [768, N]")
+        B, _, T = src.shape
+        N = index.shape[1]
+        if not 1 <= int(k) <= 8:
+            raise NotImplementedError("the HIP kernel serves k = 1 ... 8")
+        if N < k:
+            raise RuntimeError("selected index k out of range")      # what torch.topk raises in the reference
+        out = torch.empty(B, spec.SSL_DIM, T, dtype=_F32, device=self.device)
+        idx = torch.empty(B, T, int(k), dtype=torch.int64, device=self.device)
+        self._ok(self.lib.tvc_knn_match_general_f32(self.ctx, self._stream(), _ptr(src), _ptr(index), N, int(k), self.METRICS[metrics], _ptr(out), _ptr(idx), None,
+                                                    B, T, None, 0), "tvc_knn_match_general_f32")
+        return (out, idx) if want_indices else out
+
     def knn_topk(self, src, prepared, N):
         """This shard's top-4 per query: (sims [B,T,4] fp32 descending, idx [B,T,4] int64 local indices)."""
         src = _prep(src, "source", self.device)

@@ -218,10 +218,72 @@ def headline_cases(rt, ri, ru, enc, dec):
     print("convert_cfg2_B4_T200 index seed", seed, "kNN min fp64 gap", gap, b["knn_min_gap64"], "wave rms", float(np.sqrt((b["wave"] ** 2).mean())))
 
 
+MATCH_CASES = [(1, "cos", 0.0), (2, "cos", 0.5), (8, "cos", 0.0), (3, "IP", 0.0), (8, "IP", 0.25), (4, "L2", 0.0), (8, "L2", 0.0), (1, "L2", 0.75)]
+
+
+def match_general_case(rt):
+    """match_features with the arguments the inference path never passes (feature_retrieval.py:15: k, alpha, metrics): the reference's own
+    function on a seeded source [2, 768, 40] and a 1 000-vector index whose seed is searched until, for EVERY metric, the nine largest
+    similarities of every query are separated in fp64 by more than 20 times the largest error the reference's own fp32 evaluation makes on
+    that input - so any fp32 evaluation of comparable accuracy ranks them alike - and the reference's fp32 ranks ARE the fp64 ones (asserted).  Stored per case: the reference's output and the top-k indices."""
+    B, T, N = 2, 40, 1000
+    src = synth.synth_tensor("match.source", (B, 768, T), seed=7)
+
+    def sims64(s, r, metric):
+        s, r = s.double().transpose(1, 2), r.double().transpose(1, 2)
+        if metric == "IP":
+            return torch.bmm(s, r.transpose(1, 2))
+        if metric == "L2":
+            return -torch.cdist(s, r, compute_mode="donot_use_mm_for_euclid_dist")
+        return torch.bmm(s / (s.norm(dim=2, keepdim=True) + 1e-6), (r / (r.norm(dim=2, keepdim=True) + 1e-6)).transpose(1, 2))
+
+    def sims32(s, r, metric):       # the reference's own fp32 expressions (feature_retrieval.py:20-28)
+        s, r = s.transpose(1, 2), r.transpose(1, 2)
+        if metric == "IP":
+            return torch.bmm(s, r.transpose(1, 2))
+        if metric == "L2":
+            return -torch.cdist(s, r)
+        return torch.bmm(s / (torch.norm(s, dim=2, keepdim=True, p=2) + 1e-6), (r / (torch.norm(r, dim=2, keepdim=True, p=2) + 1e-6)).transpose(1, 2))
+
+    seed = None
+    for cand in range(50, 1000):
+        ref = synth.synth_index(N, seed=cand).expand(B, -1, -1)
+        ok = True
+        for metric in ("cos", "IP", "L2"):
+            t64 = sims64(src, ref, metric)
+            v = torch.topk(t64, 9, dim=2).values
+            gap = float((v[..., :-1] - v[..., 1:]).min())
+            err = float((sims32(src, ref, metric).double() - t64).abs().max())       # what fp32 evaluation costs on this very input
+            if gap <= 20.0 * err:
+                ok = False
+                break
+        if ok:
+            seed = cand
+            break
+    if seed is None:
+        raise SystemExit("no index seed with decidable top-9 under all three metrics")
+    ref = synth.synth_index(N, seed=seed).expand(B, -1, -1).contiguous()
+    out = {"source_key": np.array("match.source"), "source_seed": np.int64(7), "batch": np.int64(B), "frames": np.int64(T), "index_size": np.int64(N),
+           "index_seed": np.int64(seed), "cases": np.array([f"{k}|{m}|{a}" for k, m, a in MATCH_CASES])}
+    with torch.inference_mode():
+        for k, metric, alpha in MATCH_CASES:
+            res = rt.match_features(src, ref, k=k, alpha=alpha, metrics=metric)           # the reference's function
+            idx64 = torch.topk(sims64(src, ref, metric), k, dim=2).indices
+            idx = torch.topk(sims32(src, ref, metric), k, dim=2).indices
+            assert torch.equal(idx, idx64), f"k={k} {metric}: the reference's fp32 ranks differ from the fp64 ones - fixture undecidable"
+            tag = f"k{k}_{metric}_a{alpha}"
+            out[f"out_{tag}"] = np32(res)
+            out[f"idx_{tag}"] = np32(idx).astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "match_general.npz"), **out)
+    print("match_general: index seed", seed, "cases", len(MATCH_CASES))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     rt, ri, ru = import_reference()
+    if "--match-only" in sys.argv:
+        return match_general_case(rt)
     enc, dec = build_models(rt, seed=0)
     if "--headline-only" in sys.argv:
         return headline_cases(rt, ri, ru, enc, dec)
@@ -263,6 +325,7 @@ def main():
     print("stream(pv) shifts", c2["shift"])
 
     headline_cases(rt, ri, ru, enc, dec)
+    match_general_case(rt)
 
 
 if __name__ == "__main__":
