@@ -5,7 +5,7 @@ TAG=${1:-rXX}
 O=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $O
 rm -f $O/parity.log
-timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -3 > $O/${TAG}_pytest_gpu.txt
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/${TAG}_pytest_gpu.txt
 cp $O/parity.log $O/${TAG}_parity.log 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p1 /tmp/p2 /tmp/p3
