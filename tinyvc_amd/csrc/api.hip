@@ -608,7 +608,10 @@ int tvc_ctx_create(int hip_device, tvc_ctx** out) {
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, TVC_SIDE_PRIO_EXPR) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_amps, hipEventDisableTiming) != hipSuccess) {
         tvc_ctx_destroy(c);
         return TVC_ERR_HIP;
     }
@@ -626,6 +629,9 @@ void tvc_ctx_destroy(tvc_ctx* ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_fork2) (void)hipEventDestroy(ctx->ev_fork2);
+    if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
+    if (ctx->ev_amps) (void)hipEventDestroy(ctx->ev_amps);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     frontdoor_release(ctx);
     if (ctx->arena) (void)hipFree(ctx->arena);

@@ -193,7 +193,7 @@ static __global__ __launch_bounds__(256) void noise_ola_kernel(const float* __re
 // =================================================================================================
 // cmax: per-utterance |max| slot of `content` (block-floating-point guard of the fp16 split, conv3s.h)
 static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
-                          const float* energy, float* amps, float* kern, int B, int T, const float* cmax, float* xmax_zeroed) {
+                          const float* energy, float* amps, float* kern, int B, int T, const float* cmax, float* xmax_zeroed, hipEvent_t amps_ready = nullptr) {
     const int ncols = B * T;
     float* ef = ws.get<float>((size_t)B * T);
     float* x = ws.get<float>((size_t)B * kSrcCh * T);
@@ -212,18 +212,32 @@ static int run_source_net(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const f
     // to_amps (128 -> 15 rows: one 32-row m-tile)
     EpiBias<ACT_ELU1, false> ea{amps, ctx->src_to_amps.bias, nullptr, kHarm, T, ncols, (long)kHarm * T, 0};
     TVC_CHECK((gemm_s_launch<1, 4, 2>(ctx, s, ctx->src_to_amps, x, B, kSrcCh, T, 0, ea, xmax)));
+    if (amps_ready) TVC_HIP(ctx, hipEventRecord(amps_ready, s));      // (run_decoder's fork: the oscillator on the side stream starts here, beside to_kernel)
     // to_kernel (128 -> 961 rows): the one sizeable contraction of the net, on the split-precision path
     EpiBias<ACT_ELU1, false> ek{kern, ctx->src_to_kernel.bias, nullptr, kBins, T, ncols, (long)kBins * T, 0};
     TVC_CHECK((gemm_s_launch<2, 4, 2>(ctx, s, ctx->src_to_kernel, x, B, kSrcCh, T, 0, ek, xmax)));
     return launch_check(ctx, "source_net");
 }
 
+// the oscillator's per-frame phase sums and their exclusive scan: needs f0 only
+static int run_harm_sums(tvc_ctx* ctx, hipStream_t s, const float* f0, double* csum, int B, int T) {
+    const long L = (long)T * kHop;
+    const int NB = ctx->rag ? ctx->rag->B : B;
+    const int Tg = ctx->rag ? ctx->rag->Tlong : T;
+    RagDev rg;
+    TVC_CHECK(rag_view(ctx, s, 1, 0, &rg, nullptr));
+    const float scale_size = (float)T / (float)L;
+    hipLaunchKernelGGL(harm_frame_sum_kernel, dim3((Tg + 3) / 4, NB), dim3(256), 0, s, f0, csum, T, scale_size, rg);
+    hipLaunchKernelGGL(harm_frame_scan_kernel, dim3(kHarm, NB), dim3(64), 0, s, csum, T, rg);
+    return launch_check(ctx, "harm_sums");
+}
+
 // Decoder.dsp (decoder.py:259-266): f0 [B,1,T], amps [B,15,T], kernel [B,961,T] -> source [B,16,L]
 // smax (nullable): per-utterance |max| slot [B] of `source`, zeroed by the caller; the two kernels that write `source` publish into it
 int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, const float* amps, const float* kern,
-            const float* angle, uint64_t seed, float* source, int B, int T, float* smax) {
+            const float* angle, uint64_t seed, float* source, int B, int T, float* smax, const DspFork* fk) {
     const long L = (long)T * kHop;
-    double* csum = ws.get<double>((size_t)B * kHarm * T);
+    double* csum = fk ? fk->csum : ws.get<double>((size_t)B * kHarm * T);
     float* frames = ws.get<float>((size_t)B * T * kNfft);
     const int NB = ctx->rag ? ctx->rag->B : B;
     const int Tg = ctx->rag ? ctx->rag->Tlong : T;      // frames of the longest utterance: the per-utterance grids' extent
@@ -238,11 +252,16 @@ int run_dsp(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* f0, cons
     // harmonics -> source[:, 0:15]
     const float scale_size = (float)T / (float)L;         // F.interpolate(f0, Lw): size given
     const float scale_amp = (float)(1.0 / (double)kHop);  // F.interpolate(amps, scale_factor=480)
-    hipLaunchKernelGGL(harm_frame_sum_kernel, dim3((Tg + 3) / 4, NB), dim3(256), 0, s, f0, csum, T, scale_size, rg);
-    hipLaunchKernelGGL(harm_frame_scan_kernel, dim3(kHarm, NB), dim3(64), 0, s, csum, T, rg);
-    hipLaunchKernelGGL(harm_synth_kernel, dim3((Tg + 3) / 4, NB), dim3(256), 0, s, f0, amps, csum, source, T, scale_size, scale_amp, rg);
+    hipStream_t sh = s;      // the harmonic branch's stream
+    if (fk) {                // forked (equal-length batches only): the frame sums are already scanned on the side stream; the synthesis waits for the amplitudes
+        sh = fk->side;
+        TVC_HIP(ctx, hipStreamWaitEvent(sh, fk->amps_ready, 0));
+    } else {
+        TVC_CHECK(run_harm_sums(ctx, s, f0, csum, B, T));
+    }
+    hipLaunchKernelGGL(harm_synth_kernel, dim3((Tg + 3) / 4, NB), dim3(256), 0, sh, f0, amps, csum, source, T, scale_size, scale_amp, rg);
     // the 15 harmonic rows are sin(.) * voiced gate * interpolated amps: bounded by the amplitudes' own |max| (3 000 values per utterance)
-    TVC_CHECK(run_amax_rows(ctx, s, amps, B, kHarm, T, smax));
+    TVC_CHECK(run_amax_rows(ctx, sh, amps, B, kHarm, T, smax));
     // noise -> source[:, 15]: kernel * exp(i angle) -> inverse 1920-point FFT per frame (fft.hip) -> overlap-add
     // (angle == nullptr: the kernel draws the phases itself while it stages the tile - small_kernels.h noise_phase_hash(seed, row, bin, frame) -,
     // no [B][961][T] phase tensor is written or read)
@@ -328,14 +347,23 @@ static __global__ void g8_to_planar_kernel(const float* __restrict__ x, float* _
 }
 
 // cmax / smax (nullable): |max| slots of `content` / of cat[source, energy] if the caller already has them
+// FilterNet's input contraction x0 = content_in(content) + f0 embedding (decoder.py:224-226): needs `content`, `f0` and content's |max| slot only
+static int filter_input_gemm(tvc_ctx* ctx, hipStream_t s, const float* content, const float* f0, float* x, int B, int T, const float* cmax) {
+    EpiSumCond ep{x, ctx->flt_content_in.bias, nullptr, f0, nullptr, nullptr, ctx->flt_f_w, ctx->flt_f_b, 384, T, B * T};
+    int rc = 0;
+    if (!gemm_s2_try(&rc, ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax)) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax);
+    return rc;
+}
+
 int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* content, const float* f0,
-               const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps, const float* cmax, const float* smax, float* zeroed_slots, bool x_slot_set) {
+               const float* energy, const float* source, float* wave, int B, int T, const FilterTaps* taps, const float* cmax, const float* smax, float* zeroed_slots, bool x_slot_set,
+               float* x_pre, hipEvent_t x_ready) {
     const long L = (long)T * kHop;
     static const int ch[5] = {384, 192, 96, 48, 24};
     const long len_dn[5] = {L, L / 5, L / 20, L / 80, L / 240};   // skip i lives at len_dn[i]
     float* skip[5];
     for (int i = 0; i < 5; ++i) skip[i] = ws.get<float>((size_t)B * ch[4 - i] * len_dn[i]);
-    float* x = ws.get<float>((size_t)B * ch[0] * T);
+    float* x = x_pre ? x_pre : ws.get<float>((size_t)B * ch[0] * T);
     // Downsample i's input = interpolate(skip[i-1], 1/f), written by the conv that produces skip[i-1]
     float* xi_pre[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     for (int i = 1; i <= 4; ++i) xi_pre[i] = ws.get<float>((size_t)B * ctx->downs[i - 1].cin * len_dn[i]);
@@ -363,10 +391,7 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
             TVC_CHECK(run_amax_rows(ctx, s, energy, B, 1, L, slot(S_SRC)));
             smax = slot(S_SRC);
         }
-        EpiSumCond ep{x, ctx->flt_content_in.bias, nullptr, f0, nullptr, nullptr, ctx->flt_f_w, ctx->flt_f_b, ch[0], T, B * T};
-        int rc = 0;
-        if (!gemm_s2_try(&rc, ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax)) rc = gemm_s_launch<2, 4, 2>(ctx, s, ctx->flt_content_in, content, B, kSslDim, T, 0, ep, cmax);
-        TVC_CHECK(rc);
+        if (!x_ready) TVC_CHECK(filter_input_gemm(ctx, s, content, f0, x, B, T, cmax));      // (x_ready: the caller launched it on its side stream)
         // x0's |max| slot: the functor finishes the elements, so the slot is the bound bw |content|max + bb instead of a pass over x0
         if (!(zeroed_slots && x_slot_set)) TVC_CHECK(run_slot_affine(ctx, s, slot(S_X), cmax, 1, ctx->flt_in_bw, ctx->flt_in_bb, NB));
         // skips[0] is read as FiLM cond only (ups[4]): it is written as the two halves' ready operand; the fp32 tensor exists for the parity tap alone
@@ -404,6 +429,7 @@ int run_filter(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* conte
         }
         ws.release(mk);
     }
+    if (!dry && x_ready) TVC_HIP(ctx, hipStreamWaitEvent(s, x_ready, 0));      // the up path is x0's first reader: join here, behind the whole down path
     // up path: level outputs are persistent, block temporaries are released per level
     float* xlev[5];
     {
@@ -512,21 +538,54 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
         if (!content_bound) TVC_CHECK(run_amax_rows(ctx, s, content, B, kSslDim, T, cmax));
         if (!energy_bound) TVC_CHECK(run_amax_rows(ctx, s, energy, B, 1, L, smax));
     }
+    // FilterNet's input contraction (768 -> 384 at the frame rate: 48 us at the bench shape) reads nothing SourceNet or the DSP stage produce and
+    // its output is first read by Upsample 0, behind the whole down path: outside a stream capture (a fork inside a replayed graph costs more than
+    // it hides) and for equal-length batches (a ragged batch's tables are built on the launch stream) it runs on the
+    // context's side stream - free again since the encoder joined its pitch chain - beside SourceNet's small launches and the vector-ALU-bound
+    // oscillator, and run_filter waits for it where the up path begins.
+    float* x0 = nullptr;
+    double* csum = nullptr;
+    bool fork = false;
+    if (wave || dry) {      // (a dry run sizes the workspace for the full decoder whatever pointers it was handed)
+        x0 = ws.get<float>((size_t)B * 384 * T);
+        csum = ws.get<double>((size_t)B * kHarm * T);
+        fork = !dry && ctx->side && !ctx->rag && ctx->ev_fork2 && ctx->ev_join2 && ctx->ev_amps;
+        if (fork) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) fork = false;
+        }
+        if (fork) {
+            // The side stream's chain: the oscillator's frame sums (f0 only) -> FilterNet's input contraction -> [amplitudes ready] -> the harmonic
+            // synthesis (vector-ALU-bound, no LDS) beside SourceNet's to_kernel GEMM and the noise branch's FFTs on the launch stream.
+            TVC_HIP(ctx, hipEventRecord(ctx->ev_fork2, s));            // content, f0 and cmax are complete on s
+            TVC_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork2, 0));
+            TVC_CHECK(run_harm_sums(ctx, ctx->side, f0, csum, B, T));
+            {
+                ProfScope ps(ctx, ctx->side, dry, "filter_net.input@side");      // FilterNet's work outside its region on the launch stream: bench.py adds it to the roofline's duration
+                TVC_CHECK(filter_input_gemm(ctx, ctx->side, content, f0, x0, B, T, cmax));
+            }
+        }
+    }
     size_t mk = ws.mark();
     {
         ProfScope ps(ctx, s, dry, "source_net");
-        TVC_CHECK(run_source_net(ctx, s, ws, dry, content, f0, energy, amps, kern, B, T, cmax, xmax));
+        TVC_CHECK(run_source_net(ctx, s, ws, dry, content, f0, energy, amps, kern, B, T, cmax, xmax, fork ? ctx->ev_amps : nullptr));
     }
     ws.release(mk);
     if (!dry && !wave && !source_out) return 0;  // SourceNet.forward alone (decoder.py:126-134): the caller asked for amps / kernel only
     {
         ProfScope ps(ctx, s, dry, "dsp");
-        TVC_CHECK(run_dsp(ctx, s, ws, dry, f0, amps, kern, angle, seed, source, B, T, smax));
+        const DspFork fk{ctx->side, csum, ctx->ev_amps};
+        TVC_CHECK(run_dsp(ctx, s, ws, dry, f0, amps, kern, angle, seed, source, B, T, smax, fork ? &fk : nullptr));
+        if (fork) {      // join: the side stream's whole chain (harmonics, FilterNet's input contraction) is behind this event
+            TVC_HIP(ctx, hipEventRecord(ctx->ev_join2, ctx->side));
+            TVC_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join2, 0));
+        }
     }
     ws.release(mk);
     if (!dry && !wave) return 0;                 // ... or for Decoder.dsp's output (decoder.py:259-266) without the FilterNet pass
     ProfScope ps(ctx, s, dry, "filter_net");
-    TVC_CHECK(run_filter(ctx, s, ws, dry, content, f0, energy, source, wave, B, T, nullptr, cmax, smax, fslots, content_bound != nullptr));
+    TVC_CHECK(run_filter(ctx, s, ws, dry, content, f0, energy, source, wave, B, T, nullptr, cmax, smax, fslots, content_bound != nullptr, x0, fork ? ctx->ev_join2 : nullptr));
     ws.release(mk);
     return 0;
 }

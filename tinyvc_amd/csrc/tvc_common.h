@@ -98,6 +98,7 @@ struct tvc_ctx {
     std::vector<hipEvent_t> event_pool;       // recycled hipEvents: no hipEventCreate on the hot path
     hipStream_t side = nullptr;               // fork/join stream: the pitch estimator runs beside the SSL chain
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_amps = nullptr;      // the decoder's fork: FilterNet's input contraction beside SourceNet / dsp (decoder.hip run_decoder)
     tvc::RagHost* rag = nullptr;              // the ragged batch the drivers are currently running for (ragged.h); nullptr = equal lengths
     int rag_batch_frames = 0;                 // tvc_ctx_set_ragged_batch_frames: frames per in-kernel batch of THIS context's ragged calls (0 = the default)
     bool enc_ready = false, dec_ready = false;  // which checkpoint groups tvc_finalize_weights packed
@@ -174,7 +175,7 @@ struct ProfScope {
     int idx = -1;
     ProfScope(tvc_ctx* c, hipStream_t st, bool dry, const char* name) : ctx(c), s(st) {
         if (!c || !c->profiling || dry) return;
-        if (c->profiling == 2 && std::strcmp(name, "filter_net") != 0) return;     // the roofline's region alone: 2 event records per step instead of 38
+        if (c->profiling == 2 && std::strncmp(name, "filter_net", 10) != 0) return;     // the roofline's regions alone (filter_net, and filter_net.input@side when the input contraction is forked): 2-4 event records per step instead of 38
         tvc_prof_region r;
         r.name = name;
         auto take = [&](hipEvent_t* e) {
@@ -268,10 +269,19 @@ struct FilterTaps {   // optional copies of FilterNet's block outputs (tvc_filte
 // guard of the fp16 split, conv3s.h); nullptr = the stage computes (or keeps) its own
 int run_filter(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* content, const float* f0, const float* energy,
                const float* source, float* wave, int B, int T, const FilterTaps* taps = nullptr, const float* cmax = nullptr, const float* smax = nullptr,
-               float* zeroed_slots = nullptr, bool x_slot_set = false);      // zeroed_slots: kFilterSlots x utterances floats the caller has already zeroed on this
-                                                                             // stream; x_slot_set: ... and has set slot kFilterSlotX to flt_in_bw |content|max + flt_in_bb
+               float* zeroed_slots = nullptr, bool x_slot_set = false, float* x_pre = nullptr, hipEvent_t x_ready = nullptr);      // zeroed_slots: kFilterSlots x utterances floats the caller has already zeroed on this
+                                                                             // stream; x_slot_set: ... and has set slot kFilterSlotX to flt_in_bw |content|max + flt_in_bb; x_pre / x_ready: the input contraction's output, already
+                                                                             // launched by the caller on another stream, and the event that says it is there (run_decoder's fork)
+// run_decoder's fork (decoder.hip): the harmonic oscillator on the context's side stream beside SourceNet's output GEMMs and the noise branch.
+// csum = the frame sums' buffer, already holding the scanned sums (launched on `side` by the caller); amps_ready = recorded on the launch stream
+// behind the amplitudes' GEMM; the caller joins `side` itself.
+struct DspFork {
+    hipStream_t side;
+    double* csum;
+    hipEvent_t amps_ready;
+};
 int run_dsp(tvc_ctx*, hipStream_t, Ws&, bool dry, const float* f0, const float* amps, const float* kern,
-            const float* angle, uint64_t seed, float* source, int B, int T, float* smax = nullptr);
+            const float* angle, uint64_t seed, float* source, int B, int T, float* smax = nullptr, const DspFork* fk = nullptr);
 int run_sola(tvc_ctx*, hipStream_t, const float* y, float* sola_buf, const float* fade_in, float* out, int32_t* shift_out,
              int S, int64_t Ly, int block, int use_pv);
 int run_stream_push(tvc_ctx* ctx, hipStream_t s, float* buf, const float* blocks, int S, int n, int m);
