@@ -13,9 +13,10 @@
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all
  *     work is enqueued asynchronously on it; nothing here synchronises the device (one exception: the first use of a prepared
  *     index this process did not prepare itself reads its 24-byte header, see tvc_knn_prepare_index_f32).  Outside a stream
- *     capture the encoder forks its pitch estimator onto a context-owned side stream and joins it back onto `stream` with
- *     events before the call returns, so `stream` order is all a caller ever sees; while `stream` is being captured the pitch
- *     estimator stays on `stream` (one chain replays faster than the fork inside a graph: DESIGN.md section 4);
+ *     capture the encoder forks its pitch estimator, and the decoder its harmonic oscillator and FilterNet's input contraction,
+ *     onto a context-owned side stream and joins them back onto `stream` with events before the call returns, so `stream` order
+ *     is all a caller ever sees; while `stream` is being captured (and for ragged batches, in the decoder) everything stays on
+ *     `stream` (one chain replays faster than a fork inside a graph: DESIGN.md section 4).  Results do not depend on it;
  *   - stream capture: every call may be captured into a HIP graph, with two rules.  Kernel arguments are baked into the graph,
  *     so a call that draws its own noise phases (noise_angle = NULL: the seed is an argument) is refused with TVC_ERR_STATE while
  *     capturing - pass noise_angle and refill that buffer between replays.  And a prepared index must have been used (or
