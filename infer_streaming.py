@@ -22,7 +22,6 @@ import torch
 from tinyvc_amd import audio_io
 from tinyvc_amd.module.infer import BatchedStreamInfer, Generator
 from tinyvc_amd.module.tinyvc import Decoder, Encoder
-from tinyvc_amd.resample import gain, resample
 
 
 def build_parser():
@@ -49,10 +48,11 @@ def build_parser():
     return p
 
 
-def int16_blocks_from_wav(path, sample_rate, chunk):
-    """What `stream_input.read(chunk)` yields in the reference: int16 mono blocks at `sample_rate`."""
+def int16_blocks_from_wav(path, sample_rate, chunk, engine):
+    """What `stream_input.read(chunk)` yields in the reference: int16 mono blocks at `sample_rate` (the file is resampled on the device,
+    tvc_resample_f32, like every other resampling of the entry scripts; tinyvc_amd/resample.py is that kernel's host checker, not a second path)."""
     wf, sr = audio_io.load(path)
-    wf = resample(wf.mean(dim=0, keepdim=True), sr, sample_rate)[0]
+    wf = engine.resample(wf.mean(dim=0, keepdim=True).to(engine.device), sr, sample_rate)[0].cpu()
     pcm = (wf.clamp(-1, 1) * 32767).to(torch.int16).numpy()
     n = len(pcm) // chunk
     return [pcm[i * chunk:(i + 1) * chunk] for i in range(n)]
@@ -103,7 +103,7 @@ def main(argv=None):
             if sloop is not None:
                 sloop.write(out)
 
-    blocks = int16_blocks_from_wav(args.input_wav, args.sample_rate, args.chunk)
+    blocks = int16_blocks_from_wav(args.input_wav, args.sample_rate, args.chunk, gen.engine(device))
     outs, lat = [], []
     for blk in blocks:
         torch.cuda.synchronize(device)
