@@ -540,7 +540,7 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
     }
     // FilterNet's input contraction (768 -> 384 at the frame rate: 48 us at the bench shape) reads nothing SourceNet or the DSP stage produce and
     // its output is first read by Upsample 0, behind the whole down path: outside a stream capture (a fork inside a replayed graph costs more than
-    // it hides) and for equal-length batches (a ragged batch's tables are built on the launch stream) it runs on the
+    // it hides) it runs on the
     // context's side stream - free again since the encoder joined its pitch chain - beside SourceNet's small launches and the vector-ALU-bound
     // oscillator, and run_filter waits for it where the up path begins.
     float* x0 = nullptr;
@@ -549,7 +549,7 @@ int run_decoder(tvc_ctx* ctx, hipStream_t s, Ws& ws, bool dry, const float* cont
     if (wave || dry) {      // (a dry run sizes the workspace for the full decoder whatever pointers it was handed)
         x0 = ws.get<float>((size_t)B * 384 * T);
         csum = ws.get<double>((size_t)B * kHarm * T);
-        fork = !dry && ctx->side && !ctx->rag && ctx->ev_fork2 && ctx->ev_join2 && ctx->ev_amps;
+        fork = !dry && ctx->side && ctx->ev_fork2 && ctx->ev_join2 && ctx->ev_amps;      // (a ragged batch too: the side stream's kernels read its base tables only - rag_setup built them on s in front of the fork -, no column-tile table)
         if (fork) {
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) fork = false;

@@ -5,8 +5,8 @@ bench.py reads for `roofline.traffic`.
 
     python tools/filter_traffic.py FETCH.db WRITE.db profiles/rNN_filter_traffic_pmc.json
 
-FilterNet's launches of a step are the dispatches from the content/f0 input contraction
-(igemm ... EpiSumCond) through the second fused ups.4 kernel (up24s_kernel<U24S<..., true, ...>> / up24_kernel<Up24Cfg<..., true, ...>>).
+FilterNet's launches of a step are its content/f0 input contraction (gemm ... EpiSumCond, launched early on the library's side stream) and the
+dispatches from downs.0 (down0s_kernel) through the second fused ups.4 kernel (up24s_kernel<U24S<..., true, ...>>).
 FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 B);
 the doubling is re-checked here on the fused ups.4 first-half kernel, whose byte counts are known.
 """
@@ -35,14 +35,20 @@ def is_up24(name, second):
 
 
 def filter_segments(disp):
-    """[(first, last)] index ranges of FilterNet launches, one per step."""
-    segs, start = [], None
-    for i, (name, _, _) in enumerate(disp):
+    """[[indices]] of FilterNet's launches, one list per step: its input contraction + everything from downs.0 (down0s_kernel) through the
+    second fused ups.4 kernel.  Since round 6 the input contraction is launched EARLY, on the library's side stream (decoder.hip run_decoder),
+    so it is no longer adjacent: of the EpiSumCond contractions dispatched since the previous step's last FilterNet launch - SourceNet's
+    768 -> 128 and FilterNet's 768 -> 384 - it is the longer one (three times the rows)."""
+    segs, start, gemms = [], None, []
+    for i, (name, _, dur) in enumerate(disp):
         if "EpiSumCond" in name:
-            start = i                                   # the last one before the fused ups.4 kernels is FilterNet's input layer
+            gemms.append((dur, i))
+        if "down0s_kernel" in name and start is None:
+            start = i
         if start is not None and is_up24(name, second=True):
-            segs.append((start, i))
-            start = None
+            g = max(gemms)[1] if gemms else None
+            segs.append(([g] if g is not None and g < start else []) + list(range(start, i + 1)))
+            start, gemms = None, []
     return segs
 
 
@@ -52,20 +58,20 @@ def main(fetch_db, write_db, out):
     sf, sw = filter_segments(f), filter_segments(w)
     assert sf and len(sf) == len(sw), (len(sf), len(sw))
     k = len(sf) - 1                                       # last (steady-state) step
-    fa, fb = sf[k]
-    wa, wb = sw[k]
-    fetch_kb = sum(v for _, v, _ in f[fa:fb + 1])
-    write_kb = sum(v for _, v, _ in w[wa:wb + 1])
-    ms = sum(d for _, _, d in f[fa:fb + 1]) / 1e6
-    halfA = [x for x in f[fa:fb + 1] if is_up24(x[0], second=False)]
-    halfAw = [x for x in w[wa:wb + 1] if is_up24(x[0], second=False)]
+    fsel, wsel = [f[i] for i in sf[k]], [w[i] for i in sw[k]]
+    assert len(fsel) == len(wsel), (len(fsel), len(wsel))
+    fetch_kb = sum(v for _, v, _ in fsel)
+    write_kb = sum(v for _, v, _ in wsel)
+    ms = sum(d for _, _, d in fsel) / 1e6
+    halfA = [x for x in fsel if is_up24(x[0], second=False)]
+    halfAw = [x for x in wsel if is_up24(x[0], second=False)]
     res = {
         "note": "FilterNet launches of one bench step (64 x 4 s, default bench.py workload): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                 "separate passes (with --kernel-trace only), summed by tools/filter_traffic.py. FETCH_SIZE is doubled as "
                 "MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B); calibration: the fused ups.4 first-half "
                 "kernel writes x1 = 64*24*96000*4 B = 576000 KB (WRITE_SIZE should report exactly that) and reads cond 576000 KB plus "
                 "the low-rate x with halo (~120000 KB), to be compared with 2*FETCH_SIZE.",
-        "launches_per_step": fb - fa + 1,
+        "launches_per_step": len(fsel),
         "fetch_size_kb": fetch_kb,
         "write_size_kb": write_kb,
         "traffic_bytes": (2.0 * fetch_kb + write_kb) * 1024.0,
