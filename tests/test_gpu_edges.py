@@ -240,3 +240,41 @@ def test_noise_angle_map_equals_the_reference_expression():
     torch.manual_seed(1234)
     b = torch.rand(3, 961, 17, device=DEV) * 2 * math.pi - math.pi
     assert torch.equal(a, b)
+
+
+def test_seeded_draw_is_refused_inside_a_stream_capture_and_push_equals_roll(gen):
+    """C-ABI rules of round 6.  (1) noise_angle = NULL makes the seed a kernel argument, which a capture would bake into the graph - every
+    replay the same noise -: the call is refused with TVC_ERR_STATE while the stream is capturing, launches nothing, and the same call with
+    phases passes.  (2) tvc_stream_push_f32 is stream.py:69-70's roll + slice assignment, bit for bit."""
+    from tinyvc_amd.engine import _ptr
+    eng = gen.engine(DEV)
+    B, T = 2, 12
+    f0 = (torch.rand(B, 1, T, device=DEV) * 200 + 80).contiguous()
+    amps = torch.rand(B, 15, T, device=DEV).contiguous()
+    kern = torch.rand(B, 961, T, device=DEV).contiguous()
+    angle = synth.synth_angle(B, T, 4).to(DEV)
+    src = torch.zeros(B, 16, T * 480, device=DEV)
+    eager = eng.dsp(f0, amps, kern, noise_angle=angle)
+    p, n = eng._wsargs(B, T * 480)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s = eng._stream()
+        rc_null = eng.lib.tvc_dsp_f32(eng.ctx, s, _ptr(f0), _ptr(amps), _ptr(kern), None, 123, _ptr(src), B, T, p, n)
+        rc_ok = eng.lib.tvc_dsp_f32(eng.ctx, s, _ptr(f0), _ptr(amps), _ptr(kern), _ptr(angle), 0, _ptr(src), B, T, p, n)
+    assert rc_null == -3, (rc_null, eng.lib.tvc_last_error(eng.ctx))            # TVC_ERR_STATE
+    assert rc_ok == 0
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(src, eager), "the captured call with injected phases replays the eager result"
+
+    buf = torch.randn(5, 13440, device=DEV)
+    blk = torch.randn(5, 1920, device=DEV)
+    want = torch.roll(buf, -1920, dims=1)
+    want[:, -1920:] = blk
+    got = eng.stream_push(buf.clone(), blk)
+    assert torch.equal(got, want)
+    odd = torch.randn(3, 2000, device=DEV)                     # a buffer that is not a multiple of the workgroup, block = almost all of it
+    b2 = torch.randn(3, 1999, device=DEV)
+    w2 = torch.cat([odd[:, 1999:], b2], dim=1)
+    assert torch.equal(eng.stream_push(odd.clone(), b2), w2)
