@@ -47,5 +47,32 @@ for bad in (lambda: gen.convert(wf[:, :100], tgt, 0.0), lambda: gen.convert(wf, 
         print("no error?")
     except Exception as e:  # noqa: BLE001
         print("error path:", type(e).__name__)
+# round 6: a foreign blob's header check (a copy passes, a blob of another format version / N is refused), the per-context ragged cap, the
+# general match_features kernel's host side, the stream push, the ragged plan with a cap
+blob, n = eng.knn_prepare(tgt[0])
+src = synth.synth_tensor("q", (1, 768, 20), seed=4).to(dev)
+keep = [blob.clone()]      # (kept alive: the registry is keyed by device address, a recycled address inherits its record until tvc_knn_forget)
+ok = eng.knn_match(src, keep[0], n)
+print("foreign blob (copy)", tuple(ok.shape))
+for word, value in ((5, 1), (2, n + 1)):
+    bad_blob = blob.clone()
+    keep.append(bad_blob)
+    bad_blob.view(torch.int32)[word] = value
+    try:
+        eng.knn_match(src, bad_blob, n)
+        print("no error?")
+    except Exception as e:  # noqa: BLE001
+        print("error path:", type(e).__name__)
+eng.set_ragged_batch_frames(30)
+out = gen.convert(wf, tgt, 0.0, lengths=[19200, 9600, 14400])
+eng.set_ragged_batch_frames(0)
+print("ragged with a 30-frame cap", tuple(out.shape))
+from tinyvc_amd.module.tinyvc import match_features  # noqa: E402
+for k, m in ((1, "cos"), (8, "L2"), (3, "IP")):
+    o, i = match_features(src, tgt, k=k, metrics=m, return_indices=True)
+print("general match", tuple(o.shape), tuple(i.shape))
+buf = torch.zeros(2, 13440, device=dev)
+eng.stream_push(buf, wf[:2, :1920])
+print("stream push", float(buf[:, -1920:].abs().sum()) > 0)
 torch.cuda.synchronize()
 print("done")

@@ -12,9 +12,9 @@ cd "$ROOT/tinyvc_amd/csrc"
 RT=$(gcc -print-file-name=libasan.so)
 if [ "$1" = "build" ]; then
   mkdir -p /tmp/tvc_asan
-  FL="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Wno-unused-function -ffp-contract=on -fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer"
+  FL="--offload-arch=gfx950 -O1 -Xarch_device -O3 -Xarch_device -g0 -g -std=c++17 -fPIC -Wno-unused-function -ffp-contract=on -fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer"
   objs=""
-  for f in api frontdoor frontend fft encoder knn decoder filter_up24s conv48s sola; do
+  for f in api ragged frontdoor frontend fft encoder knn knn_general decoder filter_up24s conv48s sola; do      # = tinyvc_amd/build.py SOURCES
     /opt/rocm/bin/hipcc $FL -c $f.hip -o /tmp/tvc_asan/$f.o &
     objs="$objs /tmp/tvc_asan/$f.o"
   done
