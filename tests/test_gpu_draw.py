@@ -52,9 +52,12 @@ def test_drawn_call_equals_the_injected_hash_and_the_oracle(gen, B, T):
     assert torch.equal(drawn, injected), f"B = {B}, T = {T}: the library's draw is not the restated hash"
     with oracle_one_thread():
         ref = R.convert(enc_sd, dec_sd, wf[:1], tgt, 0.5, angle[:1])
-    d = rms(drawn[0].cpu() - ref[0])
-    print(f"[draw] B = {B}, T = {T}: drawn == injected(hash); row 0 vs the oracle on the drawn phases {d:.3e}")
-    assert d <= 1e-4, d
+    ref_all = R.convert(enc_sd, dec_sd, wf[:1], tgt, 0.5, angle[:1])                     # the host's default thread count
+    d, spread = rms(drawn[0].cpu() - ref[0]), rms(ref_all[0] - ref[0])
+    print(f"[draw] B = {B}, T = {T}: drawn == injected(hash); row 0 vs the oracle on the drawn phases {d:.3e} (the oracle's own 1-thread-vs-all spread {spread:.3e})")
+    # the bit-exact link above is the test of the draw; this is the live oracle on this host (measured 3e-5 ... 9e-5): north_star's gate, or
+    # the CPU path's own reproducibility on the host where that is larger (test_gpu_cfg3.py's rule)
+    assert d <= max(1e-4, 1.5 * spread), (d, spread)
 
 
 @pytest.mark.gpu
@@ -79,8 +82,9 @@ def test_drawn_ragged_call_equals_the_injected_hash(gen):
     b = 3
     with oracle_one_thread():
         ref = R.convert(enc_sd, dec_sd, wf[b:b + 1, :lens[b]], tgt, -1.0, angle[b:b + 1, :, :frames[b]])
-    d = rms(drawn[b, :lens[b]].cpu() - ref[0])
-    assert d <= 1e-4, d
+    ref_all = R.convert(enc_sd, dec_sd, wf[b:b + 1, :lens[b]], tgt, -1.0, angle[b:b + 1, :, :frames[b]])
+    d, spread = rms(drawn[b, :lens[b]].cpu() - ref[0]), rms(ref_all[0] - ref[0])
+    assert d <= max(1e-4, 1.5 * spread), (d, spread)
 
 
 def test_the_draw_is_uniform_on_minus_pi_pi():
